@@ -1,0 +1,125 @@
+"""oracle/raymarch.py against the fixtures the REFERENCE's own Python produced
+(tests/golden/make_golden.py).  This is what pins the oracle: the reference has no tests
+of its own for this path.  Tolerances: the generating run is torch-CPU fp32; a different host
+may take a different SIMD path inside exp/log/erf/sin, so equality is held to 2e-6 (abs, on
+O(1) quantities) rather than bit-for-bit.  In the authoring container the differences are 0.
+"""
+import pytest
+import torch
+
+import helpers as H
+from oracle import raymarch as rm
+
+TOL = 2e-6
+
+
+def test_g1_g2_step_functions():
+    fx = H.load("stepfun.npz")
+    td, wd = rm.dilate_weights(fx["t"], fx["w"], float(fx["dilation"]), 0.0, 1.0)
+    assert H.maxdiff(td, fx["t_dilate"]) <= TOL
+    assert H.maxdiff(wd, fx["w_dilate"]) <= TOL
+    t_in = fx["t_dilate"][..., 1:-1]
+    for frac in ("1.0", "0.25"):
+        got = rm.sample_fenceposts(t_in, fx[f"logits_{frac}"], 128, 0.0, 1.0)
+        assert H.maxdiff(got, fx[f"sample_eval_{frac}"]) <= TOL
+        assert (got[..., 1:] >= got[..., :-1]).all()
+    got = rm.sample_fenceposts(t_in, fx["logits_0.25"], 32, 0.0, 1.0, jitter=fx["sample_train_jitter"])
+    assert H.maxdiff(got, fx["sample_train"]) <= TOL
+    t0 = torch.tensor([[0.0, 1.0]]).expand(fx["t"].shape[0], 2)
+    got = rm.sample_fenceposts(t0, torch.zeros(fx["t"].shape[0], 1), 64, 0.0, 1.0)
+    assert H.maxdiff(got, fx["sample_level0"]) <= TOL
+    assert H.maxdiff(rm.percentiles_of_stepfun(fx["pct_t"], fx["pct_w"]), fx["pct"]) <= 8 * TOL
+
+
+def test_g3_g4_cone_cast_and_contraction():
+    fx = H.load("cast.npz")
+    args = [fx[k] for k in ("tdist", "origins", "directions", "cam_dirs", "radii")]
+    m, s, t = rm.cone_multisamples(*args, fx["eval_rand_vec"], 0.5)
+    assert H.maxdiff(m, fx["eval_means"]) <= 8 * TOL      # |means| up to ~8
+    assert H.maxdiff(s, fx["eval_stds"]) <= TOL
+    assert H.maxdiff(t, fx["eval_t"]) <= 8 * TOL
+    m, s, t = rm.cone_multisamples(*args, fx["train_rand_vec"], 0.5, flip=fx["train_flip"], spin=fx["train_spin"])
+    assert H.maxdiff(m, fx["train_means"]) <= 8 * TOL
+    assert H.maxdiff(s, fx["train_stds"]) <= TOL
+    cm, cs = rm.contract_points(fx["contract_in_mean"], fx["contract_in_std"])
+    assert H.maxdiff(cm, fx["contract_mean"]) <= TOL
+    assert H.maxdiff(cs, fx["contract_std"]) <= TOL
+    assert (cm.norm(dim=-1) <= 2 + 1e-6).all()
+
+
+def test_g5_field_on_small_grid():
+    fx = H.load("field.npz")
+    spec = rm.make_spec("tiny")
+    sd = H.state_for(fx, spec)
+    for name, fs in (("nerf", spec.nerf), ("prop", spec.props[0])):
+        raw, x, coord, feat = rm.field_density_features(fs, sd, fx["means"], fx["stds"])
+        assert H.maxdiff(feat, fx[f"{name}_features"]) <= TOL
+        assert H.maxdiff(raw, fx[f"{name}_raw_density"]) <= 4 * TOL
+        assert H.maxdiff(x, fx[f"{name}_bottleneck"]) <= 4 * TOL
+        res = rm.field_forward(fs, sd, fx["means"], fx["stds"], fx["viewdirs"])
+        assert H.maxdiff(res["density"], fx[f"{name}_density"]) <= 4 * TOL
+        assert H.maxdiff(res["rgb"], fx[f"{name}_rgb"]) <= 4 * TOL
+        assert H.maxdiff(res["coord"], fx[f"{name}_coord"]) <= TOL
+    raw, _, _, _ = rm.field_density_features(spec.nerf, sd, fx["nowarp_means"], fx["nowarp_stds"], no_warp=True)
+    assert H.maxdiff(raw, fx["nowarp_raw_density"]) <= 4 * TOL
+    # the int32 wrap of grid_sizes**2 (models.py:495) is part of the contract
+    _, _, sizes, _ = spec.nerf.layout()
+    assert int((sizes ** 2)[12]) == 131073 and int((sizes ** 2)[15]) == 1048577
+
+
+def test_g6_alpha_and_composite():
+    fx = H.load("composite.npz")
+    w = rm.alpha_weights(fx["density"], fx["tdist"], fx["dirs"])
+    assert H.maxdiff(w, fx["weights"]) <= TOL
+    assert H.maxdiff(rm.alpha_weights(fx["density"], fx["tdist"], fx["dirs"], True), fx["weights_opaque"]) <= TOL
+    out = rm.composite(fx["rgbs"], w, fx["tdist"], 1.0, fx["far"], extras=True)
+    for k, v in out.items():
+        assert H.maxdiff(v, fx["out_" + k]) <= (300 * TOL if k == "depth" else 8 * TOL), k
+    assert (out["depth"][out["acc"] < 0.6] == 300).all() and (out["acc"] < 0.6).any() and (out["acc"] >= 0.6).any()
+
+
+@pytest.mark.parametrize("name,kind,over", [
+    ("model_tiny.npz", "tiny", {}),
+    ("model_tinyR.npz", "tinyR", {}),
+    ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
+    ("model_train.npz", "tiny", {}),
+])
+def test_g7_g8_model_forward(name, kind, over):
+    fx = H.load(name)
+    spec = rm.make_spec(kind, **over)
+    sd = H.state_for(fx, spec)
+    train = "noise0_jitter" in fx
+    batch = H.batch_of(fx)
+    with torch.no_grad():
+        rend, hist = rm.model_forward(spec, sd, batch, H.noise_of(fx, spec.num_levels),
+                                      train_frac=float(fx["train_frac"]), compute_extras=not train,
+                                      eval_camidx=fx.get("eval_camidx"), training=train)
+    for lvl in range(spec.num_levels):
+        for k, v in rend[lvl].items():
+            want = fx[f"L{lvl}_{k}"]
+            assert H.maxdiff(v.reshape(want.shape), want) <= (300 * TOL if k == "depth" else 8 * TOL), (lvl, k)
+        for k in ("sdist", "weights", "density", "rgb", "coord"):
+            want = fx[f"L{lvl}_hist_{k}"]
+            assert H.maxdiff(hist[lvl][k].reshape(want.shape), want) <= 8 * TOL, (lvl, k)
+        if train:
+            assert H.maxdiff(hist[lvl]["loss_hash_decay"], fx[f"L{lvl}_hist_loss_hash_decay"]) <= TOL
+
+
+def test_g9_render_image_chunks():
+    fx = H.load("render_image.npz")
+    spec = rm.make_spec("tiny")
+    sd = H.state_for(fx, spec)
+    batch = H.batch_of(fx)
+    n = batch["origins"].shape[0]
+    chunk = int(fx["chunk"])
+    outs = []
+    with torch.no_grad():
+        for i0 in range(0, n, chunk):
+            sub = {k: v[i0:i0 + chunk] for k, v in batch.items()}
+            noise = [rm.LevelNoise(rand_vec=fx[f"noise{l}_rand_vec"][i0:i0 + chunk]) for l in range(spec.num_levels)]
+            rend, _ = rm.model_forward(spec, sd, sub, noise)
+            outs.append(rend[-1])
+    Hh, Ww = int(fx["H"]), int(fx["W"])
+    for k in [k[4:] for k in fx if k.startswith("out_")]:
+        got = torch.cat([o[k] for o in outs]).reshape((Hh, Ww) + outs[0][k].shape[1:])
+        assert H.maxdiff(got, fx["out_" + k]) <= (300 * TOL if k == "depth" else 8 * TOL), k
