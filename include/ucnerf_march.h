@@ -1,0 +1,183 @@
+/*
+ * ucnerf_march.h -- C ABI of libucnerf_march.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary for UC-NeRF's per-ray sampling + integration hot path.
+ * All entry points are `extern "C"`, take plain device/host pointers and sizes (no
+ * torch / ATen types), enqueue work on the HIP stream they are given and return
+ * immediately (asynchronous, like the reference's kernels).  Return value: 0 on
+ * success, non-zero on a precondition or launch failure; ucn_last_error() then holds
+ * the message (the Python host raises RuntimeError with it -- the counterpart of the
+ * reference's TORCH_CHECK / std::runtime_error, gridencoder.cu:15-18,381,398).
+ *
+ * "ref:" comments cite the interface each function replaces, relative to
+ * /root/reference/nerf/.
+ *
+ * Pointer residency: every `const float*` / `float*` data pointer is DEVICE memory
+ * unless the comment says HOST.  Small metadata (level offsets, grid sizes, the field
+ * descriptor structs) is HOST memory: the reference keeps `offsets` on the device and
+ * re-derives per-level constants inside every thread (gridencoder.cu:137-139); here
+ * they are derived once on the host and travel as kernel arguments, so host and
+ * device (and the CPU oracle) agree on them bit-for-bit.
+ */
+#ifndef UCNERF_MARCH_H
+#define UCNERF_MARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCN_MAX_LEVELS 24
+#define UCN_DTYPE_F32 0
+#define UCN_DTYPE_F16 1
+
+typedef void *ucn_stream_t; /* hipStream_t; NULL = the legacy default stream */
+
+/* ------------------------------------------------------------------ diagnostics */
+const char *ucn_last_error(void);
+/* ABI version: bump when a signature changes (checked by the Python loader). */
+uint32_t ucn_abi_version(void);
+/* HBM bandwidth probe: device-to-device copy kernel, returns 0 and leaves timing to the caller. */
+int ucn_probe_copy(const float *src, float *dst, uint64_t n_floats, ucn_stream_t stream);
+
+/* ------------------------------------------------- (b2) the `_gridencoder` operator
+ * ref: gridencoder/src/gridencoder.h:12-15, bindings.cpp:5-9, gridencoder.cu:448-503,639-645.
+ * Same argument order and meaning as the pybind functions; tensors become pointers,
+ * `offsets` is a HOST int32[L+1] array, `emb_dtype` says whether embeddings/outputs/grad
+ * are float32 or float16 (the reference dispatches on the tensor dtype, :467,498).
+ * Caller allocates every output (grid.py:47-52,77-82); grad_embeddings must be pre-zeroed.
+ * D in {2,3,4,5}, C in {1,2,4,8} else error (gridencoder.cu:376-399). */
+int ucn_grid_encode_forward(const float *inputs /*[B,D] in [0,1]*/, const void *embeddings /*[rows,C]*/,
+                            const int32_t *offsets_host /*[L+1]*/, void *outputs /*[L,B,C]*/,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                            void *dy_dx /*[B,L*D*C] or NULL*/, uint32_t gridtype, int align_corners,
+                            uint32_t interp, int emb_dtype, ucn_stream_t stream);
+
+int ucn_grid_encode_backward(const void *grad /*[L,B,C]*/, const float *inputs, const void *embeddings,
+                             const int32_t *offsets_host, void *grad_embeddings /*[rows,C] +=*/,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const void *dy_dx /*or NULL*/, void *grad_inputs /*[B,D] or NULL*/,
+                             uint32_t gridtype, int align_corners, uint32_t interp, int emb_dtype,
+                             ucn_stream_t stream);
+
+int ucn_grad_total_variation(const float *inputs, const float *embeddings, float *grad /*[rows,C] +=*/,
+                             const int32_t *offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C,
+                             uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                             ucn_stream_t stream);
+
+/* ------------------------------------------------- (b1) fused ray-march entry points
+ * These are what Model.forward (internal/models.py:97-365) calls instead of the
+ * unfused chain stepfun -> render.cast_rays -> coord.track_linearize -> GridEncoder ->
+ * MLP -> render.compute_alpha_weights -> render.volumetric_rendering. */
+
+/* One hash-grid + MLP "field" (ref: models.py:367-483 MLP.__init__; NerfMLP / PropMLP).
+ * HOST struct of DEVICE pointers in PyTorch nn.Linear layout ([out,in] row-major). */
+typedef struct ucn_field {
+    /* grid (ref: gridencoder/grid.py:96-149) */
+    const float *embeddings;         /* [rows, level_dim] float32 */
+    const int32_t *offsets_host;     /* HOST [num_levels+1] */
+    const int32_t *grid_sizes_host;  /* HOST [num_levels]  (grid.py:142; squared in int32, models.py:495) */
+    uint32_t num_levels, level_dim, base_resolution;
+    float log2_per_level_scale;
+    /* density MLP (models.py:438-441): Linear(F,64) ReLU Linear(64, n_bottleneck) */
+    const float *w_d0, *b_d0, *w_d1, *b_d1;
+    uint32_t n_bottleneck;           /* 1 for PropMLP (disable_rgb), else bottleneck_width */
+    /* colour MLP (models.py:456-483), NULL when n_bottleneck == 1 */
+    const float *w_c0, *b_c0;        /* [n_width, n_bottleneck + n_dir] */
+    const float *w_c1, *b_c1;        /* [n_width, n_width + n_bottleneck + n_dir] */
+    const float *w_rgb, *b_rgb;      /* [3, n_width] */
+    uint32_t n_width, n_dir;         /* n_dir = 3 + 6*deg_view = 27 */
+    float density_bias, rgb_premultiplier, rgb_bias, rgb_padding;
+    /* MFMA-ordered weight copies, filled by ucn_field_pack; size from ucn_field_packed_floats */
+    float *packed;
+} ucn_field_t;
+
+uint64_t ucn_field_packed_floats(const ucn_field_t *f);
+/* Re-pack after every weight update (render: once; train: once per step). */
+int ucn_field_pack(const ucn_field_t *f, ucn_stream_t stream);
+
+/* ref: stepfun.py:75-105 max_dilate_weights + models.py:168-191 (trim, anneal, logits) +
+ * stepfun.py:251-294 sample_intervals.  n_prev == 0 selects the first level (sdist=[0,1], w=[1]).
+ * u_table: DEVICE [S] = the linspace of stepfun.py:206 (eval) or :215 (train).
+ * jitter : NULL (eval) or DEVICE [N, jitter_cols] U[0,1) draws (stepfun.py:216). */
+int ucn_resample(const float *sdist_prev /*[N,n_prev+1]*/, const float *weights_prev /*[N,n_prev]*/,
+                 uint32_t n_prev, float dilation, float anneal, float resample_padding,
+                 const float *u_table, const float *jitter, uint32_t jitter_cols, float max_jitter,
+                 uint32_t N, uint32_t S, float *sdist_out /*[N,S+1]*/, ucn_stream_t stream);
+
+/* ref: render.py:139-146 -- the two cone cross-section axes from cam_dirs x rand_vec. */
+int ucn_cone_basis(const float *cam_dirs /*[N,3]*/, const float *rand_vec /*[N,3]*/, uint32_t N,
+                   float *basis_out /*[N,6] = e1,e2*/, ucn_stream_t stream);
+
+/* ref: render.py:94-152 cast_rays + coord.py:60-116 contraction + grid.py:158-174 /
+ * gridencoder.cu:87-199 + models.py:494-496 (erf damping, mean over the 6 multisamples).
+ * features_out layout [num_levels][N*S][level_dim]  (level-major like gridencoder.cu:108).
+ * flip/spin NULL = deterministic hexagon pattern (rand=False). coord_out/tmean_out optional. */
+int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, const float *near_ /*[N]*/,
+                       const float *far_ /*[N]*/, const float *origins, const float *directions,
+                       const float *basis /*[N,6]*/, const float *radii /*[N]*/,
+                       const float *flip /*[N,S]|NULL*/, const float *spin /*[N,S]|NULL*/,
+                       float std_scale, uint32_t N, uint32_t S, uint32_t levels_per_block,
+                       float *features_out, float *coord_out /*[N,S,3]|NULL*/,
+                       float *tmean_out /*[N,S]|NULL*/, ucn_stream_t stream);
+
+/* Same featurisation for caller-supplied Gaussians (ref: models.py:485-512 predict_density as
+ * called by extract.py:56-57,96): means [B,G,3], stds [B,G]; warp=0 skips the contraction. */
+int ucn_points_features(const ucn_field_t *f, const float *means, const float *stds, uint32_t B,
+                        uint32_t G, int warp, uint32_t levels_per_block, float *features_out /*[L][B][C]*/,
+                        float *coord_out /*[B,3]|NULL*/, ucn_stream_t stream);
+
+/* ref: coord.py:214-225 pos_enc(viewdirs) folded through the direction columns of
+ * lin_second_stage_{0,1}: per-ray additive terms for the colour MLP. */
+int ucn_field_dir_bias(const ucn_field_t *f, const float *viewdirs /*[N,3]*/, uint32_t N,
+                       float *dir_bias_out /*[N,2,n_width]*/, ucn_stream_t stream);
+
+/* ref: models.py:507-508,581,599-674 -- density MLP, softplus, colour MLP, sigmoid + padding.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), activations chained through registers.
+ * features [L][B][C]; rays_of_sample: sample b belongs to ray b / samples_per_ray.
+ * bottleneck_out optional [B, n_bottleneck]. rgb_out NULL for PropMLP. */
+int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32_t B, uint32_t samples_per_ray,
+                  const float *dir_bias /*[B/spr,2,n_width]|NULL*/, float *density_out /*[B]*/,
+                  float *rgb_out /*[B,3]|NULL*/, float *bottleneck_out, ucn_stream_t stream);
+
+/* ref: render.py:155-174 compute_alpha_weights + :177-244 volumetric_rendering +
+ * stepfun.py:329-339 weighted_percentile.  rgbs NULL = PropMLP zeros (models.py:584-585).
+ * out_main [N,5] = r,g,b,depth,acc ; out_extras [N,4] = distance_mean, p5, median, p95 (or NULL). */
+int ucn_composite(const float *density /*[N,S]*/, const float *rgbs /*[N,S,3]|NULL*/,
+                  const float *sdist /*[N,S+1]*/, const float *near_, const float *far_,
+                  const float *directions, float bg_intensity, int opaque_background, uint32_t N,
+                  uint32_t S, float *weights_out /*[N,S]*/, float *out_main, float *out_extras,
+                  ucn_stream_t stream);
+
+/* ------------------------------------------------- sky layer + colour correction
+ * ref: models.py:326-337,743-904 (sky NeRF, 120 samples, 8x256 MLP) and
+ * extrinsic_optimizer.py:4-48 + models.py:339-363 (per-camera 3x4 affine). */
+typedef struct ucn_sky {
+    const float *w_pts[8], *b_pts[8]; /* pts_linears.{0..7}; layer 5 is [256,259] */
+    const float *w_alpha, *b_alpha, *w_feat, *b_feat, *w_view, *b_view, *w_rgb, *b_rgb;
+    float *packed;
+} ucn_sky_t;
+uint64_t ucn_sky_packed_floats(void);
+int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream);
+uint64_t ucn_sky_workspace_floats(uint32_t N);
+/* t_vals: DEVICE [120] = linspace(0,1,120) (models.py:870); far0_times_1p5 = 1.5*far[0] (:329);
+ * workspace: DEVICE ucn_sky_workspace_floats(N) floats (per-ray view bias + per-sample raw outputs). */
+int ucn_sky_render(const ucn_sky_t *s, const float *origins, const float *directions,
+                   const float *cam_dirs, const float *far_ /*[N]*/, float far0_times_1p5,
+                   const float *t_vals, uint32_t N, float *workspace, float *sky_rgb_out /*[N,3]*/,
+                   ucn_stream_t stream);
+
+/* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
+int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,
+              uint32_t K, uint32_t Nout, int relu, float *y /*[M,Nout]*/, ucn_stream_t stream);
+/* rgb' = A[idx] rgb + b[idx] (+ (1-acc_last) (A_sky sky + b_sky)); ref: models.py:350-354 */
+int ucn_apply_affine(const float *rgb_in /*[N,3]*/, const float *affine /*[M,12]*/,
+                     const int64_t *ray_to_row /*[N]|NULL = row 0*/, const float *weights_last /*[N,S]|NULL*/,
+                     uint32_t S, const float *sky_rgb /*[N,3]|NULL*/, const float *affine_sky /*[M,12]|NULL*/,
+                     uint32_t N, float *rgb_out /*[N,3]*/, ucn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCNERF_MARCH_H */

@@ -58,3 +58,38 @@ def maxdiff(a, b):
     d = (a - b).abs()
     d[same] = 0
     return float(d.max()) if d.numel() else 0.0
+
+
+# ------------------------------------------------------------------ HIP-side helpers (gpu tests)
+def hip_model(spec, sd, device="cuda", **model_kw):
+    """ucnerf_amd Model configured like an oracle PathSpec and loaded with an oracle state dict."""
+    from ucnerf_amd.internal import configs, models
+
+    def fkw(fs):
+        return dict(grid_disired_resolution=fs.grid_desired_resolution, grid_level_dim=fs.grid_level_dim,
+                    grid_log2_hashmap_size=fs.grid_log2_hashmap_size, bottleneck_width=fs.bottleneck_width,
+                    net_width_viewdirs=fs.net_width_viewdirs)
+    cfg = configs.Config(model_sky=spec.model_sky, brightness_correction=spec.brightness_correction,
+                         training_views=spec.training_views, vis_num_rays=spec.vis_num_rays)
+    with models.bindings(NerfMLP=fkw(spec.nerf), PropMLP=fkw(spec.props[0])):
+        model = models.Model(config=cfg, num_levels=spec.num_levels, num_prop_samples=spec.num_prop_samples,
+                             num_nerf_samples=spec.num_nerf_samples, opaque_background=spec.opaque_background,
+                             prop_desired_grid_size=list(spec.prop_desired_grid_size), **model_kw)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith(".idx") for k in missing), missing
+    return model.to(device).eval(), cfg
+
+
+def to_dev(batch, device="cuda"):
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def pin_noise(batch, noise, device="cuda"):
+    """Feed the oracle's random draws to the HIP Model through its optional batch keys."""
+    b = dict(batch)
+    b["rand_vec"] = torch.cat([nz.rand_vec for nz in noise], dim=-1).to(device)
+    if noise[0].jitter is not None:
+        b["march_noise"] = [dict(jitter=nz.jitter.to(device), flip=nz.flip.to(device), spin=nz.spin.to(device))
+                            for nz in noise]
+    return b

@@ -1,0 +1,297 @@
+"""HIP path vs the golden fixtures of the reference and vs the CPU oracle (-m gpu).
+
+Everything goes through the C ABI (ctypes -> libucnerf_march.so).  Bars: bit-exact for the hash
+grid forward (integer addressing + a fixed fmaf chain); fp32 tolerances stated per quantity for the
+rest; 1e-4 L-inf on RGB end to end (BASELINE.json north_star).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import grid_cpu
+from oracle import raymarch as rm
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+# ------------------------------------------------------------------ a7 / a15: the `_gridencoder` op
+@pytest.mark.parametrize("D,C", [(3, 2), (3, 4), (2, 2), (3, 1), (3, 8), (4, 2)])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_grid_forward_bitexact(D, C, interp):
+    from ucnerf_amd.gridencoder import _backend
+    rng = np.random.default_rng(D * 10 + C)
+    L, T = 9, 12
+    pls, offsets, sizes, _ = grid_cpu.table_layout(L, C, 16, 4096, T, input_dim=D)
+    table = torch.from_numpy(rng.random((int(offsets[-1]), C), dtype=np.float32) * 2 - 1)
+    x = rng.random((5000, D), dtype=np.float32)
+    x[:4] = [[0.0] * D, [1.0] * D, [np.nextafter(np.float32(1), np.float32(2))] * D, [-1e-7] * D]
+    k = rng.integers(1, 4000, size=(64, D)).astype(np.float32)
+    x[4:68] = (k - np.float32(0.5)) / np.float32(4095.0)
+    x[68:100] = rng.random((32, D), dtype=np.float32) * 3 - 1
+    x = torch.from_numpy(x)
+    S = np.log2(pls)
+    want = torch.empty(L, len(x), C)
+    wjac = torch.empty(len(x), L * D * C)
+    grid_cpu.grid_encode_forward(x, table, offsets, want, len(x), D, C, L, S, 16, wjac, 0, False, interp)
+    got = torch.empty(L, len(x), C, device="cuda")
+    gjac = torch.empty(len(x), L * D * C, device="cuda")
+    _backend.grid_encode_forward(dev(x), dev(table), dev(offsets), got, len(x), D, C, L, S, 16, gjac, 0, False, interp)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(gjac.cpu(), wjac)
+
+
+def test_grid_forward_baseline_layout_quirk_levels():
+    """L=16 / T=2^19: levels 12 and 13 fall back to wrapped 'dense' strides (uint32 overflow in
+    gridencoder.cu:71-75); the device addressing must follow."""
+    from ucnerf_amd.gridencoder import _backend
+    pls, offsets, sizes, _ = grid_cpu.table_layout(16, 2, 16, 524288, 19)
+    g = torch.Generator().manual_seed(0)
+    table = torch.rand(int(offsets[-1]), 2, generator=g) * 2 - 1
+    x = torch.rand(20000, 3, generator=g)
+    want = torch.empty(16, len(x), 2)
+    grid_cpu.grid_encode_forward(x, table, offsets, want, len(x), 3, 2, 16, 1.0, 16, None, 0, False, 0)
+    got = torch.empty(16, len(x), 2, device="cuda")
+    _backend.grid_encode_forward(dev(x), dev(table), dev(offsets), got, len(x), 3, 2, 16, 1.0, 16, None, 0, False, 0)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_grid_backward_and_tv():
+    from ucnerf_amd.gridencoder import _backend
+    rng = np.random.default_rng(7)
+    L, C, D = 8, 2, 3
+    pls, offsets, sizes, _ = grid_cpu.table_layout(L, C, 16, 2048, 11)
+    B = 4000
+    x = torch.from_numpy(rng.random((B, D), dtype=np.float32))
+    x[:50] = x[:50] * 3 - 1
+    table = torch.from_numpy(rng.random((int(offsets[-1]), C), dtype=np.float32))
+    grad = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32))
+    S = np.log2(pls)
+    _, jac = grid_cpu.encode(x, table, offsets, pls, 16, want_jacobian=True)
+    want_g = torch.zeros_like(table)
+    want_gi = torch.zeros(B, D)
+    grid_cpu.grid_encode_backward(grad, x, table, offsets, want_g, B, D, C, L, S, 16, jac.contiguous(), want_gi, 0, False, 0)
+    got_g = torch.zeros_like(table, device="cuda")
+    got_gi = torch.zeros(B, D, device="cuda")
+    _backend.grid_encode_backward(dev(grad), dev(x), dev(table), dev(offsets), got_g, B, D, C, L, S, 16, dev(jac), got_gi,
+                                  0, False, 0)
+    # atomics: same addends, different order -> a few ulp of the largest per-row sums
+    assert H.maxdiff(got_g.cpu(), want_g) <= 2e-5 * float(want_g.abs().max())
+    assert torch.equal(got_gi.cpu(), want_gi)          # sequential fmaf chain: exact
+    wt = torch.zeros_like(table)
+    grid_cpu.grad_total_variation(x, table, wt, offsets, 1e-2, B, D, C, L, S, 16, 0, False)
+    gt = torch.zeros_like(table, device="cuda")
+    _backend.grad_total_variation(dev(x), dev(table), gt, dev(offsets), 1e-2, B, D, C, L, S, 16, 0, False)
+    assert H.maxdiff(gt.cpu(), wt) <= 1e-5 * float(wt.abs().max())
+
+
+def test_grid_module_autograd_and_errors():
+    from ucnerf_amd.gridencoder import GridEncoder, _backend
+    enc = GridEncoder(num_levels=8, level_dim=2, desired_resolution=2048, log2_hashmap_size=11).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = (torch.rand(300, 3, device="cuda") * 2 - 1)
+    out = enc(x)
+    out.sum().backward()
+    pls, offsets, _, _ = grid_cpu.table_layout(8, 2, 16, 2048, 11)
+    want = grid_cpu.encode((x.cpu() + 1) / 2, enc.embeddings.detach().cpu(), offsets, pls, 16)
+    assert torch.equal(out.detach().cpu(), want)
+    assert enc.embeddings.grad is not None and float(enc.embeddings.grad.abs().sum()) > 0
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _backend.grid_encode_forward(x.cpu(), enc.embeddings.data, enc.offsets, out.detach(), 300, 3, 2, 8, 1.0, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        bad = torch.zeros(int(offsets[-1]), 3, device="cuda")
+        _backend.grid_encode_forward(x.contiguous(), bad, enc.offsets, torch.empty(8, 300, 3, device="cuda"), 300, 3, 3, 8,
+                                     1.0, 16, None, 0, False, 0)
+
+
+# ------------------------------------------------------------------ a3 / a4: resampling
+def _resample(lib, sd_prev, w_prev, dilation, anneal, S, jitter=None):
+    from ucnerf_amd import _lib
+    from ucnerf_amd.internal.models import _u_table
+    N = sd_prev.shape[0] if sd_prev is not None else jitter.shape[0]
+    u, mj = _u_table(S, jitter is not None, torch.device("cuda"))
+    out = torch.empty(N, S + 1, device="cuda")
+    n_prev = 0 if sd_prev is None else w_prev.shape[1]
+    _lib.check(lib.ucn_resample(_lib.ptr(sd_prev), _lib.ptr(w_prev), n_prev, dilation, anneal, 0.0, u.data_ptr(),
+                                _lib.ptr(jitter), 0 if jitter is None else jitter.shape[1], mj, N, S, out.data_ptr(),
+                                _lib.stream()))
+    return out.cpu()
+
+
+def test_resample_vs_golden():
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    fx = H.load("stepfun.npz")
+    t, w, dil = dev(fx["t"]), dev(fx["w"]), float(fx["dilation"])
+    for frac in ("1.0", "0.25"):
+        f = float(frac)
+        got = _resample(lib, t, w, dil, 10 * f / (9 * f + 1), 128)
+        # sdist in [0,1]; scan-order / exp differences only
+        assert H.maxdiff(got, fx[f"sample_eval_{frac}"]) <= 2e-6
+        assert (got[:, 1:] >= got[:, :-1]).all()
+    got = _resample(lib, t, w, dil, 10 * 0.25 / (9 * 0.25 + 1), 32, jitter=dev(fx["sample_train_jitter"]))
+    assert H.maxdiff(got, fx["sample_train"]) <= 2e-6
+    N = fx["t"].shape[0]
+    from ucnerf_amd.internal.models import _u_table
+    u, _ = _u_table(64, False, torch.device("cuda"))
+    out = torch.empty(N, 65, device="cuda")
+    _lib.check(lib.ucn_resample(None, None, 0, 0.5, 1.0, 0.0, u.data_ptr(), None, 0, 0.0, N, 64, out.data_ptr(), _lib.stream()))
+    assert H.maxdiff(out.cpu(), fx["sample_level0"]) <= 2e-6
+
+
+# ------------------------------------------------------------------ a10 / a11: compositing
+def test_composite_vs_golden():
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    fx = H.load("composite.npz")
+    N, S = fx["density"].shape
+    # the kernel takes normalised fenceposts + near/far; tdist = s*far + (1-s)*near with near=0, far=8
+    sd = dev(fx["tdist"] / 8.0)
+    near, far = torch.zeros(N, device="cuda"), torch.full((N,), 8.0, device="cuda")
+    w = torch.empty(N, S, device="cuda"); main = torch.empty(N, 5, device="cuda"); ex = torch.empty(N, 4, device="cuda")
+    for opaque, key in ((0, "weights"), (1, "weights_opaque")):
+        _lib.check(lib.ucn_composite(dev(fx["density"]).data_ptr(), dev(fx["rgbs"]).data_ptr(), sd.data_ptr(), near.data_ptr(),
+                                     far.data_ptr(), dev(fx["dirs"]).data_ptr(), 1.0, opaque, N, S, w.data_ptr(), main.data_ptr(),
+                                     ex.data_ptr(), _lib.stream()))
+        assert H.maxdiff(w.cpu(), fx[key]) <= 5e-6
+        if opaque:
+            continue
+        m, e = main.cpu(), ex.cpu()
+        assert H.maxdiff(m[:, :3], fx["out_rgb"]) <= 1e-5
+        assert H.maxdiff(m[:, 4], fx["out_acc"]) <= 1e-5
+        sentinel = fx["out_depth"] == 300
+        assert torch.equal(m[:, 3] == 300, sentinel) or H.maxdiff(m[:, 4], fx["out_acc"]) <= 1e-6
+        assert H.maxdiff(m[:, 3][~sentinel], fx["out_depth"][~sentinel]) <= 5e-5
+        assert H.maxdiff(e[:, 0], fx["out_distance_mean"]) <= 5e-5
+        for i, k in enumerate(("distance_percentile_5", "distance_median", "distance_percentile_95")):
+            assert H.maxdiff(e[:, 1 + i], fx["out_" + k]) <= 2e-4, k      # t up to 8.5, 1/(cdf slope) amplification
+
+
+# ------------------------------------------------------------------ a5-a9: field on explicit Gaussians
+def test_field_vs_golden():
+    fx = H.load("field.npz")
+    spec = rm.make_spec("tiny")
+    sd = H.state_for(fx, spec)
+    model, _ = H.hip_model(spec, sd)
+    means, stds, vd = dev(fx["means"]), dev(fx["stds"]), dev(fx["viewdirs"])
+    for name, mlp in (("nerf", model.nerf_mlp), ("prop", model.prop_mlp_0)):
+        res = mlp(False, means, stds, viewdirs=vd)
+        assert H.maxdiff(res["density"].cpu(), fx[f"{name}_density"]) <= 2e-5
+        assert H.maxdiff(res["coord"].cpu(), fx[f"{name}_coord"]) <= 2e-6
+        assert H.maxdiff(res["rgb"].cpu(), fx[f"{name}_rgb"]) <= 2e-5
+    raw, x, coord = model.nerf_mlp.predict_density(means, stds)
+    assert H.maxdiff(raw.cpu(), fx["nerf_raw_density"]) <= 2e-5
+    assert H.maxdiff(x.cpu(), fx["nerf_bottleneck"]) <= 2e-5
+    raw, _, _ = model.nerf_mlp.predict_density(dev(fx["nowarp_means"]), dev(fx["nowarp_stds"]), no_warp=True)
+    assert H.maxdiff(raw.cpu(), fx["nowarp_raw_density"]) <= 2e-5
+
+
+# ------------------------------------------------------------------ a1: Model.forward end to end
+@pytest.mark.parametrize("name,kind,over", [
+    ("model_tiny.npz", "tiny", {}),
+    ("model_tinyR.npz", "tinyR", {}),
+    ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
+    ("model_train.npz", "tiny", {}),
+])
+def test_model_forward_vs_golden(name, kind, over):
+    fx = H.load(name)
+    spec = rm.make_spec(kind, **over)
+    sd = H.state_for(fx, spec)
+    model, cfg = H.hip_model(spec, sd)
+    train = "noise0_jitter" in fx
+    noise = H.noise_of(fx, spec.num_levels)
+    batch = H.pin_noise(H.to_dev(H.batch_of(fx)), noise)
+    cam = fx.get("eval_camidx")
+    rend, hist = model(train, batch, float(fx["train_frac"]), not train, zero_glo=not train,
+                       eval_camidx=None if cam is None else cam.cuda())
+    torch.cuda.synchronize()
+    for lvl in range(spec.num_levels):
+        g = lambda k: fx[f"L{lvl}_{k}"]
+        r = rend[lvl]
+        assert H.maxdiff(hist[lvl]["sdist"].cpu(), g("hist_sdist").reshape(hist[lvl]["sdist"].shape)) <= 5e-6, lvl
+        assert H.maxdiff(hist[lvl]["density"].cpu().reshape(-1), g("hist_density").reshape(-1)) <= 5e-5, lvl
+        assert H.maxdiff(r["weights"].cpu().reshape(-1), g("weights").reshape(-1)) <= 2e-5, lvl
+        assert H.maxdiff(r["rgb"].cpu().reshape(-1), g("rgb").reshape(-1)) <= H.RGB_TOL, lvl      # the headline bar
+        assert H.maxdiff(r["acc"].cpu().reshape(-1), g("acc").reshape(-1)) <= 5e-5, lvl
+        if lvl == spec.num_levels - 1:
+            assert H.maxdiff(hist[lvl]["rgb"].cpu().reshape(-1), g("hist_rgb").reshape(-1)) <= 5e-5
+            assert H.maxdiff(hist[lvl]["coord"].cpu().reshape(-1), g("hist_coord").reshape(-1)) <= 5e-6
+        want_d = g("depth").reshape(-1)
+        got_d = r["depth"].cpu().reshape(-1)
+        stable = (g("acc").reshape(-1) - 0.6).abs() > 1e-4                 # away from the 0.6 sentinel switch
+        assert H.maxdiff(got_d[stable], want_d[stable]) <= 5e-4, lvl
+        if not train:
+            for k in ("distance_mean", "distance_median", "distance_percentile_5", "distance_percentile_95"):
+                assert H.maxdiff(r[k].cpu().reshape(-1), g(k).reshape(-1)) <= 1e-3, (lvl, k)
+            assert H.maxdiff(r["ray_sdist"].cpu(), g("ray_sdist")) <= 5e-6
+            assert H.maxdiff(r["ray_rgbs"].cpu(), g("ray_rgbs")) <= 5e-5
+        if "sky_rgbs" in r:
+            assert H.maxdiff(r["sky_rgbs"].cpu(), g("sky_rgbs")) <= 5e-5
+            assert H.maxdiff(r["affine_trans"].cpu(), g("affine_trans")) <= 1e-5
+            assert H.maxdiff(r["affine_trans_sky"].cpu(), g("affine_trans_sky")) <= 1e-5
+
+
+def test_model_forward_vs_oracle_larger_batch_and_chunks():
+    """2000 rays through 3 internal passes (ragged last pass) against the CPU oracle."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=9)
+    n = 2000
+    rays = rm.synthetic_rays(n, seed=10)
+    noise = [rm.draw_level_noise(spec, n, l, False, torch.Generator().manual_seed(11 + l)) for l in range(2)]
+    with torch.no_grad():
+        want, _ = rm.model_forward(spec, sd, rays, noise)
+    model, _ = H.hip_model(spec, sd, max_chunk_rays=768)
+    got, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+    assert H.maxdiff(got[-1]["rgb"].cpu(), want[-1]["rgb"]) <= H.RGB_TOL
+    assert H.maxdiff(got[-1]["acc"].cpu(), want[-1]["acc"]) <= 5e-5
+    for lpb in (4, 16):                                   # level grouping is a pure scheduling knob
+        model.levels_per_block = lpb
+        again, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+        assert torch.equal(again[-1]["rgb"], got[-1]["rgb"])
+
+
+def test_render_image_vs_golden_and_invariants():
+    from ucnerf_amd.internal import models
+    fx = H.load("render_image.npz")
+    spec = rm.make_spec("tiny")
+    sd = H.state_for(fx, spec)
+    model, cfg = H.hip_model(spec, sd)
+    Hh, Ww = int(fx["H"]), int(fx["W"])
+    batch = {k: v.reshape(Hh, Ww, -1).cuda() for k, v in H.batch_of(fx).items()}
+    batch["rand_vec"] = torch.cat([fx[f"noise{l}_rand_vec"] for l in range(2)], dim=-1).reshape(Hh, Ww, -1).cuda()
+
+    class OneProc:
+        num_processes, process_index, is_main_process = 1, 0, True
+    out = models.render_image(model, OneProc(), batch, False, 1.0, cfg, verbose=False)
+    assert model.training            # render_image leaves the model in train mode (models.py:1006)
+    for k in [k[4:] for k in fx if k.startswith("out_")]:
+        tol = dict(rgb=H.RGB_TOL, acc=5e-5, weights=2e-5).get(k, 1e-3)
+        want = fx["out_" + k]
+        got = out[k].cpu()
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        if k == "depth":
+            stable = (fx["out_acc"] - 0.6).abs() > 1e-4
+            assert H.maxdiff(got[stable], want[stable]) <= 5e-4
+        else:
+            assert H.maxdiff(got, want) <= tol, k
+    assert all(len(out[k]) == 2 and out[k][0].shape[0] == 16 for k in ("ray_sdist", "ray_weights", "ray_rgbs"))
+    # size-independent properties at full resolution of the frame: weights are a sub-stochastic
+    # partition of each ray, acc = sum(weights), rgb inside the padded sigmoid range + white background
+    w = out["weights"]
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
+    assert H.maxdiff(w.sum(-1).cpu(), out["acc"].cpu()) <= 1e-5
+    assert (out["rgb"] >= -0.001 - 1e-5).all() and (out["rgb"] <= 1.001 + 1e-5).all()
+
+
+def test_product_raises_without_device_tensors():
+    spec = rm.make_spec("tiny")
+    model, _ = H.hip_model(spec, rm.init_state(spec, seed=1))
+    rays = rm.synthetic_rays(8, seed=1)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        model(False, rays, 1.0, False)

@@ -1,0 +1,116 @@
+"""ctypes loader for libucnerf_march.so (the C ABI of include/ucnerf_march.h).
+
+The HIP library is the product: if it is missing or stale this module raises -- there is no
+CPU or eager-PyTorch fallback anywhere in ucnerf_amd.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
+ABI_VERSION = 1
+
+c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+class UcnField(ctypes.Structure):
+    """struct ucn_field (include/ucnerf_march.h)."""
+    _fields_ = [
+        ("embeddings", c_vp), ("offsets_host", c_vp), ("grid_sizes_host", c_vp),
+        ("num_levels", c_u32), ("level_dim", c_u32), ("base_resolution", c_u32),
+        ("log2_per_level_scale", c_f32),
+        ("w_d0", c_vp), ("b_d0", c_vp), ("w_d1", c_vp), ("b_d1", c_vp),
+        ("n_bottleneck", c_u32),
+        ("w_c0", c_vp), ("b_c0", c_vp), ("w_c1", c_vp), ("b_c1", c_vp), ("w_rgb", c_vp), ("b_rgb", c_vp),
+        ("n_width", c_u32), ("n_dir", c_u32),
+        ("density_bias", c_f32), ("rgb_premultiplier", c_f32), ("rgb_bias", c_f32), ("rgb_padding", c_f32),
+        ("packed", c_vp),
+    ]
+
+
+class UcnSky(ctypes.Structure):
+    """struct ucn_sky (include/ucnerf_march.h)."""
+    _fields_ = [
+        ("w_pts", c_vp * 8), ("b_pts", c_vp * 8),
+        ("w_alpha", c_vp), ("b_alpha", c_vp), ("w_feat", c_vp), ("b_feat", c_vp),
+        ("w_view", c_vp), ("b_view", c_vp), ("w_rgb", c_vp), ("b_rgb", c_vp),
+        ("packed", c_vp),
+    ]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ucnerf_march.h
+SIGNATURES = {
+    "ucn_last_error": [],
+    "ucn_abi_version": [],
+    "ucn_probe_copy": [c_vp, c_vp, c_u64, c_vp],
+    "ucn_grid_encode_forward": [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_u32, c_i32,
+                                c_u32, c_i32, c_vp],
+    "ucn_grid_encode_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_vp, c_vp,
+                                 c_u32, c_i32, c_u32, c_i32, c_vp],
+    "ucn_grad_total_variation": [c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_u32, c_u32, c_u32, c_f32, c_u32, c_u32, c_i32,
+                                 c_vp],
+    "ucn_field_packed_floats": [ctypes.POINTER(UcnField)],
+    "ucn_field_pack": [ctypes.POINTER(UcnField), c_vp],
+    "ucn_resample": [c_vp, c_vp, c_u32, c_f32, c_f32, c_f32, c_vp, c_vp, c_u32, c_f32, c_u32, c_u32, c_vp, c_vp],
+    "ucn_cone_basis": [c_vp, c_vp, c_u32, c_vp, c_vp],
+    "ucn_march_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
+                           c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
+    "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],
+    "ucn_field_mlp": [ctypes.POINTER(UcnField), c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_composite": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_sky_packed_floats": [],
+    "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
+    "ucn_sky_workspace_floats": [c_u32],
+    "ucn_sky_render": [ctypes.POINTER(UcnSky), c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u32, c_vp, c_vp, c_vp],
+    "ucn_dense": [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp],
+    "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
+}
+_RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
+             "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every symbol of the header (ImportError if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with ucnerf_amd/csrc/build.sh (hipcc --offload-arch=gfx950). "
+            "ucnerf_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header/library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    got = lib.ucn_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libucnerf_march.so ABI {got} != expected {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(load().ucn_last_error().decode())
+
+
+def ptr(t):
+    """Device/host address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    """The current HIP stream handle (the reference launches on the default stream,
+    gridencoder.cu:374-382; here the caller's current torch stream is honoured)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be a CUDA tensor")      # CHECK_CUDA, gridencoder.cu:15

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds libucnerf_march.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+mkdir -p _obj
+pids=()
+for f in grid_op march_ray march_features field_mlp heads sky; do
+  [ -f "$f.hip" ] || continue
+  if [ ! -f "_obj/$f.o" ] || [ "$f.hip" -nt "_obj/$f.o" ] || [ ucn_common.h -nt "_obj/$f.o" ] || [ ../../include/ucnerf_march.h -nt "_obj/$f.o" ]; then
+    $HIPCC $FLAGS -c "$f.hip" -o "_obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libucnerf_march.so _obj/*.o
+echo "built $(pwd)/libucnerf_march.so"

@@ -1,0 +1,334 @@
+// Per-ray step-function kernels of the ray-march: resampling, cone basis, alpha compositing.
+//
+//   k_resample   <- stepfun.py:75-105 (max_dilate_weights), models.py:168-191 (trim, anneal,
+//                   logits), stepfun.py:154-218,251-294 (softmax -> CDF -> inverse-CDF -> fenceposts)
+//   k_cone_basis <- render.py:139-146
+//   k_composite  <- render.py:155-174 (alpha weights), :177-244 (volumetric_rendering),
+//                   stepfun.py:329-339 (weighted percentiles)
+//
+// The reference does the dilation and the inverse-CDF lookup with O(n*m) broadcast masks
+// ([N,3n,n] and [N,n,m] temporaries in HBM).  Here a ray's step function never leaves the chip:
+// k_resample walks the three already-sorted fencepost lists with merge pointers (one thread per
+// ray, per-thread arrays live in lane-interleaved scratch = coalesced), and k_composite gives one
+// wave64 to each ray: transmittance is a wave prefix-sum (DPP-free shuffles), the percentile
+// lookups are ballots over the CDF held in LDS.
+#include "ucn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ resample
+template <int MAXP>
+__global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_prev, const float *__restrict__ w_prev,
+                                                  uint32_t n_prev, float dilation, float anneal, float pad,
+                                                  const float *__restrict__ u_table, const float *__restrict__ jitter,
+                                                  uint32_t jcols, float max_jitter, uint32_t N, uint32_t S,
+                                                  float *__restrict__ sd_out) {
+    const uint32_t ray = blockIdx.x * 256u + threadIdx.x;
+    if (ray >= N) return;
+    float kn[3 * MAXP + 1];  // fenceposts of the (dilated) step function
+    float wt[3 * MAXP + 1];  // its weights, later the CDF
+    const float *sd;         // fenceposts actually resampled (after the [1:-1] trim)
+    float *w;
+    uint32_t nw;
+    if (n_prev == 0) {
+        kn[0] = 0.0f; kn[1] = 1.0f; wt[0] = 1.0f;
+        sd = kn; w = wt; nw = 1;
+    } else {
+        const uint32_t n = n_prev;
+        float t[MAXP + 1], p[MAXP];
+        for (uint32_t i = 0; i <= n; i++) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
+        for (uint32_t i = 0; i < n; i++)
+            p[i] = w_prev[(size_t)ray * n + i] / fmaxf(t[i + 1] - t[i], UCN_EPS);       // weight_to_pdf
+        // sort(cat[t, t0-d, t1+d]) == 3-way merge of three sorted lists, then clip to [0,1]
+        const uint32_t m = 3 * n + 1;
+        uint32_t ia = 0, ib = 0, ic = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            const float a = ia <= n ? t[ia] : INFINITY;
+            const float b = ib < n ? t[ib] - dilation : INFINITY;
+            const float c = ic < n ? t[ic + 1] + dilation : INFINITY;
+            float v;
+            if (b <= a && b <= c) { v = b; ib++; }
+            else if (a <= c)      { v = a; ia++; }
+            else                  { v = c; ic++; }
+            kn[i] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+        // max-pool the pdf over the dilated intervals covering each fencepost
+        uint32_t jlo = 0, jhi = 0;
+        float total = 0.0f;
+        for (uint32_t i = 0; i + 1 < m; i++) {
+            const float k = kn[i];
+            while (jhi < n && t[jhi] - dilation <= k) jhi++;
+            while (jlo < n && !(t[jlo + 1] + dilation > k)) jlo++;
+            float env = 0.0f;
+            for (uint32_t j = jlo; j < jhi; j++) env = fmaxf(env, p[j]);
+            const float wv = env * (kn[i + 1] - kn[i]);                                  // pdf_to_weight
+            wt[i] = wv;
+            total += wv;
+        }
+        const float norm = fmaxf(total, UCN_EPS);
+        for (uint32_t i = 0; i + 1 < m; i++) wt[i] = wt[i] / norm;
+        sd = kn + 1; w = wt + 1; nw = m - 3;                                             // models.py:175-176
+    }
+    // logits -> softmax -> CDF (in place in w[], shifted by one so that cdf[i] = w[i-1])
+    float mx = -INFINITY;
+    for (uint32_t i = 0; i < nw; i++) {
+        const float lg = (sd[i + 1] > sd[i]) ? anneal * logf(w[i] + pad) : -INFINITY;
+        w[i] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    float z = 0.0f;
+    for (uint32_t i = 0; i < nw; i++) {
+        const float e = expf(w[i] - mx);
+        w[i] = e;
+        z += e;
+    }
+    // cdf[0] = 0, cdf[i] = min(1, sum_{k<i} pw_k) for i < nw, cdf[nw] = 1  (stepfun.py:123-127)
+    float run = 0.0f;
+    for (uint32_t i = 0; i < nw; i++) {
+        const float pw = w[i] / z;
+        w[i] = fminf(run, 1.0f);           // cdf[i]; run == 0 exactly for i == 0
+        run += pw;
+    }
+    // w[nw] slot: wt has 3*MAXP+1 entries, and nw <= 3*MAXP-2
+    w[nw] = 1.0f;
+    // inverse CDF at the sorted u's, then midpoints + reflected/clamped ends (stepfun.py:283-293)
+    const float jit = jitter ? jitter[(size_t)ray * jcols] : 0.0f;
+    uint32_t idx = 0;
+    float prev_c = 0.0f, prev_mid = 0.0f, c0 = 0.0f;
+    float *out = sd_out + (size_t)ray * (S + 1);
+    for (uint32_t k = 0; k < S; k++) {
+        float u = u_table[k];
+        if (jitter) u = u + (jcols > 1 ? jitter[(size_t)ray * jcols + k] : jit) * max_jitter;
+        while (idx + 1 <= nw && w[idx + 1] <= u) idx++;
+        const uint32_t i1 = idx + 1 <= nw ? idx + 1 : nw;
+        const float x0 = w[idx], x1 = w[i1];
+        float fr = (u - x0) / (x1 - x0);
+        if (fr != fr) fr = 0.0f;                               // nan_to_num(.., 0); +-inf clip below
+        fr = fminf(fmaxf(fr, 0.0f), 1.0f);
+        const float f0 = sd[idx], f1 = sd[i1];
+        const float c = f0 + fr * (f1 - f0);
+        if (k == 0) {
+            c0 = c;
+        } else {
+            const float mid = (c + prev_c) / 2.0f;
+            if (k == 1) out[0] = fmaxf(2.0f * c0 - mid, 0.0f);
+            out[k] = mid;
+            prev_mid = mid;
+        }
+        prev_c = c;
+    }
+    out[S] = fminf(2.0f * prev_c - prev_mid, 1.0f);
+}
+
+// ------------------------------------------------------------------ cone basis
+__global__ __launch_bounds__(256) void k_cone_basis(const float *__restrict__ cam, const float *__restrict__ rnd,
+                                                    uint32_t N, float *__restrict__ basis) {
+    const uint32_t ray = blockIdx.x * 256u + threadIdx.x;
+    if (ray >= N) return;
+    const float a0 = cam[ray * 3 + 0], a1 = cam[ray * 3 + 1], a2 = cam[ray * 3 + 2];
+    const float b0 = rnd[ray * 3 + 0], b1 = rnd[ray * 3 + 1], b2 = rnd[ray * 3 + 2];
+    // ortho1 = normalize(cam x rand)  (F.normalize: v / max(|v|, 1e-12))
+    float c0 = a1 * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1 * b0;
+    float n = fmaxf(sqrtf((c0 * c0 + c1 * c1) + c2 * c2), 1e-12f);
+    c0 /= n; c1 /= n; c2 /= n;
+    // ortho2 = normalize(cam x ortho1)
+    float d0 = a1 * c2 - a2 * c1, d1 = a2 * c0 - a0 * c2, d2 = a0 * c1 - a1 * c0;
+    n = fmaxf(sqrtf((d0 * d0 + d1 * d1) + d2 * d2), 1e-12f);
+    d0 /= n; d1 /= n; d2 /= n;
+    float *o = basis + (size_t)ray * 6;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = d0; o[4] = d1; o[5] = d2;
+}
+
+// ------------------------------------------------------------------ composite
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ float wave_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float nan_to_num_inf(float v) {
+    // torch.nan_to_num(x, nan=inf): NaN -> +inf (as given), +inf -> FLT_MAX, -inf -> -FLT_MAX
+    if (v != v) return INFINITY;
+    if (v == INFINITY) return 3.4028234663852886e38f;
+    if (v == -INFINITY) return -3.4028234663852886e38f;
+    return v;
+}
+
+// One wave64 per ray, 4 rays per workgroup.  Lane owns CH consecutive samples.
+template <int CH>
+__global__ __launch_bounds__(256) void k_composite(const float *__restrict__ density, const float *__restrict__ rgbs,
+                                                   const float *__restrict__ sdist, const float *__restrict__ near_,
+                                                   const float *__restrict__ far_, const float *__restrict__ dirs,
+                                                   float bg, int opaque, uint32_t N, uint32_t S,
+                                                   float *__restrict__ weights_out, float *__restrict__ out_main,
+                                                   float *__restrict__ out_extras) {
+    __shared__ float s_cdf[4][64 * CH + 2];
+    __shared__ float s_t[4][64 * CH + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ray_raw = blockIdx.x * 4u + wv;
+    const bool live = ray_raw < N;                       // wave-uniform; dead waves still reach the barrier
+    const uint32_t ray = live ? ray_raw : N - 1;
+    const float nr = near_[ray], fr = far_[ray];
+    const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float *sd = sdist + (size_t)ray * (S + 1);
+    float tlo[CH], thi[CH], tau[CH];
+    float lane_tau = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        if (i < S) {
+            const float s0 = sd[i], s1 = sd[i + 1];
+            tlo[c] = s0 * fr + (1.0f - s0) * nr;          // coord.py:176 with fn = identity
+            thi[c] = s1 * fr + (1.0f - s1) * nr;
+            float td = density[(size_t)ray * S + i] * ((thi[c] - tlo[c]) * dnorm);
+            if (opaque && i == S - 1) td = INFINITY;
+            tau[c] = td;
+        } else {
+            tlo[c] = thi[c] = 0.0f;
+            tau[c] = 0.0f;
+        }
+        lane_tau += tau[c];
+    }
+    // exclusive prefix of tau over the ray = transmittance exponent
+    float before = wave_scan(lane_tau, lane) - lane_tau;
+    float acc = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, dnum = 0.0f, lnum = 0.0f;
+    float wloc[CH];
+    float lane_w = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        float w = 0.0f;
+        if (i < S) {
+            const float alpha = 1.0f - expf(-tau[c]);
+            const float trans = expf(-before);
+            w = alpha * trans;
+            if (live) weights_out[(size_t)ray * S + i] = w;
+            const float tm = 0.5f * (tlo[c] + thi[c]);
+            if (rgbs) {
+                const float *col = rgbs + ((size_t)ray * S + i) * 3;
+                r += w * col[0]; g += w * col[1]; b += w * col[2];
+            }
+            dnum += w * tm;
+            lnum += w * logf(tm);
+            before += tau[c];
+        }
+        wloc[c] = w;
+        lane_w += w;
+    }
+    acc = wave_sum(lane_w);
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
+    dnum = wave_sum(dnum);
+    lnum = wave_sum(lnum);
+    const float t_first = sd[0] * fr + (1.0f - sd[0]) * nr;
+    const float t_last = sd[S] * fr + (1.0f - sd[S]) * nr;
+    const float bg_w = fmaxf(1.0f - acc, 0.0f);
+    const float denom = fmaxf(acc, UCN_EPS);
+    float depth = fminf(fmaxf(nan_to_num_inf(dnum / denom), t_first), t_last);
+    if (acc < 0.6f) depth = 300.0f;                                  // render.py:208-213
+    if (lane == 0 && live) {
+        float *o = out_main + (size_t)ray * 5;
+        o[0] = r + bg_w * bg; o[1] = g + bg_w * bg; o[2] = b + bg_w * bg;
+        o[3] = depth; o[4] = acc;
+    }
+    if (!out_extras) return;
+    // CDF of [w_0..w_{S-1}, bg_w] at the S+2 fenceposts [t_0..t_S, far]  (render.py:234-238)
+    float incl = wave_scan(lane_w, lane) - lane_w;
+    float *cdf = s_cdf[wv], *tt = s_t[wv];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        if (i < S) {
+            incl += wloc[c];
+            cdf[i + 1] = fminf(incl, 1.0f);
+            tt[i] = tlo[c];
+        }
+    }
+    if (lane == 0) { cdf[0] = 0.0f; cdf[S + 1] = 1.0f; tt[S] = t_last; tt[S + 1] = fr; }
+    __syncthreads();
+    float pct[3];
+    const float ps[3] = {0.05f, 0.5f, 0.95f};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        // #{i in [0,S+1] : cdf[i] <= p}; the CDF is non-decreasing so this is a prefix
+        uint32_t cnt = 0;
+        for (uint32_t i = lane; i <= S + 1; i += 64) cnt += (cdf[i] <= ps[q]) ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        const uint32_t i0 = cnt > 0 ? cnt - 1 : 0;
+        const uint32_t i1 = cnt <= S + 1 ? cnt : S + 1;
+        const float x0 = cdf[i0], x1 = cdf[i1];
+        float f = (ps[q] - x0) / (x1 - x0);
+        if (f != f) f = 0.0f;
+        f = fminf(fmaxf(f, 0.0f), 1.0f);
+        pct[q] = tt[i0] + f * (tt[i1] - tt[i0]);
+    }
+    if (lane == 0 && live) {
+        float *e = out_extras + (size_t)ray * 4;
+        e[0] = fminf(fmaxf(nan_to_num_inf(expf(lnum / denom)), t_first), t_last);
+        e[1] = pct[0]; e[2] = pct[1]; e[3] = pct[2];
+    }
+}
+
+}  // namespace
+
+extern "C" int ucn_resample(const float *sdist_prev, const float *weights_prev, uint32_t n_prev, float dilation,
+                            float anneal, float resample_padding, const float *u_table, const float *jitter,
+                            uint32_t jitter_cols, float max_jitter, uint32_t N, uint32_t S, float *sdist_out,
+                            ucn_stream_t stream) {
+    UCN_REQUIRE(S > 1, "num_samples must be > 1, is %u.", S);                      // stepfun.py:271-272
+    UCN_REQUIRE(u_table && sdist_out, "resample: null pointer argument");
+    UCN_REQUIRE(n_prev == 0 || (sdist_prev && weights_prev), "resample: previous level missing");
+    UCN_REQUIRE(n_prev <= 256, "resample: at most 256 intervals per level are supported, got %u", n_prev);
+    UCN_REQUIRE(!jitter || jitter_cols == 1 || jitter_cols == S, "resample: jitter must be [N,1] or [N,S]");
+    if (N == 0) return 0;
+    const dim3 grid(ucn_div_up(N, 256));
+    hipStream_t st = (hipStream_t)stream;
+#define UCN_RS(MAXP)                                                                                              \
+    hipLaunchKernelGGL(k_resample<MAXP>, grid, dim3(256), 0, st, sdist_prev, weights_prev, n_prev, dilation,      \
+                       anneal, resample_padding, u_table, jitter, jitter_cols, max_jitter, N, S, sdist_out)
+    if (n_prev <= 64) UCN_RS(64);
+    else if (n_prev <= 128) UCN_RS(128);
+    else UCN_RS(256);
+#undef UCN_RS
+    UCN_LAUNCH_CHECK("resample");
+    return 0;
+}
+
+extern "C" int ucn_cone_basis(const float *cam_dirs, const float *rand_vec, uint32_t N, float *basis_out,
+                              ucn_stream_t stream) {
+    UCN_REQUIRE(cam_dirs && rand_vec && basis_out, "cone_basis: null pointer argument");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(k_cone_basis, dim3(ucn_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, cam_dirs, rand_vec, N, basis_out);
+    UCN_LAUNCH_CHECK("cone_basis");
+    return 0;
+}
+
+extern "C" int ucn_composite(const float *density, const float *rgbs, const float *sdist, const float *near_,
+                             const float *far_, const float *directions, float bg_intensity, int opaque_background,
+                             uint32_t N, uint32_t S, float *weights_out, float *out_main, float *out_extras,
+                             ucn_stream_t stream) {
+    UCN_REQUIRE(density && sdist && near_ && far_ && directions && weights_out && out_main, "composite: null pointer argument");
+    UCN_REQUIRE(S >= 1 && S <= 512, "composite: samples per ray must be in [1,512], got %u", S);
+    if (N == 0) return 0;
+    const dim3 grid(ucn_div_up(N, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define UCN_CP(CH)                                                                                               \
+    hipLaunchKernelGGL(k_composite<CH>, grid, dim3(256), 0, st, density, rgbs, sdist, near_, far_, directions,   \
+                       bg_intensity, opaque_background, N, S, weights_out, out_main, out_extras)
+    if (S <= 64) UCN_CP(1);
+    else if (S <= 128) UCN_CP(2);
+    else if (S <= 256) UCN_CP(4);
+    else UCN_CP(8);
+#undef UCN_CP
+    UCN_LAUNCH_CHECK("composite");
+    return 0;
+}
