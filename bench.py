@@ -1,0 +1,199 @@
+"""bench.py -- rays/s of the forward render hot path on N MI355X GPUs (one node).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one synthetic 1280x1920 frame (2,457,600 rays):
+BASELINE.json configs[1] -- proposal 64 + NeRF 128 samples, NeRF grid L=16 C=2 T=2^19, proposal grid
+L=6 C=2 T=2^19, 256-wide colour MLP, fp32, rand=False, compute_extras=True (what render_image does).
+Rays and weights are resident in HBM before the timed region.  With N > 1 the frame's rays are
+sharded row-contiguously over the ranks (strong scaling) and the finished buffers are exchanged with
+one packed RCCL all-gather per frame, inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+H_IMG, W_IMG, FOCAL = 1280, 1920, 2000.0
+S_PROP, S_NERF = 64, 128
+# algorithmic costs per ray (DESIGN.md "Rooflines")
+GATHER_BYTES_NERF = S_NERF * 6 * 16 * 8 * 2 * 4          # 786,432 B: samples x multisamples x levels x corners x C x 4
+GATHER_BYTES_PROP = S_PROP * 6 * 6 * 8 * 2 * 4           # 147,456 B
+MAC_NERF = 32 * 64 + 64 * 256 + 283 * 256 + 539 * 256 + 256 * 3      # 229,632 MAC / sample (reference formulation)
+FLOP_NERF_RAY = S_NERF * 2 * MAC_NERF
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def frame_rays(device):
+    """One pinhole camera, pixel centres, Waymo-like intrinsics (formulas of
+    camera_utils.py:482-557, datasets.py:446), generated on the device, outside the timed region."""
+    ys, xs = torch.meshgrid(torch.arange(H_IMG, device=device, dtype=torch.float32),
+                            torch.arange(W_IMG, device=device, dtype=torch.float32), indexing="ij")
+
+    def cam(x, y):
+        return torch.stack([(x - W_IMG / 2 + 0.5) / FOCAL, -(y - H_IMG / 2 + 0.5) / FOCAL, -torch.ones_like(x)], -1)
+    yaw = 0.3
+    R = torch.tensor([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]], dtype=torch.float32,
+                     device=device)
+    d = cam(xs, ys) @ R.T
+    v = torch.nn.functional.normalize(d, dim=-1)
+    vx = torch.nn.functional.normalize(cam(xs + 1, ys) @ R.T, dim=-1)
+    vy = torch.nn.functional.normalize(cam(xs, ys + 1) @ R.T, dim=-1)
+    radii = (0.5 * ((v - vx).norm(dim=-1) + (v - vy).norm(dim=-1)))[..., None] * 2 / np.sqrt(12)
+    o = torch.tensor([0.1, -0.05, 0.2], device=device).expand(H_IMG, W_IMG, 3).contiguous()
+    return dict(origins=o, directions=d.contiguous(), viewdirs=v.contiguous(),
+                cam_dirs=(-R[:, 2]).expand(H_IMG, W_IMG, 3).contiguous(), radii=radii.contiguous(),
+                near=torch.zeros(H_IMG, W_IMG, 1, device=device), far=torch.full((H_IMG, W_IMG, 1), 8.0, device=device),
+                cam_idx=torch.zeros(H_IMG, W_IMG, 1, device=device), lossmult=torch.ones(H_IMG, W_IMG, 1, device=device))
+
+
+class Ranks:
+    """The three attributes render_image reads from an `accelerate.Accelerator`."""
+
+    def __init__(self, world, rank):
+        self.num_processes, self.process_index, self.is_main_process = world, rank, rank == 0
+
+
+def build_model(device):
+    """Random-init weights of the reference's architecture (module init laws of models.py:438-483),
+    same seed on every rank; hash tables re-drawn ~U(-1,1) so density varies (the
+    reference's +-1e-4 table init makes the grid a no-op)."""
+    from ucnerf_amd.internal import configs, models
+    torch.manual_seed(0)
+    cfg = configs.Config()
+    kw = dict(grid_level_dim=2, grid_log2_hashmap_size=19)
+    with models.bindings(NerfMLP=dict(grid_disired_resolution=524288, **kw), PropMLP=dict(**kw)):
+        model = models.Model(config=cfg, num_levels=2, num_prop_samples=S_PROP, num_nerf_samples=S_NERF)
+    for mlp in (model.nerf_mlp, model.prop_mlp_0):
+        mlp.encoder.embeddings.data.uniform_(-1, 1)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}       # CPU copy for the CPU baseline
+    return model.to(device).eval(), cfg, sd
+
+
+def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=4096):
+    """The reference's path on the host cores: oracle/raymarch.py (== reference Python, bit-exact in
+    the authoring container) + oracle/grid_oracle.c for the CUDA-only grid op, same rays / weights.
+    This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check)."""
+    from oracle import raymarch as rm
+    spec = rm.make_spec("B")
+    torch.set_num_threads(os.cpu_count() or 1)
+    idx = torch.linspace(0, rays_flat["origins"].shape[0] - 1, n_sample).long()
+    sub = {k: v[idx].cpu() for k, v in rays_flat.items()}
+    noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3].cpu()) for l in range(2)]
+    with torch.no_grad():
+        rm.model_forward(spec, sd, {k: v[:256] for k, v in sub.items()},
+                         [rm.LevelNoise(rand_vec=n.rand_vec[:256]) for n in noise])           # warm-up
+        t0 = time.perf_counter()
+        rend, _ = rm.model_forward(spec, sd, sub, noise)
+        dt = time.perf_counter() - t0
+    linf = float((rend[-1]["rgb"] - gpu_rgb[idx].cpu()).abs().max())
+    mse = float(((rend[-1]["rgb"] - gpu_rgb[idx].cpu()) ** 2).mean())
+    return dict(value=n_sample / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_sample} rays strided over the same frame, same weights and rand_vec, 1 call, {dt:.1f} s",
+                rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--levels-per-block", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
+    from ucnerf_amd.internal import models, dist as udist
+    model, cfg, sd = build_model(device)
+    if args.levels_per_block:
+        model.levels_per_block = args.levels_per_block
+    if args.chunk:
+        model.max_chunk_rays = args.chunk
+    batch = frame_rays(device)
+    n_rays = H_IMG * W_IMG
+    g = torch.Generator().manual_seed(1)
+    rand_vec = torch.randn(n_rays, 6, generator=g)                  # pinned cone-basis draws (render.py:140)
+    batch["rand_vec"] = rand_vec.reshape(H_IMG, W_IMG, 6).to(device)
+    acc = Ranks(world, rank)
+
+    def step():
+        return models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    model._prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, model._prof = model._prof, None
+    t = torch.tensor([dt], device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # per-kernel time from the HIP events recorded on the launch stream during the timed steps
+    feat_ms = {0: 0.0, 1: 0.0}; mlp_ms = {0: 0.0, 1: 0.0}; rays_seen = {0: 0, 1: 0}; launches = {0: 0, 1: 0}
+    for lvl, n, e0, e1, e2 in prof:
+        feat_ms[lvl] += e0.elapsed_time(e1); mlp_ms[lvl] += e1.elapsed_time(e2); rays_seen[lvl] += n; launches[lvl] += 1
+    if rank == 0:
+        lo, hi = udist.shard_bounds(n_rays, world, rank)
+        rays_rank = (hi - lo) * args.steps
+        assert rays_seen[1] == rays_rank
+        gather = dict(bound="hbm", kernel="k_march_features<2> (NeRF level)",
+                      achieved=rays_seen[1] * GATHER_BYTES_NERF / (feat_ms[1] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                      avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
+        gather["frac"] = gather["achieved"] / gather["peak"]
+        mlp = dict(bound="mfma", kernel="k_field_mlp<8,8> (NeRF level)",
+                   achieved=rays_seen[1] * FLOP_NERF_RAY / (mlp_ms[1] * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                   avg_launch_ms=mlp_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
+        mlp["frac"] = mlp["achieved"] / mlp["peak"]
+        dominant, other = (gather, mlp) if feat_ms[1] >= mlp_ms[1] else (mlp, gather)
+        total_ms = dt * 1e3 / args.steps
+        res = {
+            "metric": "rays/sec (fwd render), 1280x1920 @ 64+128 samples", "value": n_rays * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: one 1280x1920 frame (2,457,600 rays), proposal 64 + NeRF 128 samples, "
+                                   "NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render, "
+                                   "compute_extras=True", "rays_per_step": n_rays,
+                       "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
+                       "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays},
+            "roofline": dominant, "roofline_secondary": other,
+            "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / args.steps, "mlp_prop": mlp_ms[0] / args.steps,
+                                         "features_nerf": feat_ms[1] / args.steps, "mlp_nerf": mlp_ms[1] / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+            res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3))
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,8 +53,11 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
             kn[i] = fminf(fmaxf(v, 0.0f), 1.0f);
         }
         // max-pool the pdf over the dilated intervals covering each fencepost
+        // Sums below accumulate in double: torch-CPU (the oracle) accumulates float cumsum in double
+        // (acc_type) and its vectorised float sums are pairwise-accurate; a sequential float sum over
+        // ~200-400 terms would drift by ~1e-5 in the CDF, i.e. whole samples in t.
         uint32_t jlo = 0, jhi = 0;
-        float total = 0.0f;
+        double total = 0.0;
         for (uint32_t i = 0; i + 1 < m; i++) {
             const float k = kn[i];
             while (jhi < n && t[jhi] - dilation <= k) jhi++;
@@ -63,9 +66,9 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
             for (uint32_t j = jlo; j < jhi; j++) env = fmaxf(env, p[j]);
             const float wv = env * (kn[i + 1] - kn[i]);                                  // pdf_to_weight
             wt[i] = wv;
-            total += wv;
+            total += (double)wv;
         }
-        const float norm = fmaxf(total, UCN_EPS);
+        const float norm = fmaxf((float)total, UCN_EPS);
         for (uint32_t i = 0; i + 1 < m; i++) wt[i] = wt[i] / norm;
         sd = kn + 1; w = wt + 1; nw = m - 3;                                             // models.py:175-176
     }
@@ -76,18 +79,19 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         w[i] = lg;
         mx = fmaxf(mx, lg);
     }
-    float z = 0.0f;
+    double zsum = 0.0;
     for (uint32_t i = 0; i < nw; i++) {
         const float e = expf(w[i] - mx);
         w[i] = e;
-        z += e;
+        zsum += (double)e;
     }
+    const float z = (float)zsum;
     // cdf[0] = 0, cdf[i] = min(1, sum_{k<i} pw_k) for i < nw, cdf[nw] = 1  (stepfun.py:123-127)
-    float run = 0.0f;
+    double run = 0.0;
     for (uint32_t i = 0; i < nw; i++) {
         const float pw = w[i] / z;
-        w[i] = fminf(run, 1.0f);           // cdf[i]; run == 0 exactly for i == 0
-        run += pw;
+        w[i] = fminf((float)run, 1.0f);    // cdf[i]; run == 0 exactly for i == 0
+        run += (double)pw;
     }
     // w[nw] slot: wt has 3*MAXP+1 entries, and nw <= 3*MAXP-2
     w[nw] = 1.0f;
@@ -199,7 +203,9 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
         lane_tau += tau[c];
     }
     // exclusive prefix of tau over the ray = transmittance exponent
-    float before = wave_scan(lane_tau, lane) - lane_tau;
+    // (shifted inclusive scan, not `inclusive - own`: with opaque_background the last tau is +inf)
+    float before = __shfl_up(wave_scan(lane_tau, lane), 1, 64);
+    if (lane == 0) before = 0.0f;
     float acc = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, dnum = 0.0f, lnum = 0.0f;
     float wloc[CH];
     float lane_w = 0.0f;
@@ -241,7 +247,8 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
     }
     if (!out_extras) return;
     // CDF of [w_0..w_{S-1}, bg_w] at the S+2 fenceposts [t_0..t_S, far]  (render.py:234-238)
-    float incl = wave_scan(lane_w, lane) - lane_w;
+    float incl = __shfl_up(wave_scan(lane_w, lane), 1, 64);
+    if (lane == 0) incl = 0.0f;
     float *cdf = s_cdf[wv], *tt = s_t[wv];
 #pragma unroll
     for (int c = 0; c < CH; c++) {

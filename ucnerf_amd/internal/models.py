@@ -383,19 +383,28 @@ class Model(nn.Module):
                                         0 if jitter is None else jitter.shape[1], max_jitter, N, S,
                                         sdist.data_ptr(), st))
             _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
+            prof = getattr(self, '_prof', None)
             for r0 in range(0, N, chunk):
                 n = min(chunk, N - r0)
                 sl = slice(r0, r0 + n)
+                if prof is not None:
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    e0.record()
                 _lib.check(lib.ucn_march_features(
                     ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
                     float(self.std_scale), n, S, int(self.levels_per_block), feat.data_ptr(),
                     None if coord is None else coord[sl].data_ptr(), None, st))
+                if prof is not None:
+                    e1.record()
                 _lib.check(lib.ucn_field_mlp(
                     ctypes.byref(desc), feat.data_ptr(), n * S, S,
                     None if is_prop else dirb[r0 * 2 * self.nerf_mlp.net_width_viewdirs:].data_ptr(),
                     density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
+                if prof is not None:
+                    e2.record()
+                    prof.append((i_level, n, e0, e1, e2))
             _lib.check(lib.ucn_composite(density.data_ptr(), _lib.ptr(rgbs), sdist.data_ptr(), near.data_ptr(),
                                          far.data_ptr(), d.data_ptr(), float(self.bg_intensity_range[0]),
                                          int(bool(self.opaque_background)), N, S, weights.data_ptr(),
@@ -499,7 +508,6 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     packed all-gather per frame (ucnerf_amd/internal/dist.py) -- rays are independent, weights are
     replicated, so no other communication exists on the path."""
     from . import dist as udist
-    was_training = model.training
     model.eval()
     height, width = batch['origins'].shape[:2]
     num_rays = height * width
@@ -532,5 +540,5 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
         pick = torch.randperm(n_have)[:n_vis].to(per_level[0][bundle_keys[0]].device)
         for k in bundle_keys:
             rendering[k] = [lvl[k][pick] for lvl in per_level]
-    model.train(was_training)
+    model.train()                       # ref models.py:1006 (unconditional)
     return rendering
