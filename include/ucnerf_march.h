@@ -119,8 +119,19 @@ int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, con
                        const float *basis /*[N,6]*/, const float *radii /*[N]*/,
                        const float *flip /*[N,S]|NULL*/, const float *spin /*[N,S]|NULL*/,
                        float std_scale, uint32_t N, uint32_t S, uint32_t levels_per_block,
+                       int sample_major /*1: features_out is [N*S][num_levels*level_dim] instead*/,
                        float *features_out, float *coord_out /*[N,S,3]|NULL*/,
-                       float *tmean_out /*[N,S]|NULL*/, ucn_stream_t stream);
+                       float *tmean_out /*[N,S]|NULL = mean t of the 6 multisamples (GradientScaler input)*/,
+                       ucn_stream_t stream);
+
+/* Backward of ucn_march_features w.r.t. the table (ref: grid.py:68-89 -> gridencoder.cu:248-340 composed
+ * with the erf damping and mean of models.py:495-496; positions carry no gradient, coord.py:75).
+ * grad_embeddings [rows, level_dim] is accumulated into (pre-zero it, like grid.py:77). */
+int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
+                                const float *origins, const float *directions, const float *basis,
+                                const float *radii, const float *flip, const float *spin, float std_scale,
+                                uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
+                                const float *grad_features, float *grad_embeddings, ucn_stream_t stream);
 
 /* Same featurisation for caller-supplied Gaussians (ref: models.py:485-512 predict_density as
  * called by extract.py:56-57,96): means [B,G,3], stds [B,G]; warp=0 skips the contraction. */

@@ -27,6 +27,29 @@ EPS = float(torch.finfo(torch.float32).eps)
 SQRT2 = 2 ** 0.5
 
 
+class _GridEncodeCPU(torch.autograd.Function):
+    """grid.py:24-89 on the CPU: forward and table-gradient through oracle/grid_oracle.c."""
+
+    @staticmethod
+    def forward(ctx, pts01, emb, offsets, pls, H):
+        out = grid_cpu.encode(pts01.detach(), emb.detach(), offsets, pls, H)
+        ctx.save_for_backward(pts01.detach().contiguous().float(), emb.detach(), offsets)
+        ctx.meta = (pls, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, emb, offsets = ctx.saved_tensors
+        pls, H = ctx.meta
+        B, D = pts.shape
+        L, C = offsets.numel() - 1, emb.shape[1]
+        grad = g.reshape(B, L, C).permute(1, 0, 2).contiguous().float()
+        gemb = torch.zeros_like(emb)
+        grid_cpu.grid_encode_backward(grad, pts, emb.contiguous(), offsets, gemb, B, D, C, L, np.log2(pls), H,
+                                      None, None, 0, False, 0)
+        return None, gemb, None, None, None
+
+
 # --------------------------------------------------------------------------- specs
 @dataclass
 class FieldSpec:
@@ -250,7 +273,7 @@ def field_density_features(fs: FieldSpec, sd, means, stds, no_warp=False):
         stds = flat_s.reshape(stds.shape) / 2
     emb = sd[fs.prefix + '.encoder.embeddings']
     pts01 = ((means + 1) / 2).reshape(-1, 3)                         # grid.py:162
-    feat = grid_cpu.encode(pts01, emb, offsets, pls, fs.grid_base_resolution)
+    feat = _GridEncodeCPU.apply(pts01, emb, offsets, pls, fs.grid_base_resolution)
     feat = feat.reshape(means.shape[:-1] + (fs.num_grid_levels, fs.grid_level_dim))
     damp = level_damping(stds, grid_sizes)
     feat = (feat * damp[..., None]).mean(dim=-3).flatten(-2, -1)

@@ -247,9 +247,76 @@ def gen_render_image(ref):
     save('render_image.npz', **npify(out))
 
 
+def grad_digest(name, g, out, gen):
+    """Compact record of one gradient tensor: all of it when small, else sums + a row sample."""
+    g = g.detach()
+    out[f'{name}.sum'] = g.double().sum()
+    out[f'{name}.abs'] = g.double().abs().sum()
+    if g.numel() <= 4096:
+        out[f'{name}.full'] = g
+    else:
+        rows = torch.randperm(g.shape[0], generator=gen)[:64].sort().values
+        out[f'{name}.rows'] = rows
+        out[f'{name}.sample'] = g[rows]
+
+
+def gen_train_step(ref, name, spec, seed):
+    """G10: one training step of the REFERENCE -- Model.forward(rand=True) with autograd, the
+    reference's own loss functions (train.py:173-216 / train_utils.py), backward -- with every random
+    draw captured.  Stores loss terms and gradient digests."""
+    sd = rm.init_state(spec, seed=seed)
+    model, cfg = ref_import.build_reference_model(ref, spec, sd)
+    model.train()
+    n = 96
+    rays = rm.synthetic_rays(n, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    rays['rgb'] = torch.rand(n, 3, generator=g)
+    rays['cam_idx'] = torch.randint(0, spec.training_views, (n, 1), generator=g)
+    rays['sky_segs'] = (torch.rand(n, generator=g) > 0.7).float()
+    batch = {k: (v[:, None, None, :] if v.dim() == 2 else v[:, None, None]) for k, v in rays.items()}
+    train_frac = 0.4
+    torch.manual_seed(seed + 3)
+    with ref_import.capture_rng() as cap:
+        rend, hist = model(True, dict(batch), train_frac=train_frac, compute_extras=False, zero_glo=False)
+    tu = ref.train_utils
+    losses = {}
+    losses['data'], stats = tu.compute_data_loss(batch, rend, cfg)
+    losses['anti_interlevel'] = tu.anti_interlevel_loss(hist, cfg)
+    losses['distortion'] = tu.distortion_loss(hist, cfg)
+    losses['hash_decay'] = tu.hash_decay_loss(hist, cfg)
+    if spec.model_sky:
+        losses['sky'] = 0.002 * tu.sky_loss(batch, rend)            # train.py:181 sky_loss_mult
+    if spec.brightness_correction:
+        losses['identity'] = 0.002 * tu.transformIdentityLoss(rend)  # train.py:185
+    total = sum(losses.values())
+    total.backward()
+    out = dict(seed=torch.tensor(seed), checksum=torch.tensor(state_checksum(sd), dtype=torch.float64),
+               train_frac=torch.tensor(train_frac), mse=torch.tensor(stats['mses']))
+    out.update({'ray_' + k: v for k, v in rays.items()})
+    assert len(cap.draws) == 4 * spec.num_levels
+    for lvl in range(spec.num_levels):
+        d = cap.draws[4 * lvl: 4 * lvl + 4]
+        out[f'noise{lvl}_jitter'], out[f'noise{lvl}_flip'], out[f'noise{lvl}_spin'], out[f'noise{lvl}_rand_vec'] = [x[1] for x in d]
+        out[f'L{lvl}_sdist'] = hist[lvl]['sdist']
+        out[f'L{lvl}_weights'] = hist[lvl]['weights']
+        out[f'L{lvl}_rgb'] = rend[lvl]['rgb']
+    for k, v in losses.items():
+        out['loss_' + k] = v.detach().double()
+    out['loss_total'] = total.detach().double()
+    gg = torch.Generator().manual_seed(seed + 4)
+    for pname, p in model.named_parameters():
+        if p.grad is not None:
+            grad_digest('grad_' + pname, p.grad, out, gg)
+    save(name, **npify(out))
+
+
 if __name__ == '__main__':
     ref = ref_import.load()
     torch.set_num_threads(1)              # fixed reduction order for the generating run
+    if len(sys.argv) > 1 and sys.argv[1] == 'train':
+        gen_train_step(ref, 'train_step.npz', rm.make_spec('tiny'), 71)
+        gen_train_step(ref, 'train_step_sky.npz', rm.make_spec('tiny', model_sky=True, brightness_correction=True), 81)
+        sys.exit(0)
     gen_stepfun(ref)
     gen_cast(ref)
     gen_field(ref)

@@ -233,7 +233,8 @@ def test_model_forward_vs_golden(name, kind, over):
     noise = H.noise_of(fx, spec.num_levels)
     batch = H.pin_noise(H.to_dev(H.batch_of(fx)), noise)
     cam = fx.get("eval_camidx")
-    rend, hist = model(train, batch, float(fx["train_frac"]), not train, zero_glo=not train,
+    with torch.no_grad():
+        rend, hist = model(train, batch, float(fx["train_frac"]), not train, zero_glo=not train,
                        eval_camidx=None if cam is None else cam.cuda())
     torch.cuda.synchronize()
     # Level 0 (proposal grid, res <= 512) is well conditioned: everything agrees to a few ulp.
@@ -280,6 +281,7 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
     with torch.no_grad():
         want, _ = rm.model_forward(spec, sd, rays, noise)
     model, _ = H.hip_model(spec, sd, max_chunk_rays=768)
+    torch.set_grad_enabled(False)                          # the fused (inference) march
     got, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
     assert H.maxdiff(got[-1]["rgb"].cpu(), want[-1]["rgb"]) <= H.RGB_TOL
     assert float((got[-1]["rgb"].cpu() - want[-1]["rgb"]).abs().mean()) <= 1e-5
@@ -289,6 +291,7 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
         model.levels_per_block = lpb
         again, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
         assert torch.equal(again[-1]["rgb"], got[-1]["rgb"])
+    torch.set_grad_enabled(True)
 
 
 def test_render_image_vs_golden_and_invariants():

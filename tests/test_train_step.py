@@ -1,0 +1,135 @@
+"""Training-step row against G10: one step of the REFERENCE (Model.forward with
+rand=True under autograd, the reference's own loss functions, backward), all draws captured.
+
+CPU part: the loss functions of ucnerf_amd.internal.train_utils reproduce the reference's loss values
+from the reference's own renderings / ray_history; the oracle's autograd reproduces its gradients.
+GPU part: the HIP train graph (fused featurisation forward + hand-written backward, library GEMMs for
+the dense layers) reproduces losses and gradients."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import raymarch as rm
+
+CASES = [("train_step.npz", {}), ("train_step_sky.npz", dict(model_sky=True, brightness_correction=True))]
+CFG = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                            anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                            hash_decay_mults=0.1, disable_multiscale_loss=False)
+
+
+def train_batch(fx, device="cpu"):
+    b = {k[4:]: v for k, v in fx.items() if k.startswith("ray_")}
+    return {k: (v[:, None, None, :] if v.dim() == 2 else v[:, None, None]).to(device) for k, v in b.items()}
+
+
+def losses_of(tu, batch, rend, hist, spec):
+    out = {}
+    out['data'], stats = tu.compute_data_loss(batch, rend, CFG)
+    out['anti_interlevel'] = tu.anti_interlevel_loss(hist, CFG)
+    out['distortion'] = tu.distortion_loss(hist, CFG)
+    out['hash_decay'] = tu.hash_decay_loss(hist, CFG)
+    if spec.model_sky:
+        out['sky'] = 0.002 * tu.sky_loss(batch, rend)
+    if spec.brightness_correction:
+        out['identity'] = 0.002 * tu.transformIdentityLoss(rend)
+    return out, stats
+
+
+def check_grad(fx, name, g, rtol):
+    """Compare a gradient with its digest (full tensor, or sums + sampled rows)."""
+    g = g.detach().cpu()
+    scale = float(fx[f"grad_{name}.abs"]) / max(g.numel(), 1)          # mean |g| of the reference
+    assert abs(float(g.double().abs().sum()) - float(fx[f"grad_{name}.abs"])) <= rtol * float(fx[f"grad_{name}.abs"]) + 1e-12, name
+    if f"grad_{name}.full" in fx:
+        want = fx[f"grad_{name}.full"]
+        assert H.maxdiff(g, want) <= rtol * max(float(want.abs().max()), scale) + 1e-12, name
+    else:
+        want = fx[f"grad_{name}.sample"]
+        got = g[fx[f"grad_{name}.rows"].long()]
+        assert H.maxdiff(got, want) <= rtol * max(float(want.abs().max()), 8 * scale) + 1e-12, name
+
+
+@pytest.mark.parametrize("name,over", CASES)
+def test_loss_functions_match_reference_values(name, over):
+    """a16: our train_utils on the reference's own outputs."""
+    from ucnerf_amd.internal import train_utils as tu
+    fx = H.load(name)
+    spec = rm.make_spec("tiny", **over)
+    hist = [dict(sdist=fx[f"L{l}_sdist"], weights=fx[f"L{l}_weights"]) for l in range(2)]
+    rend = [dict(rgb=fx[f"L{l}_rgb"], weights=fx[f"L{l}_weights"]) for l in range(2)]
+    batch = train_batch(fx)
+    data, stats = tu.compute_data_loss(batch, rend, CFG)
+    assert abs(float(data) - float(fx["loss_data"])) <= 1e-6
+    assert np.allclose(stats['mses'], fx["mse"].numpy(), rtol=1e-5)
+    assert abs(float(tu.anti_interlevel_loss(hist, CFG)) - float(fx["loss_anti_interlevel"])) <= 2e-6 * max(1.0, float(fx["loss_anti_interlevel"]))
+    # O(S) prefix-sum form of the O(S^2) pairwise distortion loss
+    assert abs(float(tu.distortion_loss(hist, CFG)) - float(fx["loss_distortion"])) <= 1e-6 * max(1.0, float(fx["loss_distortion"]))
+    if spec.model_sky:
+        assert abs(0.002 * float(tu.sky_loss(batch, rend)) - float(fx["loss_sky"])) <= 1e-7
+
+
+@pytest.mark.parametrize("name,over", CASES[:1])
+def test_oracle_autograd_matches_reference_gradients(name, over):
+    fx = H.load(name)
+    spec = rm.make_spec("tiny", **over)
+    sd = H.state_for(fx, spec)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    state = dict(sd); state.update(params)
+    b = {k[4:]: v for k, v in fx.items() if k.startswith("ray_")}
+    rend, hist = rm.model_forward(spec, state, b, H.noise_of(fx, 2), train_frac=float(fx["train_frac"]),
+                                  compute_extras=False, training=True)
+    from ucnerf_amd.internal import train_utils as tu
+    batch = train_batch(fx)
+    rend = [{k: (v[:, None, None] if torch.is_tensor(v) else v) for k, v in r.items()} for r in rend]
+    hist = [{k: (v[:, None, None] if torch.is_tensor(v) and v.dim() >= 1 and k != 'loss_hash_decay' else v) for k, v in h.items()} for h in hist]
+    losses, _ = losses_of(tu, batch, rend, hist, spec)
+    for k, v in losses.items():
+        assert abs(float(v) - float(fx["loss_" + k])) <= 2e-6 * max(1.0, abs(float(fx["loss_" + k]))), k
+    sum(losses.values()).backward()
+    # The train-mode forward is not bit-identical across hosts/thread counts (GEMM blocking), and the
+    # 16-level grid amplifies 1e-7 forward differences (DESIGN.md "Parity analysis"): proposal-side
+    # gradients agree to 1e-3, NeRF-side dense gradients to 2e-2, single rows of the fine table only in
+    # aggregate.
+    for pname, p in params.items():
+        if f"grad_{pname}.abs" not in fx:
+            continue
+        if pname == "nerf_mlp.encoder.embeddings":
+            assert abs(float(p.grad.double().abs().sum()) - float(fx[f"grad_{pname}.abs"])) <= 1e-3 * float(fx[f"grad_{pname}.abs"])
+        else:
+            check_grad(fx, pname, p.grad, 1e-3 if pname.startswith("prop") else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,over", CASES)
+def test_hip_train_graph_matches_reference_step(name, over):
+    from ucnerf_amd.internal import train_utils as tu
+    fx = H.load(name)
+    spec = rm.make_spec("tiny", **over)
+    sd = H.state_for(fx, spec)
+    model, cfg = H.hip_model(spec, sd)
+    model.train()
+    noise = H.noise_of(fx, 2)
+    batch = H.pin_noise(train_batch(fx, "cuda"), noise)
+    batch['rand_vec'] = batch['rand_vec'][:, None, None, :]
+    rend, hist = model(True, batch, float(fx["train_frac"]), False, zero_glo=False)
+    assert rend[-1]['rgb'].shape == fx["L1_rgb"].shape and rend[-1]['rgb'].requires_grad
+    losses, _ = losses_of(tu, batch, rend, hist, spec)
+    for k, v in losses.items():
+        # data / interlevel / distortion inherit the per-pixel noise floor of the fine NeRF grid
+        assert abs(float(v) - float(fx["loss_" + k])) <= 2e-4 * max(1.0, abs(float(fx["loss_" + k]))), (k, float(v), float(fx["loss_" + k]))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    for pname, p in model.named_parameters():
+        if f"grad_{pname}.abs" not in fx:
+            continue
+        assert p.grad is not None, pname
+        fine_table = pname == "nerf_mlp.encoder.embeddings"
+        # dense-layer gradients are sums over ~12k samples: the fine-level noise averages out (1e-2);
+        # individual rows of the 16-level table see single samples -> only their aggregate is compared
+        if fine_table:
+            assert abs(float(p.grad.double().abs().sum()) - float(fx[f"grad_{pname}.abs"])) <= 2e-2 * float(fx[f"grad_{pname}.abs"])
+        else:
+            check_grad(fx, pname, p.grad, 2e-2)

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -56,7 +56,9 @@ SIGNATURES = {
     "ucn_resample": [c_vp, c_vp, c_u32, c_f32, c_f32, c_f32, c_vp, c_vp, c_u32, c_f32, c_u32, c_u32, c_vp, c_vp],
     "ucn_cone_basis": [c_vp, c_vp, c_u32, c_vp, c_vp],
     "ucn_march_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
-                           c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
+                           c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                    c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],
     "ucn_field_mlp": [ctypes.POINTER(UcnField), c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],

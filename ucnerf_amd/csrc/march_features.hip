@@ -99,10 +99,60 @@ __device__ __forceinline__ void contract_to_unit(float x, float y, float z, floa
     sd_out = sd;
 }
 
+// Backward of level_lookup w.r.t. the table: grad_table[row_k] += w_k * g (gridencoder.cu:304-339).
+template <uint32_t C>
+__device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restrict__ gtab, float px, float py,
+                                              float pz, const float (&g)[C]) {
+    if (px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f) return;
+    float fx = fmaf(px, lv.scale, 0.5f), fy = fmaf(py, lv.scale, 0.5f), fz = fmaf(pz, lv.scale, 0.5f);
+    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
+    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t x = x0 + (k & 1u), y = y0 + ((k >> 1) & 1u), z = z0 + ((k >> 2) & 1u);
+        uint32_t idx = lv.hashed ? ucn_hash3(x, y, z) : x * lv.stride[0] + y * lv.stride[1] + z * lv.stride[2];
+        idx = lv.mask ? (idx & lv.mask) : (idx < lv.rows ? idx : idx % lv.rows);
+        float w = 1.0f;
+        w *= (k & 1u) ? fx : gx;
+        w *= (k & 2u) ? fy : gy;
+        w *= (k & 4u) ? fz : gz;
+        float *r = gtab + (size_t)idx * C;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, w * g[c]);
+    }
+}
+
+template <uint32_t C>
+__device__ __forceinline__ void featurise_bwd(const UcnLevels &lvls, float *__restrict__ grad_table, uint32_t lvl0,
+                                              uint32_t lvl1, const float (&u)[6][3], const float (&sd)[6], uint32_t G,
+                                              size_t B, size_t b, const float *__restrict__ grad, bool sample_major) {
+    const uint32_t F = lvls.L * C;
+    for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
+        const UcnLevel lv = lvls.lv[lvl];
+        float *gtab = grad_table + (size_t)lv.first_row * C;
+        const float *gp = sample_major ? grad + b * F + (size_t)lvl * C : grad + ((size_t)lvl * B + b) * C;
+        float gout[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) gout[c] = gp[c] / (float)G;          // d(mean over G)
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            if (j < G) {
+                const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+                float g[C];
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) g[c] = gout[c] * damp;
+                level_scatter<C>(lv, gtab, u[j][0], u[j][1], u[j][2], g);
+            }
+        }
+    }
+}
+
 template <uint32_t C>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
                                           uint32_t lvl1, const float (&u)[6][3], const float (&sd)[6], uint32_t G,
-                                          size_t B, size_t b, float *__restrict__ out) {
+                                          size_t B, size_t b, float *__restrict__ out, bool sample_major = false) {
+    const uint32_t F_out = lvls.L * C;
     for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
         const float *tab = table + (size_t)lv.first_row * C;
@@ -120,7 +170,7 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
                 for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
             }
         }
-        float *o = out + ((size_t)lvl * B + b) * C;
+        float *o = sample_major ? out + b * F_out + (size_t)lvl * C : out + ((size_t)lvl * B + b) * C;
         const float inv = (float)G;
         if constexpr (C == 2) {
             *reinterpret_cast<float2 *>(o) = make_float2(acc[0] / inv, acc[1] / inv);
@@ -133,15 +183,12 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
     }
 }
 
-template <uint32_t C>
-__global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
-                                                        HexPattern hx, float std_scale, uint32_t N, uint32_t S,
-                                                        uint32_t lpb, float *__restrict__ features,
-                                                        float *__restrict__ coord_out, float *__restrict__ tmean_out) {
-    const size_t B = (size_t)N * S;
-    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+// The six multisample Gaussians of sample (ray, s): render.py:108-152 then coord.py:60-72 and the
+// /2 + [0,1] mapping.  Shared by the forward and the backward kernel (the backward recomputes it:
+// 200 flops instead of reading back 6x4 floats per sample).
+__device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPattern &hx, float std_scale, uint32_t ray,
+                                            uint32_t s, uint32_t S, float (&u)[6][3], float (&sd)[6],
+                                            float (&csum)[3], float &tsum) {
     const float nr = in.near_[ray], fr = in.far_[ray];
     const float s0 = in.sdist[(size_t)ray * (S + 1) + s], s1 = in.sdist[(size_t)ray * (S + 1) + s + 1];
     const float t0 = s0 * fr + (1.0f - s0) * nr, t1 = s1 * fr + (1.0f - s1) * nr;
@@ -165,8 +212,8 @@ __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const fl
         keep = in.flip[(size_t)ray * S + s] > 0.5f;
         spin2pi = 6.2831854820251465f * in.spin[(size_t)ray * S + s];
     }
-    float u[6][3], sd[6];
-    float csum0 = 0.0f, csum1 = 0.0f, csum2 = 0.0f, tsum = 0.0f;
+    csum[0] = csum[1] = csum[2] = 0.0f;
+    tsum = 0.0f;
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
         const float t = t0 + a_ * (base + hx.cj[j] * root);
@@ -187,17 +234,49 @@ __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const fl
         const float wz = ((l0 * e1z + l1 * e2z) + t * dz) + oz;
         float c0, c1, c2;
         contract_to_unit(wx, wy, wz, sdev, true, u[j][0], u[j][1], u[j][2], sd[j], c0, c1, c2);
-        csum0 += c0; csum1 += c1; csum2 += c2; tsum += t;
+        csum[0] += c0; csum[1] += c1; csum[2] += c2; tsum += t;
     }
+}
+
+template <uint32_t C>
+__global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
+                                                        HexPattern hx, float std_scale, uint32_t N, uint32_t S,
+                                                        uint32_t lpb, int sample_major, float *__restrict__ features,
+                                                        float *__restrict__ coord_out, float *__restrict__ tmean_out) {
+    const size_t B = (size_t)N * S;
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    float u[6][3], sd[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, sd, csum, tsum);
     const uint32_t lvl0 = blockIdx.y * lpb;
     const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
-    featurise<C>(lvls, table, lvl0, lvl1, u, sd, 6, B, b, features);
+    featurise<C>(lvls, table, lvl0, lvl1, u, sd, 6, B, b, features, sample_major != 0);
     if (blockIdx.y == 0) {
         if (coord_out) {
-            coord_out[b * 3 + 0] = csum0 / 6.0f; coord_out[b * 3 + 1] = csum1 / 6.0f; coord_out[b * 3 + 2] = csum2 / 6.0f;
+            coord_out[b * 3 + 0] = csum[0] / 6.0f; coord_out[b * 3 + 1] = csum[1] / 6.0f; coord_out[b * 3 + 2] = csum[2] / 6.0f;
         }
         if (tmean_out) tmean_out[b] = tsum / 6.0f;
     }
+}
+
+// d(loss)/d(table) of k_march_features: grad_table[rows of the 6x8 corners] += w_corner * damp_j * g / 6.
+// (means/stds carry no gradient: coord.track_linearize is @torch.no_grad, coord.py:75, and sdist is
+//  detached, models.py:204-205.)  fp32 atomics in L2, like kernel_grid_backward (gridencoder.cu:336).
+template <uint32_t C>
+__global__ __launch_bounds__(256) void k_march_features_bwd(UcnLevels lvls, float *__restrict__ grad_table, RayInputs in,
+                                                            HexPattern hx, float std_scale, uint32_t N, uint32_t S,
+                                                            uint32_t lpb, int sample_major,
+                                                            const float *__restrict__ grad_features) {
+    const size_t B = (size_t)N * S;
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    float u[6][3], sd[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, sd, csum, tsum);
+    const uint32_t lvl0 = blockIdx.y * lpb;
+    const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
+    featurise_bwd<C>(lvls, grad_table, lvl0, lvl1, u, sd, 6, B, b, grad_features, sample_major != 0);
 }
 
 // predict_density's featurisation for caller-supplied Gaussians (extract.py / API parity)
@@ -259,8 +338,8 @@ int field_levels(const ucn_field_t *f, UcnLevels *lv) {
 extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                   const float *origins, const float *directions, const float *basis,
                                   const float *radii, const float *flip, const float *spin, float std_scale,
-                                  uint32_t N, uint32_t S, uint32_t levels_per_block, float *features_out,
-                                  float *coord_out, float *tmean_out, ucn_stream_t stream) {
+                                  uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
+                                  float *features_out, float *coord_out, float *tmean_out, ucn_stream_t stream) {
     UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && features_out,
                 "march_features: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
@@ -276,7 +355,7 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     hipStream_t st = (hipStream_t)stream;
 #define UCN_MF(CC)                                                                                              \
     hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), 0, st, lv, f->embeddings, in, hx, std_scale, N, S, \
-                       levels_per_block, features_out, coord_out, tmean_out)
+                       levels_per_block, sample_major, features_out, coord_out, tmean_out)
     switch (lv.C) {
         case 1: UCN_MF(1); break;
         case 2: UCN_MF(2); break;
@@ -310,5 +389,37 @@ extern "C" int ucn_points_features(const ucn_field_t *f, const float *means, con
     }
 #undef UCN_PF
     UCN_LAUNCH_CHECK("points_features");
+    return 0;
+}
+
+extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
+                                           const float *origins, const float *directions, const float *basis,
+                                           const float *radii, const float *flip, const float *spin, float std_scale,
+                                           uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
+                                           const float *grad_features, float *grad_embeddings, ucn_stream_t stream) {
+    UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
+                "march_features_backward: null pointer argument");
+    UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
+    UcnLevels lv;
+    if (int rc = field_levels(f, &lv)) return rc;
+    if (N == 0) return 0;
+    if (levels_per_block == 0) levels_per_block = 1;
+    const size_t B = (size_t)N * S;
+    UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
+    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
+    const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
+    const HexPattern hx = make_hex();
+    hipStream_t st = (hipStream_t)stream;
+#define UCN_MB(CC)                                                                                                  \
+    hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \
+                       S, levels_per_block, sample_major, grad_features)
+    switch (lv.C) {
+        case 1: UCN_MB(1); break;
+        case 2: UCN_MB(2); break;
+        case 4: UCN_MB(4); break;
+        case 8: UCN_MB(8); break;
+    }
+#undef UCN_MB
+    UCN_LAUNCH_CHECK("march_features_backward");
     return 0;
 }

@@ -302,14 +302,18 @@ class Model(nn.Module):
                                                         model_sky=getattr(self.config, 'model_sky', False))
 
     # ------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, eval_camidx=None):
         """ref models.py:97-365.  `batch` may carry two optional extra keys that pin the random
         draws (the reference draws them from torch's global RNG, render.py:123-124,140 and
         stepfun.py:216): 'rand_vec' [..., num_levels*3] and 'march_noise' (list of per-level dicts
-        with 'jitter', 'flip', 'spin')."""
-        out = self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
-        return out
+        with 'jitter', 'flip', 'spin').
+
+        With autograd enabled the differentiable graph of train_graph.py is built (HIP featurisation
+        forward/backward + library GEMMs); under torch.no_grad() the fully fused HIP march runs."""
+        if torch.is_grad_enabled():
+            from . import train_graph
+            return train_graph.march_train(self, rand, batch, train_frac, compute_extras, eval_camidx)
+        return self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
 
     def _march(self, rand, batch, train_frac, compute_extras, eval_camidx, want_history):
         lib = _lib.load()
@@ -394,7 +398,7 @@ class Model(nn.Module):
                     ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
-                    float(self.std_scale), n, S, int(self.levels_per_block), feat.data_ptr(),
+                    float(self.std_scale), n, S, int(self.levels_per_block), 0, feat.data_ptr(),
                     None if coord is None else coord[sl].data_ptr(), None, st))
                 if prof is not None:
                     e1.record()

@@ -1,0 +1,253 @@
+"""Differentiable (training) form of Model.forward -- SURVEY.md 8(a15/a16), round-1 state.
+
+What carries gradients in the reference's training step (train.py:165-221): the hash tables (through
+_grid_encode.backward, grid.py:68-89), the MLP weights, and -- when enabled -- the sky / colour-correction
+parameters.  Sample positions do not (`stop_level_grad`, models.py:204-205; `track_linearize` is
+@torch.no_grad, coord.py:75).  Here:
+
+* resampling, cone basis and the fused cast/contract/hash-grid/erf featurisation are the same HIP kernels as
+  in rendering; their backward (`ucn_march_features_backward`, fp32 atomics into the table gradient) is
+  hand-written HIP and replaces kernel_grid_backward + the autograd of the erf/mean glue;
+* the dense layers and the O(S) per-ray compositing run as library GEMMs / elementwise ops under torch
+  autograd (hipBLASLt via F.linear; bf16 under autocast like the reference's `accelerator.autocast()`).
+  A fused MFMA backward on the register-chained engine is the next step; until then this
+  is a GPU path through vendor GEMMs, not a fallback to the CPU: host tensors still raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+EPS = float(torch.finfo(torch.float32).eps)
+
+
+class _FieldFeatures(torch.autograd.Function):
+    """features[N*S, L*C] = HIP featurisation of one level; backward scatters into the table gradient."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb):
+        lib = _lib.load()
+        desc = mlp.field()
+        L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
+        feat = torch.empty(N * S, L * C, device=embeddings.device)
+        coord = torch.empty(N, S, 3, device=embeddings.device)
+        tmean = torch.empty(N, S, device=embeddings.device)
+        _lib.check(lib.ucn_march_features(ctypes.byref(desc), *[_lib.ptr(t) for t in geom], float(std_scale), N, S,
+                                          int(lpb), 1, feat.data_ptr(), coord.data_ptr(), tmean.data_ptr(), _lib.stream()))
+        ctx.mlp, ctx.geom, ctx.dims = mlp, geom, (N, S, float(std_scale), int(lpb))
+        ctx.mark_non_differentiable(coord, tmean)
+        return feat, coord, tmean
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_feat, _g_coord, _g_tmean):
+        lib = _lib.load()
+        N, S, std_scale, lpb = ctx.dims
+        mlp = ctx.mlp
+        emb = mlp.encoder.embeddings
+        grad = torch.zeros_like(emb)                                   # dense, like grid.py:77
+        g = g_feat.contiguous().float()
+        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
+                                                   N, S, lpb, 1, g.data_ptr(), grad.data_ptr(), _lib.stream()))
+        return grad, None, None, None, None, None, None
+
+
+class GradientScaler(torch.autograd.Function):
+    """ref train_utils.py:101-111: identity forward, grads scaled by clamp(ray_dist^2, 0, 1)."""
+
+    @staticmethod
+    def forward(ctx, colors, sigmas, ray_dist):
+        ctx.save_for_backward(ray_dist)
+        return colors, sigmas
+
+    @staticmethod
+    def backward(ctx, g_colors, g_sigmas):
+        (ray_dist,) = ctx.saved_tensors
+        k = torch.square(ray_dist).clamp(0, 1)
+        return g_colors * k[..., None], g_sigmas * k, None
+
+
+def view_encoding(d, deg):
+    """coord.py:214-225 pos_enc(min_deg=0, max_deg=deg, append_identity=True)."""
+    scales = 2 ** torch.arange(0, deg, device=d.device)
+    scaled = (d[..., None, :] * scales[:, None]).reshape(d.shape[:-1] + (-1,))
+    return torch.cat([d, torch.sin(torch.cat([scaled, scaled + 0.5 * torch.pi], dim=-1))], dim=-1)
+
+
+def field_heads(mlp, feat, viewdirs, N, S):
+    """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs)."""
+    x = mlp.density_layer(feat).reshape(N, S, -1)
+    density = F.softplus(x[..., 0] + mlp.density_bias)
+    if mlp.disable_rgb:
+        return density, torch.zeros(N, S, 3, device=feat.device)
+    enc = view_encoding(viewdirs, mlp.deg_view)[:, None, :].expand(N, S, -1)
+    h = torch.cat([x, enc], dim=-1)
+    skip = h
+    for i in range(mlp.net_depth_viewdirs):
+        h = F.relu(mlp.get_submodule(f"lin_second_stage_{i}")(h))
+        if i == mlp.skip_layer_dir:
+            h = torch.cat([h, skip], dim=-1)
+    rgb = torch.sigmoid(mlp.rgb_premultiplier * mlp.rgb_layer(h) + mlp.rgb_bias)
+    return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
+
+
+def alpha_weights(density, tdist, dirs, opaque_background):
+    """render.py:155-174."""
+    tau = density * ((tdist[..., 1:] - tdist[..., :-1]) * torch.norm(dirs[..., None, :], dim=-1))
+    if opaque_background:
+        tau = torch.cat([tau[..., :-1], torch.full_like(tau[..., -1:], torch.inf)], dim=-1)
+    trans = torch.exp(-torch.cat([torch.zeros_like(tau[..., :1]), torch.cumsum(tau[..., :-1], dim=-1)], dim=-1))
+    return (1 - torch.exp(-tau)) * trans
+
+
+def composite(rgbs, weights, tdist, bg):
+    """render.py:203-216 (rgb / depth / acc; the distance extras are display-only and not differentiated)."""
+    acc = weights.sum(dim=-1)
+    bg_w = (1 - acc[..., None]).clamp_min(0.)
+    rgb = (weights[..., None] * rgbs).sum(dim=-2) + bg_w * bg
+    t_mid = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
+    depth = torch.nan_to_num((weights * t_mid).sum(dim=-1) / acc.clamp_min(EPS), torch.inf)
+    depth = torch.clip(depth, tdist[..., 0], tdist[..., -1]).clone()
+    depth[acc < 0.6] = 300
+    return dict(rgb=rgb, depth=depth, acc=acc)
+
+
+def hash_decay(mlp):
+    """models.py:297-306: mean over levels and channels of the per-level mean of embeddings^2
+    (torch_scatter.segment_coo(reduce='mean') over the sorted level index, restated with slices)."""
+    emb, off = mlp.encoder.embeddings, mlp.encoder._offsets_np
+    return torch.stack([(emb[int(off[i]):int(off[i + 1])] ** 2).mean(dim=0) for i in range(len(off) - 1)]).mean()
+
+
+def sky_forward(net, origins, directions, cam_dirs, far):
+    """models.py:852-904 + :743-850 with torch ops (training only; rendering uses csrc/sky.hip)."""
+    n = origins.shape[0]
+    near = far.reshape(n, 1)
+    sky_far = torch.full_like(near, float(near[0].detach().cpu().item()) * 1.5)
+    tv = torch.linspace(0., 1., steps=120, device=origins.device)
+    z = (near * (1. - tv) + 1. / sky_far * tv).expand(n, 120)
+    pts = origins[:, None, :] + directions[:, None, :] * z[:, :, None]
+    views = cam_dirs[:, None, :].expand(-1, 120, -1)
+    freqs = 2. ** torch.linspace(0., 3., 4, device=origins.device)
+    venc = torch.cat([views] + [fn(views * f) for f in freqs for fn in (torch.sin, torch.cos)], dim=-1)
+    h = pts
+    for i in range(8):
+        h = F.relu(net.pts_linears[i](h))
+        if i == 4:
+            h = torch.cat([pts, h], dim=-1)
+    sigma = net.alpha_linear(h)
+    h = F.relu(net.views_linears[0](torch.cat([net.feature_linear(h), venc], dim=-1)))
+    rgb = torch.sigmoid(net.rgb_linear(h))
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], dim=-1)
+    dists = dists * torch.norm(directions[:, None, :], dim=-1)
+    alpha = 1. - torch.exp(-F.relu(sigma[..., 0]) * dists)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], dim=-1), dim=-1)[:, :-1]
+    return ((alpha * trans)[..., None] * rgb).sum(dim=-2)
+
+
+def brightness_forward(bc, idx, which="latent_code"):
+    x = getattr(bc, which)[idx.reshape(-1).long()]
+    for lin in bc.brightness_MLP.pts_linears:
+        x = F.relu(lin(x))
+    return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)
+
+
+def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
+    """Model.forward with an autograd graph (ref models.py:97-365)."""
+    from .models import _f32, _u_table
+    lib = _lib.load()
+    origins = batch['origins']
+    _lib.require_device(origins, "batch['origins']")
+    dev = origins.device
+    prefix = tuple(origins.shape[:-1])
+    N = int(np.prod(prefix))
+    o, d = _f32(origins, N, 3), _f32(batch['directions'], N, 3)
+    vd, cam = _f32(batch['viewdirs'], N, 3), _f32(batch['cam_dirs'], N, 3)
+    rad, near, far = _f32(batch['radii'], N, 1), _f32(batch['near'], N, 1), _f32(batch['far'], N, 1)
+    pinned_vec = batch.get('rand_vec')
+    if pinned_vec is not None:
+        pinned_vec = _f32(pinned_vec, N, 3 * model.num_levels)
+    pinned = batch.get('march_noise')
+    st = _lib.stream()
+    cfg = model.config
+    anneal = (model.anneal_slope * train_frac) / ((model.anneal_slope - 1) * train_frac + 1) if model.anneal_slope > 0 else 1.
+    renderings, ray_history = [], []
+    sdist_prev = weights_prev = None
+    n_prev, prod = 0, 1
+    for i_level in range(model.num_levels):
+        is_prop = i_level < model.num_levels - 1
+        S = model.num_prop_samples if is_prop else model.num_nerf_samples
+        mlp = model.get_submodule(f'prop_mlp_{i_level}') if is_prop else model.nerf_mlp
+        dilation = model.dilation_bias + model.dilation_multiplier * 1.0 / prod
+        prod *= S
+        jitter = flip = spin = None
+        u_tab, max_jitter = _u_table(S, bool(rand), dev)
+        if rand:
+            pn = pinned[i_level] if pinned is not None else {}
+            jcols = 1 if model.single_jitter else S
+            jitter = _f32(pn['jitter'], N, jcols) if 'jitter' in pn else torch.rand(N, jcols, device=dev)
+            flip = _f32(pn['flip'], N, S) if 'flip' in pn else torch.rand(N, S, device=dev)
+            spin = _f32(pn['spin'], N, S) if 'spin' in pn else torch.rand(N, S, device=dev)
+        rvec = (pinned_vec[:, 3 * i_level:3 * i_level + 3].contiguous() if pinned_vec is not None
+                else torch.randn(N, 3, device=dev))
+        sdist = torch.empty(N, S + 1, device=dev)
+        basis = torch.empty(N, 6, device=dev)
+        wp = None if weights_prev is None else weights_prev.detach().contiguous()
+        _lib.check(lib.ucn_resample(_lib.ptr(sdist_prev), _lib.ptr(wp), n_prev, dilation, anneal,
+                                    float(model.resample_padding), u_tab.data_ptr(), _lib.ptr(jitter),
+                                    0 if jitter is None else jitter.shape[1], max_jitter, N, S, sdist.data_ptr(), st))
+        _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
+        geom = (sdist, near, far, o, d, basis, rad, flip, spin)
+        feat, coord, tmean = _FieldFeatures.apply(mlp.encoder.embeddings, mlp, geom, N, S, model.std_scale,
+                                                  model.levels_per_block)
+        density, rgbs = field_heads(mlp, feat, vd, N, S)
+        if getattr(cfg, 'brightness_correction', False):              # models.py:233-235 (gated on this flag)
+            rgbs, density = GradientScaler.apply(rgbs, density, tmean)
+        tdist = sdist * far + (1 - sdist) * near
+        weights = alpha_weights(density.float(), tdist, d, model.opaque_background)
+        rendering = composite(rgbs.float(), weights, tdist, float(model.bg_intensity_range[0]))
+        rendering = {k: v.reshape(prefix + v.shape[1:]) for k, v in rendering.items()}
+        rendering['weights'] = weights.reshape(prefix + (S,))
+        if compute_extras:
+            n_vis = getattr(cfg, 'vis_num_rays', 16)
+            rendering['ray_sdist'] = sdist[:n_vis]
+            rendering['ray_weights'] = weights[:n_vis]
+            rendering['ray_rgbs'] = rgbs[:n_vis]
+        hist = dict(coord=coord.reshape(prefix + (S, 3)), density=density.reshape(prefix + (S,)),
+                    rgb=rgbs.reshape(prefix + (S, 3)), raw_grad_density=None, grad_pred=None, normals=None,
+                    normals_pred=None, roughness=None)
+        if model.training:
+            hist['loss_hash_decay'] = hash_decay(mlp)
+        hist['sdist'] = sdist.reshape(prefix + (S + 1,)).clone()
+        hist['weights'] = weights.reshape(prefix + (S,)).clone()
+        renderings.append(rendering)
+        ray_history.append(hist)
+        sdist_prev, weights_prev, n_prev = sdist, weights, S
+    if compute_extras:
+        final = (renderings[-1]['ray_rgbs'] * renderings[-1]['ray_weights'][..., None]).sum(dim=-2)
+        for r in renderings[:-1]:
+            r['ray_rgbs'] = final[:, None, :].expand(r['ray_rgbs'].shape)
+    with_sky = getattr(cfg, 'model_sky', False)
+    if with_sky:
+        sky = sky_forward(model.skynerf, o, d, cam, far)
+        for r in renderings:
+            r['sky_rgbs'] = sky
+    if getattr(cfg, 'brightness_correction', False):
+        idx = batch['cam_idx'].reshape(N, -1)[:, 0] if eval_camidx is None else eval_camidx.to(dev).reshape(-1)[:1].repeat(N)
+        A = brightness_forward(model.brightness_corr, idx)
+        A_sky = brightness_forward(model.brightness_corr, idx, 'sky_latent_code') if with_sky else None
+        last_w = renderings[-1]['weights'].reshape(N, -1)
+        for r in renderings:
+            rgb = torch.bmm(A[:, :3, :3], r['rgb'].reshape(N, 3, 1)) + A[:, :3, 3:]
+            if with_sky:
+                opac = 1 - last_w.sum(dim=-1, keepdim=True)
+                rgb = rgb + opac[..., None] * (torch.bmm(A_sky[:, :3, :3], r['sky_rgbs'].reshape(N, 3, 1)) + A_sky[:, :3, 3:])
+            r['rgb'] = rgb.reshape(N, 1, 1, 3) if eval_camidx is None else rgb.reshape(N, 3)
+            r['affine_trans'] = A
+            if with_sky:
+                r['affine_trans_sky'] = A_sky
+    return renderings, ray_history
