@@ -85,7 +85,9 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=4096):
     This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check)."""
     from oracle import raymarch as rm
     spec = rm.make_spec("B")
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch-CPU eager ops stop scaling (and regress) beyond a few dozen threads on these small tensors:
+    # 256 threads measured 82 rays/s on the MI355X host; 32 is the better configuration for the baseline.
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     idx = torch.linspace(0, rays_flat["origins"].shape[0] - 1, n_sample).long()
     sub = {k: v[idx].cpu() for k, v in rays_flat.items()}
     noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3].cpu()) for l in range(2)]
@@ -102,12 +104,53 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=4096):
                 rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
 
 
+def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
+    """BASELINE configs[2]: one training step on an 8192-ray batch -- Model.forward(rand=True) under bf16
+    autocast, the losses of train.py:173-216 with waymo defaults, backward, nan_to_num on grads
+    (train_utils.py:335-344), Adam(lr 0.01, betas (0.9, 0.99), eps 1e-8; waymo.gin:6).  Median of `steps`."""
+    import types
+    from ucnerf_amd.internal import train_utils as tu
+    cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                                anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                                hash_decay_mults=0.1, disable_multiscale_loss=False)
+    g = torch.Generator(device=device).manual_seed(2)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+    model.train()
+    times = []
+    n_total = batch_flat['origins'].shape[0]
+    for it in range(steps + 2):
+        idx = torch.randint(0, n_total, (n_rays,), device=device, generator=g)
+        batch = {k: v[idx][:, None, None, :] for k, v in batch_flat.items()}
+        batch['rgb'] = torch.rand(n_rays, 1, 1, 3, device=device, generator=g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            rend, hist = model(True, batch, 0.5, False, zero_glo=False)
+            loss = (tu.compute_data_loss(batch, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg)
+                    + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.nan_to_num_()
+        opt.step()
+        torch.cuda.synchronize()
+        if it >= 2:
+            times.append((time.perf_counter() - t0) * 1e3)
+    model.eval()
+    return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
+                autocast="bf16 GEMMs, fp32 tables/compositing",
+                graph="HIP resample + fused featurisation fwd/bwd; dense layers via library GEMMs (round 1)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--mlp-mode", type=int, default=None, help="0 fp32-input MFMA, 1 split-f16 MFMA (default: the package default)")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
@@ -121,6 +164,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
     from ucnerf_amd.internal import models, dist as udist
+    if args.mlp_mode is not None:
+        models.MLP.mlp_mode = args.mlp_mode
     model, cfg, sd = build_model(device)
     if args.levels_per_block:
         model.levels_per_block = args.levels_per_block
@@ -182,7 +227,8 @@ def main():
                                    "NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render, "
                                    "compute_extras=True", "rays_per_step": n_rays,
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
-                       "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays},
+                       "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
+                       "mlp_mode": {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]},
             "roofline": dominant, "roofline_secondary": other,
             "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / args.steps, "mlp_prop": mlp_ms[0] / args.steps,
                                          "features_nerf": feat_ms[1] / args.steps, "mlp_nerf": mlp_ms[1] / args.steps},
@@ -190,6 +236,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3))
+        if world == 1 and not args.no_train:
+            flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+            res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -91,6 +91,10 @@ typedef struct ucn_field {
     float density_bias, rgb_premultiplier, rgb_bias, rgb_padding;
     /* MFMA-ordered weight copies, filled by ucn_field_pack; size from ucn_field_packed_floats */
     float *packed;
+    /* 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products, 157 TF ceiling);
+     * 1: split-f16 MFMA (hi/lo f16 operands, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate; ~3e-7
+     *    relative per product).  Must be the same at ucn_field_pack and ucn_field_mlp time. */
+    uint32_t mlp_mode;
 } ucn_field_t;
 
 uint64_t ucn_field_packed_floats(const ucn_field_t *f);

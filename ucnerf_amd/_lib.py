@@ -27,6 +27,7 @@ class UcnField(ctypes.Structure):
         ("n_width", c_u32), ("n_dir", c_u32),
         ("density_bias", c_f32), ("rgb_premultiplier", c_f32), ("rgb_bias", c_f32), ("rgb_padding", c_f32),
         ("packed", c_vp),
+        ("mlp_mode", c_u32),
     ]
 
 

@@ -18,7 +18,7 @@
 //         colour layer 0     [it < NTB][r4]                    rows 32t.. of W_c0[:, 0:NB]
 //         colour layer 1, h1 [ot < NTW][r4]                    W_c1[:, 32t:32t+32]
 // padded to a whole number of LDS chunks.
-#include "mfma_chain.h"
+#include "mfma_chain_h.h"
 
 namespace {
 
@@ -36,6 +36,8 @@ int make_plan(const ucn_field_t *f, PackPlan *pl) {
     pl->prop = f->n_bottleneck == 1;
     pl->p0 = 0;
     uint64_t o = 2ull * pl->KQ * 64;
+    const uint64_t o_h = 2ull * ((pl->F + 15) / 16) * 2 * 256;   // split-f16 first layer: [ot][s][hi,lo] x 1 KiB
+    if (o_h > o) o = o_h;
     o = (o + 255) & ~255ull;                           // keep the stream 1 KiB aligned
     if (pl->prop) {
         pl->NTB = pl->NTW = 0;
@@ -249,6 +251,128 @@ __global__ __launch_bounds__(256) void k_field_mlp(MlpArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ split-f16 variant (mlp_mode 1)
+// Same program and weight-stream order as k_field_mlp; operands are (hi, lo) f16 pairs, see
+// mfma_chain_h.h.  x is split tile by tile as it is produced, so the fp32 copy never exists in full.
+template <int T, int NTB, int NTW>
+__device__ __forceinline__ void hidden_tiles_h(const int G3, const int per_tile, f32x16 (&h2)[NTW],
+                                               const HTile (&x)[NTB], const float *__restrict__ b_c0,
+                                               const float *__restrict__ db, int h, WeightStream &ws) {
+    f32x16 h1;
+    init_tile(h1, T, b_c0, db, h);
+    chain_one_h<NTB>(G3 + T * per_tile, h1, x, ws);
+    relu_tile(h1);
+    HTile h1s;
+    split_tile(h1, h1s);
+    chain_from_one_h<NTW>(G3 + T * per_tile + NTB * 4, h2, h1s, ws);
+    if constexpr (T + 1 < NTW) hidden_tiles_h<T + 1, NTB, NTW>(G3, per_tile, h2, x, b_c0, db, h, ws);
+}
+
+template <int OT, int NTB>
+__device__ __forceinline__ void density_tiles_h(const int G1, HTile (&x)[NTB], const HTile (&h0)[2], const MlpArgs &a,
+                                                uint32_t b, bool live, int h, WeightStream &ws) {
+    f32x16 acc;
+    init_tile(acc, OT, a.b_d1, nullptr, h);
+    chain_one_h<2>(G1 + OT * 2 * 4, acc, h0, ws);
+    if (OT == 0 && live && h == 0) a.density[b] = softplus(acc[0] + a.density_bias);     // models.py:508,581
+    if (a.bott && live) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) a.bott[(size_t)b * (NTB * 32) + acc_row(OT, r, h)] = acc[r];
+    }
+    split_tile(acc, x[OT]);
+    if constexpr (OT + 1 < NTB) density_tiles_h<OT + 1, NTB>(G1, x, h0, a, b, live, h, ws);
+}
+
+template <int NTB, int NTW>
+__global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t b0 = (blockIdx.x * 4u + wave) * 32u;
+    const bool live = b0 + j < a.B;
+    const uint32_t b = live ? b0 + j : a.B - 1;
+
+    WeightStream ws{a.packed + a.pstream, s_w, lane, wave, a.n_chunks};
+    ws.issue(0);
+
+    // ---- density layer 0: F -> 64.  B operand: features k = 16s + 8h + e, split on the fly.
+    HTile h0[2];
+    {
+        f32x16 acc[2];
+        init_bias<2>(acc, a.b_d0, nullptr, h);
+        const h8 *p0 = reinterpret_cast<const h8 *>(a.packed + a.p0);
+        const uint32_t KS = (a.F + 15) / 16;
+        for (uint32_t s = 0; s < KS; s++) {
+            h8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t k = 16u * s + 8u * h + e;
+                float v = 0.0f;
+                if (k < a.F) {
+                    const uint32_t l = k / a.C, c = k - l * a.C;
+                    v = a.feat[((size_t)l * a.B + b) * a.C + c];
+                }
+                const _Float16 hv = (_Float16)v;
+                bh[e] = hv;
+                bl[e] = (_Float16)(v - (float)hv);
+            }
+#pragma unroll
+            for (int ot = 0; ot < 2; ot++) {
+                const h8 a_hi = p0[((size_t)(ot * KS + s) * 2 + 0) * 64 + lane];
+                const h8 a_lo = p0[((size_t)(ot * KS + s) * 2 + 1) * 64 + lane];
+                acc[ot] = mfma16h(a_hi, bh, acc[ot]);
+                acc[ot] = mfma16h(a_hi, bl, acc[ot]);
+                acc[ot] = mfma16h(a_lo, bh, acc[ot]);
+            }
+        }
+        relu_tile(acc[0]);
+        relu_tile(acc[1]);
+        split_tile(acc[0], h0[0]);
+        split_tile(acc[1], h0[1]);
+    }
+    constexpr int G1 = 0;
+    constexpr int G2 = G1 + NTB * 2 * 4;
+    constexpr int G3 = G2 + NTW * NTB * 4;
+    constexpr int PER_TILE = NTB * 4 + NTW * 4;
+
+    HTile x[NTB];
+    density_tiles_h<0, NTB>(G1, x, h0, a, b, live, h, ws);
+    if (a.rgb == nullptr) {
+        __syncthreads();
+        return;
+    }
+    const float *db = a.dir_bias + (size_t)(b / a.spr) * 2 * (NTW * 32);
+    f32x16 h2[NTW];
+    init_bias<NTW>(h2, a.b_c1, db + NTW * 32, h);
+    chain_h<NTW, NTB>(G2, h2, x, ws);
+    hidden_tiles_h<0, NTB, NTW>(G3, PER_TILE, h2, x, a.b_c0, db, h, ws);
+    const float4 *pr = reinterpret_cast<const float4 *>(a.packed + a.phead);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NTW; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float4 w = pr[(t * 16 + r) * 2 + h];
+            const float v = fmaxf(h2[t][r], 0.0f);
+            s0 = fmaf(v, w.x, s0);
+            s1 = fmaf(v, w.y, s1);
+            s2 = fmaf(v, w.z, s2);
+        }
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (live && h == 0) {
+        const float pad = a.rgb_padding;
+        float v[3] = {s0 + a.b_rgb[0], s1 + a.b_rgb[1], s2 + a.b_rgb[2]};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float sg = 1.0f / (1.0f + expf(-(a.rgb_premult * v[c] + a.rgb_bias)));
+            a.rgb[(size_t)b * 3 + c] = sg * (1.0f + 2.0f * pad) - pad;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" uint64_t ucn_field_packed_floats(const ucn_field_t *f) {
@@ -262,6 +386,33 @@ extern "C" int ucn_field_pack(const ucn_field_t *f, ucn_stream_t stream) {
     if (int rc = make_plan(f, &pl)) return rc;
     UCN_REQUIRE(f->packed && f->w_d0 && f->w_d1 && f->b_d0 && f->b_d1, "field_pack: density MLP weights / packed buffer missing");
     hipStream_t st = (hipStream_t)stream;
+    UCN_REQUIRE(f->mlp_mode <= 1, "field: mlp_mode must be 0 (fp32 MFMA) or 1 (split-f16 MFMA)");
+    if (!pl.prop && f->mlp_mode == 1) {
+        // split-f16 layout: same stream order, every 1 KiB group holds 64 lanes x 8 halfs of one
+        // (k-step, hi|lo) instead of 64 lanes x 4 floats of one r4
+        const uint32_t NB = f->n_bottleneck, NW = f->n_width, ND = f->n_dir, KS = (pl.F + 15) / 16;
+        hipLaunchKernelGGL(k_pack_first_h, dim3(ucn_div_up(2ull * KS * 2 * 512, 256)), dim3(256), 0, st, f->w_d0, pl.F, KS,
+                           reinterpret_cast<_Float16 *>(f->packed + pl.p0));
+        uint64_t off = pl.pstream;
+        auto chainpack = [&](const float *W, uint32_t ld, uint32_t col0, uint32_t row_tile0, uint32_t nto, uint32_t nti) {
+            hipLaunchKernelGGL(k_pack_chain_h, dim3(ucn_div_up((uint64_t)nto * nti * 2048, 256)), dim3(256), 0, st, W, ld,
+                               col0, row_tile0, nto, nti, reinterpret_cast<_Float16 *>(f->packed + off));
+            off += (uint64_t)nto * nti * 1024;
+        };
+        chainpack(f->w_d1, 64, 0, 0, pl.NTB, 2);
+        chainpack(f->w_c1, NW + NB + ND, NW, 0, pl.NTW, pl.NTB);
+        for (uint32_t t = 0; t < pl.NTW; t++) {
+            chainpack(f->w_c0, NB + ND, 0, t, 1, pl.NTB);
+            chainpack(f->w_c1, NW + NB + ND, 32 * t, 0, pl.NTW, 1);
+        }
+        const uint64_t end = pl.pstream + (uint64_t)pl.n_groups * 256;
+        if (off < end)
+            hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up(end - off, 256)), dim3(256), 0, st, f->packed + off, (uint32_t)(end - off));
+        hipLaunchKernelGGL(k_pack_head, dim3(ucn_div_up((uint64_t)NW * 4, 256)), dim3(256), 0, st, f->w_rgb, NW, 0u, NW,
+                           3u, 4u, f->packed + pl.phead);
+        UCN_LAUNCH_CHECK("field_pack (split-f16)");
+        return 0;
+    }
     hipLaunchKernelGGL(k_pack_first, dim3(ucn_div_up(2ull * pl.KQ * 64, 256)), dim3(256), 0, st, f->w_d0, pl.F, f->packed + pl.p0);
     if (pl.prop) {
         hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, f->w_d1, 64u, 0u, 64u, 1u, 1u, f->packed + pl.phead);
@@ -329,7 +480,10 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
     const dim3 grid(ucn_div_up(B, 128));
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 2 * kChunkGroups * 256 * sizeof(float);
+    UCN_REQUIRE(f->mlp_mode <= 1, "field: mlp_mode must be 0 (fp32 MFMA) or 1 (split-f16 MFMA)");
     if (pl.prop) hipLaunchKernelGGL(k_prop_mlp, grid, dim3(256), 0, st, a);
+    else if (f->mlp_mode == 1 && pl.NTB == 8) hipLaunchKernelGGL((k_field_mlp_h<8, 8>), grid, dim3(256), lds, st, a);
+    else if (f->mlp_mode == 1) hipLaunchKernelGGL((k_field_mlp_h<2, 2>), grid, dim3(256), lds, st, a);
     else if (pl.NTB == 8) hipLaunchKernelGGL((k_field_mlp<8, 8>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((k_field_mlp<2, 2>), grid, dim3(256), lds, st, a);
     UCN_LAUNCH_CHECK("field_mlp");

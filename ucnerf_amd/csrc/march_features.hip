@@ -79,6 +79,45 @@ __device__ __forceinline__ void level_lookup(const UcnLevel &lv, const float *__
     }
 }
 
+// Lattice cell of a point in one level (same arithmetic as level_lookup); false when the point is
+// outside [0,1]^3 (zero feature, gridencoder.cu:110-135).
+__device__ __forceinline__ bool cell_of(const UcnLevel &lv, float px, float py, float pz, uint32_t &x0, uint32_t &y0,
+                                        uint32_t &z0) {
+    if (px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f) return false;
+    x0 = (uint32_t)floorf(fmaf(px, lv.scale, 0.5f));
+    y0 = (uint32_t)floorf(fmaf(py, lv.scale, 0.5f));
+    z0 = (uint32_t)floorf(fmaf(pz, lv.scale, 0.5f));
+    return true;
+}
+
+__device__ __forceinline__ void cell_rows(const UcnLevel &lv, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t (&rows)[8]) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t x = x0 + (k & 1u), y = y0 + ((k >> 1) & 1u), z = z0 + ((k >> 2) & 1u);
+        uint32_t idx = lv.hashed ? ucn_hash3(x, y, z) : x * lv.stride[0] + y * lv.stride[1] + z * lv.stride[2];
+        rows[k] = lv.mask ? (idx & lv.mask) : (idx < lv.rows ? idx : idx % lv.rows);
+    }
+}
+
+// The six multisamples of a sample sit inside a cone of radius ~3e-4*t: on the coarse levels (cell
+// >> cone) they share one lattice cell, so its 8 corner rows are fetched ONCE and interpolated six
+// times from registers -- 8 lane-requests instead of 48 on those levels.  The arithmetic per point is
+// the same fmaf chain as level_lookup, so the result is bit-identical.
+template <uint32_t C>
+__device__ __forceinline__ bool shared_cell(const UcnLevel &lv, const float (&u)[6][3], uint32_t G, uint32_t &cx,
+                                            uint32_t &cy, uint32_t &cz) {
+    bool same = cell_of(lv, u[0][0], u[0][1], u[0][2], cx, cy, cz);
+#pragma unroll
+    for (uint32_t j = 1; j < 6; j++) {
+        if (j < G) {
+            uint32_t ax = 0, ay = 0, az = 0;
+            const bool in = cell_of(lv, u[j][0], u[j][1], u[j][2], ax, ay, az);
+            same = same && in && ax == cx && ay == cy && az == cz;
+        }
+    }
+    return same;
+}
+
 // coord.py:60-72 followed by the /2 of models.py:491-493; returns the [0,1] grid coordinate
 __device__ __forceinline__ void contract_to_unit(float x, float y, float z, float sd, bool warp, float &u0, float &u1,
                                                  float &u2, float &sd_out, float &c0, float &c1, float &c2) {
@@ -135,14 +174,48 @@ __device__ __forceinline__ void featurise_bwd(const UcnLevels &lvls, float *__re
         float gout[C];
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) gout[c] = gp[c] / (float)G;          // d(mean over G)
+        uint32_t cx = 0, cy = 0, cz = 0;
+        if (shared_cell<C>(lv, u, G, cx, cy, cz)) {
+            // all multisamples in one cell: sum their corner weights first, 8*C atomics instead of 48*C
+            float wsum[8];
 #pragma unroll
-        for (uint32_t j = 0; j < 6; j++) {
-            if (j < G) {
-                const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
-                float g[C];
+            for (uint32_t k = 0; k < 8; k++) wsum[k] = 0.0f;
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) g[c] = gout[c] * damp;
-                level_scatter<C>(lv, gtab, u[j][0], u[j][1], u[j][2], g);
+            for (uint32_t j = 0; j < 6; j++) {
+                if (j < G) {
+                    const float fx = fmaf(u[j][0], lv.scale, 0.5f) - (float)cx;
+                    const float fy = fmaf(u[j][1], lv.scale, 0.5f) - (float)cy;
+                    const float fz = fmaf(u[j][2], lv.scale, 0.5f) - (float)cz;
+                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        float w = 1.0f;
+                        w *= (k & 1u) ? fx : gx;
+                        w *= (k & 2u) ? fy : gy;
+                        w *= (k & 4u) ? fz : gz;
+                        wsum[k] += w * damp;
+                    }
+                }
+            }
+            uint32_t rows[8];
+            cell_rows(lv, cx, cy, cz, rows);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                float *r = gtab + (size_t)rows[k] * C;
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, wsum[k] * gout[c]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) {
+                if (j < G) {
+                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+                    float g[C];
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) g[c] = gout[c] * damp;
+                    level_scatter<C>(lv, gtab, u[j][0], u[j][1], u[j][2], g);
+                }
             }
         }
     }
@@ -159,15 +232,60 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
         float acc[C];
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) acc[c] = 0.0f;
+        uint32_t cx = 0, cy = 0, cz = 0;
+        if (shared_cell<C>(lv, u, G, cx, cy, cz)) {
+            uint32_t rows[8];
+            cell_rows(lv, cx, cy, cz, rows);
+            float v[8][C];
 #pragma unroll
-        for (uint32_t j = 0; j < 6; j++) {
-            if (j < G) {
-                float f[C];
-                level_lookup<C>(lv, tab, u[j][0], u[j][1], u[j][2], f);
-                // models.py:495: erf(1 / sqrt(8 * std^2 * grid_sizes^2)), grid_sizes^2 in wrapped int32
-                const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+            for (uint32_t k = 0; k < 8; k++) {
+                const float *r = tab + (size_t)rows[k] * C;
+                if constexpr (C == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(r);
+                    v[k][0] = t.x; v[k][1] = t.y;
+                } else if constexpr (C == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(r);
+                    v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+                } else {
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
+                    for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) {
+                if (j < G) {
+                    const float fx = fmaf(u[j][0], lv.scale, 0.5f) - (float)cx;
+                    const float fy = fmaf(u[j][1], lv.scale, 0.5f) - (float)cy;
+                    const float fz = fmaf(u[j][2], lv.scale, 0.5f) - (float)cz;
+                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+                    float f[C];
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) f[c] = 0.0f;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        float w = 1.0f;
+                        w *= (k & 1u) ? fx : gx;
+                        w *= (k & 2u) ? fy : gy;
+                        w *= (k & 4u) ? fz : gz;
+#pragma unroll
+                        for (uint32_t c = 0; c < C; c++) f[c] = fmaf(w, v[k][c], f[c]);
+                    }
+                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) {
+                if (j < G) {
+                    float f[C];
+                    level_lookup<C>(lv, tab, u[j][0], u[j][1], u[j][2], f);
+                    // models.py:495: erf(1 / sqrt(8 * std^2 * grid_sizes^2)), grid_sizes^2 in wrapped int32
+                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
+                }
             }
         }
         float *o = sample_major ? out + b * F_out + (size_t)lvl * C : out + ((size_t)lvl * B + b) * C;

@@ -17,7 +17,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kChunkGroups = 32;   // 32 KiB per LDS buffer, two buffers
+constexpr int kChunkGroups = 64;   // 64 KiB per LDS buffer, two buffers (128 of the CU's 160 KiB)
 
 // neuron held by accumulator register r of tile `tile` in wave-half h
 __host__ __device__ __forceinline__ uint32_t acc_row(uint32_t tile, uint32_t r, uint32_t h) {

@@ -95,6 +95,10 @@ class MLP(nn.Module):
     grid_log2_hashmap_size: int = 21
     net_width_glo: int = 128
     net_depth_glo: int = 2
+    # ---- knob of this implementation (not in the reference): arithmetic of the dense layers
+    #   0 = fp32-input MFMA (exact fp32 products; 157 TF ceiling)
+    #   1 = split-f16 MFMA, fp32 accumulate (hi/lo f16 operands, ~3e-7 relative per product; 5.3x rate)
+    mlp_mode: int = 1
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -151,7 +155,7 @@ class MLP(nn.Module):
             _lib.require_device(w, f"{type(self).__name__} parameter")
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise RuntimeError("field parameters must be contiguous float32")
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (int(self.mlp_mode),)
         if key == self._desc_key:
             return self._desc
         lib = _lib.load()
@@ -170,6 +174,7 @@ class MLP(nn.Module):
         d.n_dir = self.dim_dir_enc
         d.density_bias, d.rgb_premultiplier = float(self.density_bias), float(self.rgb_premultiplier)
         d.rgb_bias, d.rgb_padding = float(self.rgb_bias), float(self.rgb_padding)
+        d.mlp_mode = int(self.mlp_mode)
         n = lib.ucn_field_packed_floats(ctypes.byref(d))
         if n == 0:
             raise RuntimeError(lib.ucn_last_error().decode())
