@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--ray-major", action="store_true", help="lanes = consecutive samples of a ray (default: neighbouring rays)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="0 fp32-input MFMA, 1 split-f16 MFMA (default: the package default)")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
@@ -171,6 +172,8 @@ def main():
         model.levels_per_block = args.levels_per_block
     if args.chunk:
         model.max_chunk_rays = args.chunk
+    if args.ray_major:
+        model.rays_fastest = False
     batch = frame_rays(device)
     n_rays = H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)

@@ -143,18 +143,24 @@ int ucn_points_features(const ucn_field_t *f, const float *means, const float *s
                         uint32_t G, int warp, uint32_t levels_per_block, float *features_out /*[L][B][C]*/,
                         float *coord_out /*[B,3]|NULL*/, ucn_stream_t stream);
 
-/* ref: coord.py:214-225 pos_enc(viewdirs) folded through the direction columns of
- * lin_second_stage_{0,1}: per-ray additive terms for the colour MLP. */
+/* ref: coord.py:214-225 pos_enc(viewdirs): the per-ray direction inputs of the colour MLP.
+ * mlp_mode 0: folded through the direction columns of lin_second_stage_{0,1} into additive terms
+ *             [N,2,n_width];  mlp_mode 1: the encoding itself as one 32-wide input tile [N,32]
+ *             (k < n_dir: pos_enc, k = n_dir: 1 -- the bias slot, then 0).
+ * ucn_field_dir_floats = number of floats of dir_bias_out for N rays in the field's mode. */
+uint64_t ucn_field_dir_floats(const ucn_field_t *f, uint32_t N);
 int ucn_field_dir_bias(const ucn_field_t *f, const float *viewdirs /*[N,3]*/, uint32_t N,
-                       float *dir_bias_out /*[N,2,n_width]*/, ucn_stream_t stream);
+                       float *dir_bias_out, ucn_stream_t stream);
 
 /* ref: models.py:507-508,581,599-674 -- density MLP, softplus, colour MLP, sigmoid + padding.
- * fp32 MFMA (v_mfma_f32_32x32x2_f32), activations chained through registers.
- * features [L][B][C]; rays_of_sample: sample b belongs to ray b / samples_per_ray.
+ * MFMA (fp32-input or split-f16 per mlp_mode), activations chained through registers.
+ * features [L][B][C] as written by ucn_march_features: rays_fastest = 0 -> b = ray*samples_per_ray + s
+ * (layout 0), rays_fastest = 1 -> b = s*n_rays + ray (layout 2).  Outputs are always [ray][s]-ordered.
  * bottleneck_out optional [B, n_bottleneck]. rgb_out NULL for PropMLP. */
 int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32_t B, uint32_t samples_per_ray,
-                  const float *dir_bias /*[B/spr,2,n_width]|NULL*/, float *density_out /*[B]*/,
-                  float *rgb_out /*[B,3]|NULL*/, float *bottleneck_out, ucn_stream_t stream);
+                  int rays_fastest, const float *dir_bias /*from ucn_field_dir_bias|NULL*/,
+                  float *density_out /*[B]*/, float *rgb_out /*[B,3]|NULL*/, float *bottleneck_out,
+                  ucn_stream_t stream);
 
 /* ref: render.py:155-174 compute_alpha_weights + :177-244 volumetric_rendering +
  * stepfun.py:329-339 weighted_percentile.  rgbs NULL = PropMLP zeros (models.py:584-585).

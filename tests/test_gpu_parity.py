@@ -291,6 +291,9 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
         model.levels_per_block = lpb
         again, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
         assert torch.equal(again[-1]["rgb"], got[-1]["rgb"])
+    model.rays_fastest = not model.rays_fastest           # thread<->sample mapping: also pure scheduling
+    again, _ = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+    assert torch.equal(again[-1]["rgb"], got[-1]["rgb"]) and torch.equal(again[-1]["weights"], got[-1]["weights"])
     torch.set_grad_enabled(True)
 
 

@@ -61,8 +61,9 @@ SIGNATURES = {
     "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
+    "ucn_field_dir_floats": [ctypes.POINTER(UcnField), c_u32],
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],
-    "ucn_field_mlp": [ctypes.POINTER(UcnField), c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_field_mlp": [ctypes.POINTER(UcnField), c_vp, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_composite": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
@@ -72,6 +73,7 @@ SIGNATURES = {
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
+             "ucn_field_dir_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64}
 
 _lib = None

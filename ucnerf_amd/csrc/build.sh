@@ -6,9 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
 mkdir -p _obj
 pids=()
-for f in grid_op march_ray march_features field_mlp heads sky; do
-  [ -f "$f.hip" ] || continue
-  if [ ! -f "_obj/$f.o" ] || [ "$f.hip" -nt "_obj/$f.o" ] || [ ucn_common.h -nt "_obj/$f.o" ] || [ ../../include/ucnerf_march.h -nt "_obj/$f.o" ]; then
+for f in grid_op march_ray march_features field_mlp field_mlp_h heads sky; do
+  stale=0
+  for h in "$f.hip" *.h ../../include/ucnerf_march.h; do
+    if [ ! -f "_obj/$f.o" ] || [ "$h" -nt "_obj/$f.o" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "_obj/$f.o" &
     pids+=($!)
   fi

@@ -52,6 +52,7 @@ int ucn_build_levels(UcnLevels *out, const int32_t *offsets, const int32_t *grid
         if (grid_sizes) {
             const int32_t g = grid_sizes[l];
             lv.gs2 = (float)(int32_t)((uint32_t)g * (uint32_t)g);   // int32 wrap, models.py:495
+            lv.inv_gs = 1.0f / sqrtf(lv.gs2);                       // NaN if the wrap went negative, like torch
         }
     }
     return 0;

@@ -11,13 +11,21 @@
 //
 // Mapping (CDNA4): one thread = one sample x `levels_per_block` consecutive levels; blockIdx.y is
 // the level group, so the grid is level-major in dispatch order and an XCD's L2 (4 MiB) sees one
-// 4 MiB hashed level slice at a time; lanes of a wave are consecutive samples of a ray -> the
-// [L][B][C] store is a contiguous 64*C*4-byte run per wave, and the 48 corner gathers of a
-// thread-level are independent loads the memory pipe can keep in flight.  The bound is the L2 /
-// HBM random-sector rate, not flops: keep VGPRs low (occupancy) and never re-read the table.
+// 4 MiB hashed level slice at a time (measured: levels_per_block 1 -> 16 costs 1.8x); lanes of a wave
+// are consecutive samples of a ray -> the [L][B][C] store is a contiguous 64*C*4-byte run per wave.
 //
-// Arithmetic follows the reference op-by-op in fp32 (built with -ffp-contract=off); the grid
-// interpolation uses the fmaf spelling of oracle/grid_oracle.c and is bit-identical to it.
+// What bounds it (rocprofv3, r01b): with the tables L2/MALL-resident the kernel is VALU-bound
+// (SQ_ACTIVE_INST_VALU = 21 % of wave-cycles at 4 waves/SIMD = 84 % of a SIMD), ~3000 VALU
+// instructions per (sample, level).  Hence this file's shape:
+//   * the level's addressing mode (xor-hash vs strided, pow2 mask vs modulo) is a TEMPLATE argument
+//     chosen by a wave-uniform branch, not a per-corner select between two computed indices;
+//   * y*P1 and z*P2 are multiplied once per point, the +1 corners add the prime (uint32 wrap keeps
+//     (y+1)*P == y*P + P);
+//   * quantities that only feed the erf damping (std) use fast reciprocals / exp2-log2 instead of
+//     IEEE division and powf, and erf itself is the Abramowitz-Stegun 7.1.26 form (|err| <= 1.5e-7);
+//     everything that feeds a COORDINATE keeps the reference's exact fp32 op sequence
+//     (correctly-rounded div/sqrt, no contraction), so positions -- and the interpolated features
+//     for given positions -- stay bit-identical to the oracle.
 #include "ucn_common.h"
 
 namespace {
@@ -33,209 +41,72 @@ struct RayInputs {
     const float *sdist, *near_, *far_, *origins, *dirs, *basis, *radii, *flip, *spin;
 };
 
-// trilinear lookup of one point in one level; gridencoder.cu:146-191 for D = 3, linear, no align
-template <uint32_t C>
-__device__ __forceinline__ void level_lookup(const UcnLevel &lv, const float *__restrict__ tab, float px, float py,
-                                             float pz, float (&out)[C]) {
-#pragma unroll
-    for (uint32_t c = 0; c < C; c++) out[c] = 0.0f;
-    if (px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f) return;
-    float fx = fmaf(px, lv.scale, 0.5f), fy = fmaf(py, lv.scale, 0.5f), fz = fmaf(pz, lv.scale, 0.5f);
+constexpr uint32_t kP1 = 2654435761u, kP2 = 805459861u;   // gridencoder.cu:54
+
+// erf(x), x >= 0: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (the damping multiplies O(1) features)
+__device__ __forceinline__ float erf_pos(float x) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    return fmaf(-(p * t), __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x), 1.0f);
+}
+
+// One multisample point in one level: lattice cell, fractions, the 8 corner rows.
+// gridencoder.cu:146-159 (locate) and :66-84 (index) for D = 3, linear, align_corners = false.
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void corner_rows(const UcnLevel &lv, float px, float py, float pz, float &fx, float &fy,
+                                            float &fz, uint32_t (&rows)[8]) {
+    fx = fmaf(px, lv.scale, 0.5f); fy = fmaf(py, lv.scale, 0.5f); fz = fmaf(pz, lv.scale, 0.5f);
     const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
     fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    uint32_t ya, yb, za, zb, xa, xb;
+    if constexpr (HASHED) {
+        xa = x0; xb = x0 + 1u;
+        ya = y0 * kP1; yb = ya + kP1;
+        za = z0 * kP2; zb = za + kP2;
+    } else {
+        xa = x0 * lv.stride[0]; xb = xa + lv.stride[0];
+        ya = y0 * lv.stride[1]; yb = ya + lv.stride[1];
+        za = z0 * lv.stride[2]; zb = za + lv.stride[2];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t xv = (k & 1u) ? xb : xa, yv = (k & 2u) ? yb : ya, zv = (k & 4u) ? zb : za;
+        uint32_t idx;
+        if constexpr (HASHED) idx = xv ^ yv ^ zv;
+        else idx = xv + yv + zv;
+        if constexpr (POW2) rows[k] = idx & lv.mask;
+        else rows[k] = idx < lv.rows ? idx : idx % lv.rows;
+    }
+}
+
+// w_k = ((1*wx)*wy)*wz in the reference's multiplication order (gridencoder.cu:168-180)
+__device__ __forceinline__ void corner_weights(float fx, float fy, float fz, float (&w)[8]) {
     const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    uint32_t rows[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t x = x0 + (k & 1u), y = y0 + ((k >> 1) & 1u), z = z0 + ((k >> 2) & 1u);
-        uint32_t idx = lv.hashed ? ucn_hash3(x, y, z) : x * lv.stride[0] + y * lv.stride[1] + z * lv.stride[2];
-        rows[k] = lv.mask ? (idx & lv.mask) : (idx < lv.rows ? idx : idx % lv.rows);
-    }
-    // issue all eight row loads before the first use
-    float v[8][C];
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        const float *r = tab + (size_t)rows[k] * C;
-        if constexpr (C == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(r);
-            v[k][0] = t.x; v[k][1] = t.y;
-        } else if constexpr (C == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(r);
-            v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
-        } else {
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
-        }
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        // w = ((1 * wx) * wy) * wz in the reference's multiplication order (gridencoder.cu:168-180)
-        float w = 1.0f;
-        w *= (k & 1u) ? fx : gx;
-        w *= (k & 2u) ? fy : gy;
-        w *= (k & 4u) ? fz : gz;
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) out[c] = fmaf(w, v[k][c], out[c]);
-    }
+    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+    w[0] = w00 * gz; w[1] = w10 * gz; w[2] = w01 * gz; w[3] = w11 * gz;
+    w[4] = w00 * fz; w[5] = w10 * fz; w[6] = w01 * fz; w[7] = w11 * fz;
 }
 
-// Lattice cell of a point in one level (same arithmetic as level_lookup); false when the point is
-// outside [0,1]^3 (zero feature, gridencoder.cu:110-135).
-__device__ __forceinline__ bool cell_of(const UcnLevel &lv, float px, float py, float pz, uint32_t &x0, uint32_t &y0,
-                                        uint32_t &z0) {
-    if (px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f) return false;
-    x0 = (uint32_t)floorf(fmaf(px, lv.scale, 0.5f));
-    y0 = (uint32_t)floorf(fmaf(py, lv.scale, 0.5f));
-    z0 = (uint32_t)floorf(fmaf(pz, lv.scale, 0.5f));
-    return true;
+__device__ __forceinline__ bool in_unit_cube(float px, float py, float pz) {
+    return !(px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f);   // gridencoder.cu:110-135
 }
 
-__device__ __forceinline__ void cell_rows(const UcnLevel &lv, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t (&rows)[8]) {
+// sum_j damp_j * trilerp(point_j) for one level
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float *__restrict__ tab,
+                                                 const float (&u)[6][3], const float (&rs)[6], uint32_t G,
+                                                 float (&acc)[C]) {
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t x = x0 + (k & 1u), y = y0 + ((k >> 1) & 1u), z = z0 + ((k >> 2) & 1u);
-        uint32_t idx = lv.hashed ? ucn_hash3(x, y, z) : x * lv.stride[0] + y * lv.stride[1] + z * lv.stride[2];
-        rows[k] = lv.mask ? (idx & lv.mask) : (idx < lv.rows ? idx : idx % lv.rows);
-    }
-}
-
-// The six multisamples of a sample sit inside a cone of radius ~3e-4*t: on the coarse levels (cell
-// >> cone) they share one lattice cell, so its 8 corner rows are fetched ONCE and interpolated six
-// times from registers -- 8 lane-requests instead of 48 on those levels.  The arithmetic per point is
-// the same fmaf chain as level_lookup, so the result is bit-identical.
-template <uint32_t C>
-__device__ __forceinline__ bool shared_cell(const UcnLevel &lv, const float (&u)[6][3], uint32_t G, uint32_t &cx,
-                                            uint32_t &cy, uint32_t &cz) {
-    bool same = cell_of(lv, u[0][0], u[0][1], u[0][2], cx, cy, cz);
+    for (uint32_t c = 0; c < C; c++) acc[c] = 0.0f;
 #pragma unroll
-    for (uint32_t j = 1; j < 6; j++) {
-        if (j < G) {
-            uint32_t ax = 0, ay = 0, az = 0;
-            const bool in = cell_of(lv, u[j][0], u[j][1], u[j][2], ax, ay, az);
-            same = same && in && ax == cx && ay == cy && az == cz;
-        }
-    }
-    return same;
-}
-
-// coord.py:60-72 followed by the /2 of models.py:491-493; returns the [0,1] grid coordinate
-__device__ __forceinline__ void contract_to_unit(float x, float y, float z, float sd, bool warp, float &u0, float &u1,
-                                                 float &u2, float &sd_out, float &c0, float &c1, float &c2) {
-    if (warp) {
-        const float m = fmaxf((x * x + y * y) + z * z, UCN_EPS);
-        if (!(m <= 1.0f)) {
-            const float root = sqrtf(m);
-            const float k = (2.0f * root - 1.0f) / m;
-            x = k * x; y = k * y; z = k * z;
-            float sh = powf(2.0f * root - 1.0f, 0.3333333432674408f) / root;
-            sd = (sh * sh) * sd;
-        }
-        x = x / 2.0f; y = y / 2.0f; z = z / 2.0f;
-        sd = sd / 2.0f;
-    }
-    c0 = x; c1 = y; c2 = z;
-    u0 = (x + 1.0f) / 2.0f; u1 = (y + 1.0f) / 2.0f; u2 = (z + 1.0f) / 2.0f;    // grid.py:162, bound = 1
-    sd_out = sd;
-}
-
-// Backward of level_lookup w.r.t. the table: grad_table[row_k] += w_k * g (gridencoder.cu:304-339).
-template <uint32_t C>
-__device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restrict__ gtab, float px, float py,
-                                              float pz, const float (&g)[C]) {
-    if (px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f) return;
-    float fx = fmaf(px, lv.scale, 0.5f), fy = fmaf(py, lv.scale, 0.5f), fz = fmaf(pz, lv.scale, 0.5f);
-    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
-    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t x = x0 + (k & 1u), y = y0 + ((k >> 1) & 1u), z = z0 + ((k >> 2) & 1u);
-        uint32_t idx = lv.hashed ? ucn_hash3(x, y, z) : x * lv.stride[0] + y * lv.stride[1] + z * lv.stride[2];
-        idx = lv.mask ? (idx & lv.mask) : (idx < lv.rows ? idx : idx % lv.rows);
-        float w = 1.0f;
-        w *= (k & 1u) ? fx : gx;
-        w *= (k & 2u) ? fy : gy;
-        w *= (k & 4u) ? fz : gz;
-        float *r = gtab + (size_t)idx * C;
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, w * g[c]);
-    }
-}
-
-template <uint32_t C>
-__device__ __forceinline__ void featurise_bwd(const UcnLevels &lvls, float *__restrict__ grad_table, uint32_t lvl0,
-                                              uint32_t lvl1, const float (&u)[6][3], const float (&sd)[6], uint32_t G,
-                                              size_t B, size_t b, const float *__restrict__ grad, bool sample_major) {
-    const uint32_t F = lvls.L * C;
-    for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
-        const UcnLevel lv = lvls.lv[lvl];
-        float *gtab = grad_table + (size_t)lv.first_row * C;
-        const float *gp = sample_major ? grad + b * F + (size_t)lvl * C : grad + ((size_t)lvl * B + b) * C;
-        float gout[C];
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) gout[c] = gp[c] / (float)G;          // d(mean over G)
-        uint32_t cx = 0, cy = 0, cz = 0;
-        if (shared_cell<C>(lv, u, G, cx, cy, cz)) {
-            // all multisamples in one cell: sum their corner weights first, 8*C atomics instead of 48*C
-            float wsum[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) wsum[k] = 0.0f;
-#pragma unroll
-            for (uint32_t j = 0; j < 6; j++) {
-                if (j < G) {
-                    const float fx = fmaf(u[j][0], lv.scale, 0.5f) - (float)cx;
-                    const float fy = fmaf(u[j][1], lv.scale, 0.5f) - (float)cy;
-                    const float fz = fmaf(u[j][2], lv.scale, 0.5f) - (float)cz;
-                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        float w = 1.0f;
-                        w *= (k & 1u) ? fx : gx;
-                        w *= (k & 2u) ? fy : gy;
-                        w *= (k & 4u) ? fz : gz;
-                        wsum[k] += w * damp;
-                    }
-                }
-            }
+    for (uint32_t j = 0; j < 6; j++) {
+        if (j < G && in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            float fx, fy, fz, w[8];
             uint32_t rows[8];
-            cell_rows(lv, cx, cy, cz, rows);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                float *r = gtab + (size_t)rows[k] * C;
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, wsum[k] * gout[c]);
-            }
-        } else {
-#pragma unroll
-            for (uint32_t j = 0; j < 6; j++) {
-                if (j < G) {
-                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
-                    float g[C];
-#pragma unroll
-                    for (uint32_t c = 0; c < C; c++) g[c] = gout[c] * damp;
-                    level_scatter<C>(lv, gtab, u[j][0], u[j][1], u[j][2], g);
-                }
-            }
-        }
-    }
-}
-
-template <uint32_t C>
-__device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
-                                          uint32_t lvl1, const float (&u)[6][3], const float (&sd)[6], uint32_t G,
-                                          size_t B, size_t b, float *__restrict__ out, bool sample_major = false) {
-    const uint32_t F_out = lvls.L * C;
-    for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
-        const UcnLevel lv = lvls.lv[lvl];
-        const float *tab = table + (size_t)lv.first_row * C;
-        float acc[C];
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) acc[c] = 0.0f;
-        uint32_t cx = 0, cy = 0, cz = 0;
-        if (shared_cell<C>(lv, u, G, cx, cy, cz)) {
-            uint32_t rows[8];
-            cell_rows(lv, cx, cy, cz, rows);
+            corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
             float v[8][C];
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
@@ -251,42 +122,109 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
                     for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
                 }
             }
+            corner_weights(fx, fy, fz, w);
+            float f[C];
 #pragma unroll
-            for (uint32_t j = 0; j < 6; j++) {
-                if (j < G) {
-                    const float fx = fmaf(u[j][0], lv.scale, 0.5f) - (float)cx;
-                    const float fy = fmaf(u[j][1], lv.scale, 0.5f) - (float)cy;
-                    const float fz = fmaf(u[j][2], lv.scale, 0.5f) - (float)cz;
-                    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-                    float f[C];
+            for (uint32_t c = 0; c < C; c++) f[c] = 0.0f;
 #pragma unroll
-                    for (uint32_t c = 0; c < C; c++) f[c] = 0.0f;
+            for (uint32_t k = 0; k < 8; k++)
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        float w = 1.0f;
-                        w *= (k & 1u) ? fx : gx;
-                        w *= (k & 2u) ? fy : gy;
-                        w *= (k & 4u) ? fz : gz;
+                for (uint32_t c = 0; c < C; c++) f[c] = fmaf(w[k], v[k][c], f[c]);
+            // models.py:495: erf(1 / sqrt(8 std^2 gs^2)) = erf(rs_j * lv.inv_gs), gs^2 in wrapped int32
+            const float damp = erf_pos(rs[j] * lv.inv_gs);
 #pragma unroll
-                        for (uint32_t c = 0; c < C; c++) f[c] = fmaf(w, v[k][c], f[c]);
-                    }
-                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
+            for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
+        }
+    }
+}
+
+// Backward of level_accumulate w.r.t. the table: grad_table[row_k] += w_k * damp_j * g
+// (gridencoder.cu:304-339 composed with models.py:495-496).  When all multisamples of the sample share
+// one lattice cell (coarse levels) their corner weights are summed first: 8*C atomics instead of 48*C
+// -- atomics, unlike loads, do not coalesce across lanes.
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restrict__ gtab, const float (&u)[6][3],
+                                              const float (&rs)[6], uint32_t G, const float (&gout)[C]) {
+    uint32_t rows0[8];
+    float wsum[8];
+    bool have0 = false, shared = true;
 #pragma unroll
-                    for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
-                }
+    for (uint32_t k = 0; k < 8; k++) { wsum[k] = 0.0f; rows0[k] = 0u; }
+    // pass 1: is it one cell?  (compare the corner-0 row and the integer cell through rows[0], rows[7])
+    float fxs[6], fys[6], fzs[6];
+    uint32_t r0s[6], r7s[6];
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        fxs[j] = fys[j] = fzs[j] = 0.0f; r0s[j] = r7s[j] = 0u;
+        if (j < G) {
+            if (!in_unit_cube(u[j][0], u[j][1], u[j][2])) { shared = false; continue; }
+            uint32_t rows[8];
+            corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fxs[j], fys[j], fzs[j], rows);
+            r0s[j] = rows[0]; r7s[j] = rows[7];
+            if (!have0) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) rows0[k] = rows[k];
+                have0 = true;
+            } else if (rows[0] != rows0[0] || rows[7] != rows0[7] || rows[1] != rows0[1] || rows[2] != rows0[2] ||
+                       rows[4] != rows0[4]) {
+                shared = false;
             }
+        }
+    }
+    if (shared && have0) {
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            if (j < G) {
+                float w[8];
+                corner_weights(fxs[j], fys[j], fzs[j], w);
+                const float damp = erf_pos(rs[j] * lv.inv_gs);
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) wsum[k] += w[k] * damp;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            float *r = gtab + (size_t)rows0[k] * C;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, wsum[k] * gout[c]);
+        }
+        return;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (j < G && in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            float fx, fy, fz, w[8];
+            uint32_t rows[8];
+            corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+            corner_weights(fx, fy, fz, w);
+            const float damp = erf_pos(rs[j] * lv.inv_gs);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                float *r = gtab + (size_t)rows[k] * C;
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) atomicAdd(r + c, (w[k] * damp) * gout[c]);
+            }
+        }
+    }
+}
+
+// layout: 0 = [L][B][C] (b as given), 1 = [B][L*C]
+template <uint32_t C>
+__device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
+                                          uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
+                                          size_t B, size_t b, float *__restrict__ out, bool sample_major) {
+    const uint32_t F_out = lvls.L * C;
+    for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
+        const UcnLevel lv = lvls.lv[lvl];
+        const float *tab = table + (size_t)lv.first_row * C;
+        float acc[C];
+        // wave-uniform dispatch on the level's addressing mode (lv lives in SGPRs)
+        if (lv.hashed) {
+            if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
+            else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
         } else {
-#pragma unroll
-            for (uint32_t j = 0; j < 6; j++) {
-                if (j < G) {
-                    float f[C];
-                    level_lookup<C>(lv, tab, u[j][0], u[j][1], u[j][2], f);
-                    // models.py:495: erf(1 / sqrt(8 * std^2 * grid_sizes^2)), grid_sizes^2 in wrapped int32
-                    const float damp = erff(1.0f / sqrtf((8.0f * (sd[j] * sd[j])) * lv.gs2));
-#pragma unroll
-                    for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
-                }
-            }
+            if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
+            else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);
         }
         float *o = sample_major ? out + b * F_out + (size_t)lvl * C : out + ((size_t)lvl * B + b) * C;
         const float inv = (float)G;
@@ -301,11 +239,57 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
     }
 }
 
-// The six multisample Gaussians of sample (ray, s): render.py:108-152 then coord.py:60-72 and the
-// /2 + [0,1] mapping.  Shared by the forward and the backward kernel (the backward recomputes it:
-// 200 flops instead of reading back 6x4 floats per sample).
+template <uint32_t C>
+__device__ __forceinline__ void featurise_bwd(const UcnLevels &lvls, float *__restrict__ grad_table, uint32_t lvl0,
+                                              uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
+                                              size_t B, size_t b, const float *__restrict__ grad, bool sample_major) {
+    const uint32_t F = lvls.L * C;
+    for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
+        const UcnLevel lv = lvls.lv[lvl];
+        float *gtab = grad_table + (size_t)lv.first_row * C;
+        const float *gp = sample_major ? grad + b * F + (size_t)lvl * C : grad + ((size_t)lvl * B + b) * C;
+        float gout[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) gout[c] = gp[c] / (float)G;          // d(mean over G)
+        if (lv.hashed) {
+            if (lv.mask) level_scatter<C, true, true>(lv, gtab, u, rs, G, gout);
+            else level_scatter<C, true, false>(lv, gtab, u, rs, G, gout);
+        } else {
+            if (lv.mask) level_scatter<C, false, true>(lv, gtab, u, rs, G, gout);
+            else level_scatter<C, false, false>(lv, gtab, u, rs, G, gout);
+        }
+    }
+}
+
+// coord.py:60-72 followed by the /2 of models.py:491-493; returns the [0,1] grid coordinate (exact op
+// sequence of the reference) and rs = 1/sqrt(8 std^2) of the contracted, halved std (fast math: it only
+// feeds the erf damping).
+__device__ __forceinline__ void contract_to_unit(float x, float y, float z, float sd, bool warp, float &u0, float &u1,
+                                                 float &u2, float &rs, float &c0, float &c1, float &c2) {
+    if (warp) {
+        const float m = fmaxf((x * x + y * y) + z * z, UCN_EPS);
+        if (!(m <= 1.0f)) {
+            const float root = sqrtf(m);
+            const float k = (2.0f * root - 1.0f) / m;
+            x = k * x; y = k * y; z = k * z;
+            // ((2 root - 1)^(1/3) / root)^2 ; coord.py:69
+            const float cb = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(2.0f * root - 1.0f) * 0.3333333432674408f);
+            const float sh = cb * __builtin_amdgcn_rcpf(root);
+            sd = (sh * sh) * sd;
+        }
+        x = x / 2.0f; y = y / 2.0f; z = z / 2.0f;
+        sd = sd / 2.0f;
+    }
+    c0 = x; c1 = y; c2 = z;
+    u0 = (x + 1.0f) / 2.0f; u1 = (y + 1.0f) / 2.0f; u2 = (z + 1.0f) / 2.0f;    // grid.py:162, bound = 1
+    rs = __builtin_amdgcn_rsqf(8.0f * (sd * sd));
+}
+
+// The six multisample Gaussians of sample (ray, s): render.py:108-152 then contract_to_unit.
+// Shared by the forward and the backward kernel (the backward recomputes it instead of reading back
+// 6x4 floats per sample).
 __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPattern &hx, float std_scale, uint32_t ray,
-                                            uint32_t s, uint32_t S, float (&u)[6][3], float (&sd)[6],
+                                            uint32_t s, uint32_t S, float (&u)[6][3], float (&rs)[6],
                                             float (&csum)[3], float &tsum) {
     const float nr = in.near_[ray], fr = in.far_[ray];
     const float s0 = in.sdist[(size_t)ray * (S + 1) + s], s1 = in.sdist[(size_t)ray * (S + 1) + s + 1];
@@ -330,6 +314,8 @@ __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPatter
         keep = in.flip[(size_t)ray * S + s] > 0.5f;
         spin2pi = 6.2831854820251465f * in.spin[(size_t)ray * S + s];
     }
+    const float sd_unit = (std_scale * rad) * 0.70710678118654752f;   // std only: multiply instead of IEEE divide
+    const uint32_t odd = s & 1u;
     csum[0] = csum[1] = csum[2] = 0.0f;
     tsum = 0.0f;
 #pragma unroll
@@ -341,60 +327,67 @@ __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPatter
             if (!keep) ang = 5.235987663269043f - ang;
             cs = cosf(ang); sn = sinf(ang);
         } else {
-            cs = hx.cs[s & 1u][j]; sn = hx.sn[s & 1u][j];
+            cs = odd ? hx.cs[1][j] : hx.cs[0][j];
+            sn = odd ? hx.sn[1][j] : hx.sn[0][j];
         }
         const float rt = rad * t;
         const float l0 = (rt * cs) / 1.4142135381698608f, l1 = (rt * sn) / 1.4142135381698608f;
-        const float sdev = ((std_scale * rad) * t) / 1.4142135381698608f;
         // math.matmul with basis^T (render.py:146-148): sum_k local_k * axis_k, then + origin
         const float wx = ((l0 * e1x + l1 * e2x) + t * dx) + ox;
         const float wy = ((l0 * e1y + l1 * e2y) + t * dy) + oy;
         const float wz = ((l0 * e1z + l1 * e2z) + t * dz) + oz;
         float c0, c1, c2;
-        contract_to_unit(wx, wy, wz, sdev, true, u[j][0], u[j][1], u[j][2], sd[j], c0, c1, c2);
+        contract_to_unit(wx, wy, wz, sd_unit * t, true, u[j][0], u[j][1], u[j][2], rs[j], c0, c1, c2);
         csum[0] += c0; csum[1] += c1; csum[2] += c2; tsum += t;
     }
 }
 
+// layout: 0 = [L][N*S][C] with b = ray*S+s; 1 = [N*S][L*C]; 2 = [L][S*N][C] with b = s*N+ray
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
-                                                        uint32_t lpb, int sample_major, float *__restrict__ features,
+                                                        uint32_t lpb, int layout, float *__restrict__ features,
                                                         float *__restrict__ coord_out, float *__restrict__ tmean_out) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b >= B) return;
-    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
-    float u[6][3], sd[6], csum[3], tsum;
-    cast_sample(in, hx, std_scale, ray, s, S, u, sd, csum, tsum);
+    // layout 2 ("rays fastest"): the 64 lanes of a wave are NEIGHBOURING RAYS at one sample index.
+    // Measured (r01b): -5 % on this kernel but +24 % on the MLP (strided first-layer reads), so the
+    // default stays layout 0; kept for narrow-field-of-view workloads.
+    uint32_t ray, s;
+    if (layout == 2) { s = (uint32_t)(b / N); ray = (uint32_t)(b - (size_t)s * N); }
+    else { ray = (uint32_t)(b / S); s = (uint32_t)(b - (size_t)ray * S); }
+    float u[6][3], rs[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = blockIdx.y * lpb;
     const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
-    featurise<C>(lvls, table, lvl0, lvl1, u, sd, 6, B, b, features, sample_major != 0);
+    featurise<C>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
     if (blockIdx.y == 0) {
+        const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
         if (coord_out) {
-            coord_out[b * 3 + 0] = csum[0] / 6.0f; coord_out[b * 3 + 1] = csum[1] / 6.0f; coord_out[b * 3 + 2] = csum[2] / 6.0f;
+            coord_out[o * 3 + 0] = csum[0] / 6.0f; coord_out[o * 3 + 1] = csum[1] / 6.0f; coord_out[o * 3 + 2] = csum[2] / 6.0f;
         }
-        if (tmean_out) tmean_out[b] = tsum / 6.0f;
+        if (tmean_out) tmean_out[o] = tsum / 6.0f;
     }
 }
 
-// d(loss)/d(table) of k_march_features: grad_table[rows of the 6x8 corners] += w_corner * damp_j * g / 6.
-// (means/stds carry no gradient: coord.track_linearize is @torch.no_grad, coord.py:75, and sdist is
-//  detached, models.py:204-205.)  fp32 atomics in L2, like kernel_grid_backward (gridencoder.cu:336).
+// d(loss)/d(table) of k_march_features.  (means/stds carry no gradient: coord.track_linearize is
+// @torch.no_grad, coord.py:75, and sdist is detached, models.py:204-205.)  fp32 atomics in L2, like
+// kernel_grid_backward (gridencoder.cu:336).
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_march_features_bwd(UcnLevels lvls, float *__restrict__ grad_table, RayInputs in,
                                                             HexPattern hx, float std_scale, uint32_t N, uint32_t S,
-                                                            uint32_t lpb, int sample_major,
+                                                            uint32_t lpb, int layout,
                                                             const float *__restrict__ grad_features) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b >= B) return;
     const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
-    float u[6][3], sd[6], csum[3], tsum;
-    cast_sample(in, hx, std_scale, ray, s, S, u, sd, csum, tsum);
+    float u[6][3], rs[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = blockIdx.y * lpb;
     const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
-    featurise_bwd<C>(lvls, grad_table, lvl0, lvl1, u, sd, 6, B, b, grad_features, sample_major != 0);
+    featurise_bwd<C>(lvls, grad_table, lvl0, lvl1, u, rs, 6, B, b, grad_features, layout == 1);
 }
 
 // predict_density's featurisation for caller-supplied Gaussians (extract.py / API parity)
@@ -405,22 +398,22 @@ __global__ __launch_bounds__(256) void k_points_features(UcnLevels lvls, const f
                                                          float *__restrict__ features, float *__restrict__ coord_out) {
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b >= Bn) return;
-    float u[6][3], sd[6];
+    float u[6][3], rs[6];
     float cs0 = 0.0f, cs1 = 0.0f, cs2 = 0.0f;
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
         if (j < G) {
             const float *m = means + (b * G + j) * 3;
             float c0, c1, c2;
-            contract_to_unit(m[0], m[1], m[2], stds[b * G + j], warp != 0, u[j][0], u[j][1], u[j][2], sd[j], c0, c1, c2);
+            contract_to_unit(m[0], m[1], m[2], stds[b * G + j], warp != 0, u[j][0], u[j][1], u[j][2], rs[j], c0, c1, c2);
             cs0 += c0; cs1 += c1; cs2 += c2;
         } else {
-            u[j][0] = u[j][1] = u[j][2] = 0.0f; sd[j] = 1.0f;
+            u[j][0] = u[j][1] = u[j][2] = 0.0f; rs[j] = 1.0f;
         }
     }
     const uint32_t lvl0 = blockIdx.y * lpb;
     const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
-    featurise<C>(lvls, table, lvl0, lvl1, u, sd, G, Bn, b, features);
+    featurise<C>(lvls, table, lvl0, lvl1, u, rs, G, Bn, b, features, false);
     if (blockIdx.y == 0 && coord_out) {
         coord_out[b * 3 + 0] = cs0 / (float)G; coord_out[b * 3 + 1] = cs1 / (float)G; coord_out[b * 3 + 2] = cs2 / (float)G;
     }
@@ -456,11 +449,12 @@ int field_levels(const ucn_field_t *f, UcnLevels *lv) {
 extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                   const float *origins, const float *directions, const float *basis,
                                   const float *radii, const float *flip, const float *spin, float std_scale,
-                                  uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
+                                  uint32_t N, uint32_t S, uint32_t levels_per_block, int layout,
                                   float *features_out, float *coord_out, float *tmean_out, ucn_stream_t stream) {
     UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && features_out,
                 "march_features: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
+    UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
@@ -473,7 +467,7 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     hipStream_t st = (hipStream_t)stream;
 #define UCN_MF(CC)                                                                                              \
     hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), 0, st, lv, f->embeddings, in, hx, std_scale, N, S, \
-                       levels_per_block, sample_major, features_out, coord_out, tmean_out)
+                       levels_per_block, layout, features_out, coord_out, tmean_out)
     switch (lv.C) {
         case 1: UCN_MF(1); break;
         case 2: UCN_MF(2); break;
@@ -482,6 +476,39 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     }
 #undef UCN_MF
     UCN_LAUNCH_CHECK("march_features");
+    return 0;
+}
+
+extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
+                                           const float *origins, const float *directions, const float *basis,
+                                           const float *radii, const float *flip, const float *spin, float std_scale,
+                                           uint32_t N, uint32_t S, uint32_t levels_per_block, int layout,
+                                           const float *grad_features, float *grad_embeddings, ucn_stream_t stream) {
+    UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
+                "march_features_backward: null pointer argument");
+    UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
+    UCN_REQUIRE(layout == 0 || layout == 1, "march_features_backward: layout must be 0 or 1");
+    UcnLevels lv;
+    if (int rc = field_levels(f, &lv)) return rc;
+    if (N == 0) return 0;
+    if (levels_per_block == 0) levels_per_block = 1;
+    const size_t B = (size_t)N * S;
+    UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
+    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
+    const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
+    const HexPattern hx = make_hex();
+    hipStream_t st = (hipStream_t)stream;
+#define UCN_MB(CC)                                                                                                  \
+    hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \
+                       S, levels_per_block, layout, grad_features)
+    switch (lv.C) {
+        case 1: UCN_MB(1); break;
+        case 2: UCN_MB(2); break;
+        case 4: UCN_MB(4); break;
+        case 8: UCN_MB(8); break;
+    }
+#undef UCN_MB
+    UCN_LAUNCH_CHECK("march_features_backward");
     return 0;
 }
 
@@ -507,37 +534,5 @@ extern "C" int ucn_points_features(const ucn_field_t *f, const float *means, con
     }
 #undef UCN_PF
     UCN_LAUNCH_CHECK("points_features");
-    return 0;
-}
-
-extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
-                                           const float *origins, const float *directions, const float *basis,
-                                           const float *radii, const float *flip, const float *spin, float std_scale,
-                                           uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
-                                           const float *grad_features, float *grad_embeddings, ucn_stream_t stream) {
-    UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
-                "march_features_backward: null pointer argument");
-    UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
-    UcnLevels lv;
-    if (int rc = field_levels(f, &lv)) return rc;
-    if (N == 0) return 0;
-    if (levels_per_block == 0) levels_per_block = 1;
-    const size_t B = (size_t)N * S;
-    UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
-    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
-    const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
-    const HexPattern hx = make_hex();
-    hipStream_t st = (hipStream_t)stream;
-#define UCN_MB(CC)                                                                                                  \
-    hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \
-                       S, levels_per_block, sample_major, grad_features)
-    switch (lv.C) {
-        case 1: UCN_MB(1); break;
-        case 2: UCN_MB(2); break;
-        case 4: UCN_MB(4); break;
-        case 8: UCN_MB(8); break;
-    }
-#undef UCN_MB
-    UCN_LAUNCH_CHECK("march_features_backward");
     return 0;
 }

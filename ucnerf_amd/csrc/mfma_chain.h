@@ -87,24 +87,51 @@ struct WeightStream {
     int lane, wave;
     uint32_t n_chunks;
 
+    // The DMA is written as inline asm on purpose: with __builtin_amdgcn_global_load_lds the compiler
+    // cannot tell that the DMA's LDS writes (buffer c+1) never alias the ds_reads that follow (buffer c)
+    // and puts s_waitcnt vmcnt(0) right behind the issue -- the whole L2 -> LDS latency (~1.3 us per
+    // chunk, measured) then sits in front of the MFMAs instead of under them.  Here the DMA is invisible
+    // to the waitcnt pass, and boundary() waits for it explicitly before the publishing barrier.
+    // this wave's share of the stream: global and LDS byte positions of its group 0 (wave-uniform)
+    const float *wsrc = src + wave * 256;
+    uint32_t wlds = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)lds + wave * 1024u;
+    uint32_t voff = lane * 16u;
+
+    // this wave's i-th piece (one 1 KiB group per wave-instruction, i < kChunkGroups/4) of chunk c;
+    // the caller guarantees c < n_chunks.  With compile-time (c, i): 2 SALU + s_mov m0 + the DMA.
+    __device__ __forceinline__ void piece_unchecked(uint32_t c, int i) {
+        const float *g = wsrc + ((size_t)c * kChunkGroups + i * 4) * 256;
+        const uint32_t l = wlds + ((c & 1u) * kChunkGroups + i * 4) * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :
+                     : "s"(l), "v"(voff), "s"(g)
+                     : "memory");           // m0 is a reserved register: the compiler never keeps a value in it
+    }
+    __device__ __forceinline__ void piece(uint32_t c, int i) {
+        if (c < n_chunks) piece_unchecked(c, i);
+    }
     __device__ __forceinline__ void issue(uint32_t c) {
-        if (c >= n_chunks) return;
-        const float *g = src + (size_t)c * kChunkGroups * 256;
-        float *l = lds + (c & 1u) * kChunkGroups * 256;
 #pragma unroll
-        for (int i = 0; i < kChunkGroups / 4; i++) {
-            const int slot = i * 4 + wave;                         // one 1 KiB group per wave-instruction
-            __builtin_amdgcn_global_load_lds(g + slot * 256 + lane * 4,
-                                             (__attribute__((address_space(3))) void *)(l + slot * 256), 16, 0, 0);
-        }
+        for (int i = 0; i < kChunkGroups / 4; i++) piece(c, i);
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ void sync() {   // publish the chunk whose DMA is in flight, retire reads of the other
+        drain();
+        __syncthreads();
     }
     __device__ __forceinline__ void boundary(uint32_t c) {
-        __syncthreads();
+        sync();
         issue(c + 1);
     }
-    __device__ __forceinline__ float4 group(int g) const {       // g = index in the whole stream
-        const float *l = lds + ((g / kChunkGroups) & 1) * kChunkGroups * 256 + (g % kChunkGroups) * 256;
-        return *reinterpret_cast<const float4 *>(l + lane * 4);
+    __device__ __forceinline__ const float *group_ptr(int g) const {   // g = index in the whole stream
+        return lds + ((g / kChunkGroups) & 1) * kChunkGroups * 256 + (g % kChunkGroups) * 256;
+    }
+    // two per-lane base addresses (one per buffer) + an immediate offset < 64 KiB: ds_read_b128's offset
+    // field is 16 bits, so a single base would need a separate address register for every group of buffer 1
+    __device__ __forceinline__ float4 group(int g) const {
+        const float *b0 = lds + lane * 4, *b1 = lds + kChunkGroups * 256 + lane * 4;
+        const float *l = ((g / kChunkGroups) & 1) ? b1 : b0;
+        return *reinterpret_cast<const float4 *>(l + (g % kChunkGroups) * 256);
     }
 };
 

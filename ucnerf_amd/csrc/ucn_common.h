@@ -38,6 +38,7 @@ struct UcnLevel {
     // early exit: stride[d] = 0 for dimensions the walk never reaches.  (With side = 65537 the
     // product 65537^2 wraps to 131073 <= rows, so that level is *not* hashed in the reference.)
     uint32_t stride[5];
+    float inv_gs;         // 1/sqrt(gs2): erf argument = inv_gs / sqrt(8 std^2)   (models.py:495)
 };
 struct UcnLevels {
     UcnLevel lv[UCN_MAX_LEVELS];

@@ -234,10 +234,10 @@ class MLP(nn.Module):
             if B % n_rays:
                 raise RuntimeError("viewdirs do not divide the sample count")
             spr = B // n_rays
-            dirb = torch.empty(n_rays * 2 * self.net_width_viewdirs, device=dev)
+            dirb = torch.empty(lib.ucn_field_dir_floats(ctypes.byref(d), n_rays), device=dev)
             _lib.check(lib.ucn_field_dir_bias(ctypes.byref(d), vd.data_ptr(), n_rays, dirb.data_ptr(), st))
             rgb = torch.empty(B, 3, device=dev)
-        _lib.check(lib.ucn_field_mlp(ctypes.byref(d), feat.data_ptr(), B, spr, _lib.ptr(dirb), density.data_ptr(),
+        _lib.check(lib.ucn_field_mlp(ctypes.byref(d), feat.data_ptr(), B, spr, 0, _lib.ptr(dirb), density.data_ptr(),
                                      _lib.ptr(rgb), _lib.ptr(x), st))
         # raw (pre-activation) density: softplus is inverted only for API parity of predict_density
         raw = None
@@ -286,6 +286,7 @@ class Model(nn.Module):
     # ---- knobs of this implementation (not in the reference) ----
     max_chunk_rays: int = 1 << 16        # rays per internal pass (bounds the feature workspace)
     levels_per_block: int = 1            # hash-grid levels handled per thread (1 = level-major)
+    rays_fastest: bool = True            # wave lanes = neighbouring rays at one sample index (L1/L2 locality)
 
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -347,7 +348,7 @@ class Model(nn.Module):
         else:
             anneal = 1.
         nerf_desc = self.nerf_mlp.field()
-        dirb = torch.empty(N * 2 * self.nerf_mlp.net_width_viewdirs, device=dev)
+        dirb = torch.empty(lib.ucn_field_dir_floats(ctypes.byref(nerf_desc), N), device=dev)
         _lib.check(lib.ucn_field_dir_bias(ctypes.byref(nerf_desc), vd.data_ptr(), N, dirb.data_ptr(), st))
 
         renderings, ray_history = [], []
@@ -403,13 +404,13 @@ class Model(nn.Module):
                     ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
-                    float(self.std_scale), n, S, int(self.levels_per_block), 0, feat.data_ptr(),
-                    None if coord is None else coord[sl].data_ptr(), None, st))
+                    float(self.std_scale), n, S, int(self.levels_per_block), 2 if self.rays_fastest else 0,
+                    feat.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, st))
                 if prof is not None:
                     e1.record()
                 _lib.check(lib.ucn_field_mlp(
-                    ctypes.byref(desc), feat.data_ptr(), n * S, S,
-                    None if is_prop else dirb[r0 * 2 * self.nerf_mlp.net_width_viewdirs:].data_ptr(),
+                    ctypes.byref(desc), feat.data_ptr(), n * S, S, int(bool(self.rays_fastest)),
+                    None if is_prop else dirb[r0 * (dirb.numel() // N):].data_ptr(),
                     density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
                 if prof is not None:
                     e2.record()
