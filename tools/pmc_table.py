@@ -2,7 +2,8 @@
 import csv, glob, collections, sys
 agg = collections.defaultdict(lambda: [0, 0.0])
 dur = collections.defaultdict(lambda: [0, 0.0])
-for f in sorted(glob.glob("gpurun_out/pmc_*/p_counter_collection.csv")):
+import os
+for f in sorted(glob.glob(os.environ.get("PMC_GLOB", "gpurun_out/pmc_*/p_counter_collection.csv"))):
     seen = set()
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
