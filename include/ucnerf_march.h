@@ -130,12 +130,20 @@ int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, con
 
 /* Backward of ucn_march_features w.r.t. the table (ref: grid.py:68-89 -> gridencoder.cu:248-340 composed
  * with the erf damping and mean of models.py:495-496; positions carry no gradient, coord.py:75).
- * grad_embeddings [rows, level_dim] is accumulated into (pre-zero it, like grid.py:77). */
+ * grad_embeddings [rows, level_dim] is accumulated into (pre-zero it, like grid.py:77).
+ * levels_per_block = 0 picks the algorithm: row-block ownership in LDS without global atomics while the
+ * table has <= 64 blocks of 128 KiB per level, else the atomic scatter; >= 1 forces the atomic scatter.
+ * sample_major: 0 = grad_features [num_levels][N*S][level_dim] (preferred), 1 = [N*S][num_levels*level_dim]. */
 int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                 const float *origins, const float *directions, const float *basis,
                                 const float *radii, const float *flip, const float *spin, float std_scale,
                                 uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
-                                const float *grad_features, float *grad_embeddings, ucn_stream_t stream);
+                                const float *grad_features, float *grad_embeddings,
+                                float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(N,S) floats, or NULL:
+                                                   the row-block algorithm then re-derives the sample geometry in
+                                                   every workgroup instead of reading it back (3x slower)*/,
+                                ucn_stream_t stream);
+uint64_t ucn_march_features_backward_ws_floats(uint32_t N, uint32_t S);
 
 /* Same featurisation for caller-supplied Gaussians (ref: models.py:485-512 predict_density as
  * called by extract.py:56-57,96): means [B,G,3], stds [B,G]; warp=0 skips the contraction. */

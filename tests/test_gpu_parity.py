@@ -297,6 +297,57 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
     torch.set_grad_enabled(True)
 
 
+def test_features_backward_algorithms_agree():
+    """Table gradient of the fused featurisation: row-block ownership (no global atomics) == atomic scatter,
+    in both gradient layouts; the atomic scatter itself is pinned to the reference's training step by
+    test_train_step.py."""
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=3)
+    n = 700
+    rays = rm.synthetic_rays(n, seed=4)
+    noise = [rm.draw_level_noise(spec, n, l, False, torch.Generator().manual_seed(5 + l)) for l in range(2)]
+    model, _ = H.hip_model(spec, sd)
+    with torch.no_grad():
+        _, hist = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+    mlp = model.nerf_mlp
+    enc = mlp.encoder
+    sdist = hist[-1]["sdist"].contiguous()
+    S = sdist.shape[-1] - 1
+    b = H.to_dev(rays)
+    flat = {k: b[k].reshape(n, -1).contiguous() for k in ("origins", "directions", "cam_dirs", "radii", "near", "far")}
+    basis = torch.empty(n, 6, device="cuda")
+    rvec = noise[-1].rand_vec.cuda().contiguous()
+    st = _lib.stream()
+    _lib.check(lib.ucn_cone_basis(flat["cam_dirs"].data_ptr(), rvec.data_ptr(), n, basis.data_ptr(), st))
+    L, C = enc.num_levels, enc.level_dim
+    g0 = torch.randn(L, n * S, C, device="cuda")
+    g0[:, ::7] = 0                                            # samples without gradient are skipped
+    g1 = g0.permute(1, 0, 2).contiguous()                     # [N*S][L*C]
+
+    ws = torch.empty(lib.ucn_march_features_backward_ws_floats(n, S), device="cuda")
+    assert ws.numel() == 24 * n * S
+
+    def run(lpb, layout, g, work=None, out=None):
+        out = torch.zeros_like(enc.embeddings) if out is None else out
+        _lib.check(lib.ucn_march_features_backward(
+            ctypes.byref(mlp.field()), sdist.data_ptr(), flat["near"].data_ptr(), flat["far"].data_ptr(),
+            flat["origins"].data_ptr(), flat["directions"].data_ptr(), basis.data_ptr(), flat["radii"].data_ptr(), None, None,
+            float(model.std_scale), n, S, lpb, layout, g.data_ptr(), out.data_ptr(), _lib.ptr(work), st))
+        return out
+
+    want = run(1, 0, g0)                                      # atomic scatter
+    assert float(want.abs().max()) > 0
+    tol = 2e-5 * float(want.abs().max())                      # same addends, different summation order
+    assert H.maxdiff(run(0, 0, g0, ws), want) <= tol          # row blocks, cached geometry, level-major gradient
+    assert H.maxdiff(run(0, 0, g0), want) <= tol              # row blocks, geometry re-derived per workgroup
+    assert H.maxdiff(run(0, 1, g1, ws), want) <= tol          # row blocks, sample-major gradient
+    assert H.maxdiff(run(4, 1, g1), want) <= tol
+    twice = run(0, 0, g0, ws, run(0, 0, g0, ws))              # accumulates into grad_embeddings
+    assert H.maxdiff(twice, 2 * want) <= 2 * tol
+
+
 def test_render_image_vs_golden_and_invariants():
     from ucnerf_amd.internal import models
     fx = H.load("render_image.npz")

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -59,7 +59,8 @@ SIGNATURES = {
     "ucn_march_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
                            c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                    c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp],
+                                    c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_march_features_backward_ws_floats": [c_u32, c_u32],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
     "ucn_field_dir_floats": [ctypes.POINTER(UcnField), c_u32],
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
-             "ucn_field_dir_floats": c_u64,
+             "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64}
 
 _lib = None

@@ -208,6 +208,39 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
     }
 }
 
+// Row-block variant of level_scatter: only corners whose row lies in [row_lo, row_lo + nrows) count, and
+// they go to the workgroup's LDS copy of that row block (ds_add_f32).
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo,
+                                                    uint32_t nrows, const float (&u)[6][3], const float (&rs)[6],
+                                                    const float (&gout)[C]) {
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            float fx, fy, fz;
+            uint32_t rows[8];
+            corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+            bool any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                rows[k] -= row_lo;                      // uint32 wrap: rows below the block become huge
+                any |= rows[k] < nrows;
+            }
+            if (any) {
+                float w[8];
+                corner_weights(fx, fy, fz, w);
+                const float damp = erf_pos(rs[j] * lv.inv_gs);
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                    if (rows[k] < nrows) {
+#pragma unroll
+                        for (uint32_t c = 0; c < C; c++) atomicAdd(acc + rows[k] * C + c, (w[k] * damp) * gout[c]);
+                    }
+            }
+        }
+    }
+}
+
 // layout: 0 = [L][B][C] (b as given), 1 = [B][L*C]
 template <uint32_t C>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
@@ -390,6 +423,100 @@ __global__ __launch_bounds__(256) void k_march_features_bwd(UcnLevels lvls, floa
     featurise_bwd<C>(lvls, grad_table, lvl0, lvl1, u, rs, 6, B, b, grad_features, layout == 1);
 }
 
+// Same gradient without global atomics.  Scattered fp32 atomics run at ~21 G/s on MI355X whatever their
+// scope (tools/atomic_bench.hip: 50 M row updates x 2 channels = 4.8 ms, against 0.14 ms for the forward's
+// gathers of the same rows), and a hashed level receives ~100 updates per row per 8192-ray batch.  So:
+// one workgroup OWNS a block of `rpb` rows of one level (128 KiB of LDS), walks ALL samples, recomputes
+// their corners (VALU is cheap here) and accumulates the ones that fall in its block with ds_add_f32;
+// the block is then added to the table gradient with plain coalesced read-modify-writes -- no other
+// workgroup touches those rows.  blockIdx.x enumerates (level, block) pairs, level-major.
+// The six contracted multisample positions and damping arguments of every sample, as 24 planes of
+// [N*S] floats: written once per backward call, read by every (level, row block) workgroup.
+__global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx, float std_scale, uint32_t N, uint32_t S,
+                                                    float *__restrict__ geom) {
+    const size_t B = (size_t)N * S;
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    float u[6][3], rs[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) geom[(size_t)(j * 3 + d) * B + b] = u[j][d];
+        geom[(size_t)(18 + j) * B + b] = rs[j];
+    }
+}
+
+__host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level) {
+    return blocks_in_level >= 128u ? 1u : 128u / blocks_in_level;        // ~128 workgroups per level
+}
+
+template <uint32_t C>
+__global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls, float *__restrict__ grad_table,
+                                                                 RayInputs in, HexPattern hx, float std_scale, uint32_t N,
+                                                                 uint32_t S, int layout, uint32_t rpb,
+                                                                 const float *__restrict__ grad_features,
+                                                                 const float *__restrict__ geom) {
+    extern __shared__ float s_acc[];
+    uint32_t task = blockIdx.x, lvl = 0, nb = 1, split = 1;
+    for (;; lvl++) {
+        nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
+        split = bwd_sample_split(nb);
+        if (task < nb * split || lvl + 1 == lvls.L) break;
+        task -= nb * split;
+    }
+    const UcnLevel lv = lvls.lv[lvl];
+    const uint32_t row_lo = (task / split) * rpb, part = task % split;
+    const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) s_acc[i] = 0.0f;
+    __syncthreads();
+    const size_t B = (size_t)N * S;
+    const uint32_t F = lvls.L * C;
+    // a level with few blocks (the dense coarse ones) is cut along the samples too: `split` workgroups per
+    // block, interleaved in units of 1024 samples; they share the block, so their flush is atomic
+    for (size_t b = (size_t)part * 1024u + threadIdx.x; b < B; b += (size_t)split * 1024u) {
+        const float *gp = layout == 1 ? grad_features + b * F + (size_t)lvl * C : grad_features + ((size_t)lvl * B + b) * C;
+        float gout[C];
+        bool nz = false;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            gout[c] = gp[c] / 6.0f;                                     // d(mean over the 6 multisamples)
+            nz |= gout[c] != 0.0f;
+        }
+        if (!nz) continue;
+        float u[6][3], rs[6];
+        if (geom) {                                   // k_cast_cache's planes: every task re-reads, nobody re-derives
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) {
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) u[j][d] = geom[(size_t)(j * 3 + d) * B + b];
+                rs[j] = geom[(size_t)(18 + j) * B + b];
+            }
+        } else {
+            const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+            float csum[3], tsum;
+            cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
+        }
+        if (lv.hashed) {
+            if (lv.mask) level_scatter_block<C, true, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else level_scatter_block<C, true, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+        } else {
+            if (lv.mask) level_scatter_block<C, false, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else level_scatter_block<C, false, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+        }
+    }
+    __syncthreads();
+    float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
+        const float v = s_acc[i];
+        if (v != 0.0f) {
+            if (split == 1) gtab[i] += v;
+            else atomicAdd(gtab + i, v);
+        }
+    }
+}
+
 // predict_density's featurisation for caller-supplied Gaussians (extract.py / API parity)
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_points_features(UcnLevels lvls, const float *__restrict__ table,
@@ -479,11 +606,14 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     return 0;
 }
 
+extern "C" uint64_t ucn_march_features_backward_ws_floats(uint32_t N, uint32_t S) { return 24ull * N * S; }
+
 extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                            const float *origins, const float *directions, const float *basis,
                                            const float *radii, const float *flip, const float *spin, float std_scale,
                                            uint32_t N, uint32_t S, uint32_t levels_per_block, int layout,
-                                           const float *grad_features, float *grad_embeddings, ucn_stream_t stream) {
+                                           const float *grad_features, float *grad_embeddings, float *workspace,
+                                           ucn_stream_t stream) {
     UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
                 "march_features_backward: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
@@ -491,13 +621,41 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
-    if (levels_per_block == 0) levels_per_block = 1;
     const size_t B = (size_t)N * S;
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
-    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     hipStream_t st = (hipStream_t)stream;
+    if (levels_per_block == 0) {
+        // row-block ownership (no global atomics) while the recomputation stays cheap: every block walks
+        // all samples, so the cost grows with the number of blocks; above 64 blocks per level the atomic
+        // scatter below wins again
+        const uint32_t rpb = 128u * 1024u / (lv.C * 4u);
+        uint32_t tasks = 0, blocks = 0;
+        for (uint32_t l = 0; l < lv.L; l++) {
+            const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
+            blocks += nb;
+            tasks += nb * bwd_sample_split(nb);
+        }
+        if (blocks <= 64u * lv.L) {
+            if (workspace)
+                hipLaunchKernelGGL(k_cast_cache, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, in, hx, std_scale, N, S, workspace);
+#define UCN_MBB(CC)                                                                                              \
+    hipLaunchKernelGGL(k_march_features_bwd_blk<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4, st, lv,      \
+                       grad_embeddings, in, hx, std_scale, N, S, layout, rpb, grad_features, workspace)
+            switch (lv.C) {
+                case 1: UCN_MBB(1); break;
+                case 2: UCN_MBB(2); break;
+                case 4: UCN_MBB(4); break;
+                case 8: UCN_MBB(8); break;
+            }
+#undef UCN_MBB
+            UCN_LAUNCH_CHECK("march_features_backward (row blocks)");
+            return 0;
+        }
+        levels_per_block = 1;
+    }
+    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
 #define UCN_MB(CC)                                                                                                  \
     hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \
                        S, levels_per_block, layout, grad_features)

@@ -50,9 +50,13 @@ class _FieldFeatures(torch.autograd.Function):
         mlp = ctx.mlp
         emb = mlp.encoder.embeddings
         grad = torch.zeros_like(emb)                                   # dense, like grid.py:77
-        g = g_feat.contiguous().float()
+        # level-major copy of the feature gradient ([L][N*S][C]): every (level, row block) workgroup of the
+        # backward then streams its own level's 8 bytes per sample instead of striding through [N*S][L*C]
+        enc = mlp.encoder
+        g = g_feat.float().reshape(N * S, enc.num_levels, enc.level_dim).permute(1, 0, 2).contiguous()
+        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
-                                                   N, S, lpb, 1, g.data_ptr(), grad.data_ptr(), _lib.stream()))
+                                                   N, S, 0, 0, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
         return grad, None, None, None, None, None, None
 
 
