@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--ray-major", action="store_true", help="lanes = consecutive samples of a ray (default: neighbouring rays)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="0 fp32-input MFMA, 1 split-f16 MFMA (default: the package default)")
+    ap.add_argument("--overlap", action="store_true", help="featurisation of pass i+1 beside the MLP of pass i (2 streams)")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
@@ -184,6 +185,8 @@ def main():
         model.max_chunk_rays = args.chunk
     if args.ray_major:
         model.rays_fastest = False
+    if args.overlap:
+        model.overlap_streams = True
     batch = frame_rays(device)
     n_rays = H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)
@@ -216,8 +219,8 @@ def main():
 
     # per-kernel time from the HIP events recorded on the launch stream during the timed steps
     feat_ms = {0: 0.0, 1: 0.0}; mlp_ms = {0: 0.0, 1: 0.0}; rays_seen = {0: 0, 1: 0}; launches = {0: 0, 1: 0}
-    for lvl, n, e0, e1, e2 in prof:
-        feat_ms[lvl] += e0.elapsed_time(e1); mlp_ms[lvl] += e1.elapsed_time(e2); rays_seen[lvl] += n; launches[lvl] += 1
+    for lvl, n, e0, e1, m0, e2 in prof:
+        feat_ms[lvl] += e0.elapsed_time(e1); mlp_ms[lvl] += m0.elapsed_time(e2); rays_seen[lvl] += n; launches[lvl] += 1
     if rank == 0:
         lo, hi = udist.shard_bounds(n_rays, world, rank)
         rays_rank = (hi - lo) * args.steps

@@ -117,7 +117,9 @@ int ucn_cone_basis(const float *cam_dirs /*[N,3]*/, const float *rand_vec /*[N,3
 /* ref: render.py:94-152 cast_rays + coord.py:60-116 contraction + grid.py:158-174 /
  * gridencoder.cu:87-199 + models.py:494-496 (erf damping, mean over the 6 multisamples).
  * features_out layout [num_levels][N*S][level_dim]  (level-major like gridencoder.cu:108).
- * flip/spin NULL = deterministic hexagon pattern (rand=False). coord_out/tmean_out optional. */
+ * flip/spin NULL = deterministic hexagon pattern (rand=False). coord_out/tmean_out optional.
+ * levels_per_block: levels handled by one thread (the sample geometry is derived once per group);
+ * 0 = auto (levels of resolution <= 2048 in groups of eight, finer levels alone); results do not depend on it. */
 int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, const float *near_ /*[N]*/,
                        const float *far_ /*[N]*/, const float *origins, const float *directions,
                        const float *basis /*[N,6]*/, const float *radii /*[N]*/,

@@ -375,11 +375,38 @@ __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPatter
     }
 }
 
+// Levels handled by one thread: group g = levels [lo[g], lo[g+1]).  A thread re-derives the sample's six
+// contracted positions (~800 VALU instructions) once per GROUP, then pays ~400-500 per level.  Fine
+// hashed levels stay alone (level-major dispatch keeps one 4 MiB slice per XCD L2); the coarse levels,
+// which are VALU-bound and whose accesses are concentrated on a few cells, share the geometry.
+struct LevelGroups {
+    uint8_t lo[UCN_MAX_LEVELS + 1];
+    uint32_t n;
+};
+static LevelGroups make_groups(const UcnLevels &lv, uint32_t levels_per_block) {
+    LevelGroups g;
+    g.n = 0;
+    uint32_t l = 0;
+    const uint32_t cres = 2048u, cgrp = 8u;   // measured: (512..8192) x (3..8) all within 3 %; this is the best
+    while (l < lv.L) {
+        g.lo[g.n++] = (uint8_t)l;
+        uint32_t take = levels_per_block;
+        if (levels_per_block == 0) take = lv.lv[l].resolution <= cres ? cgrp : 1u;          // auto
+        uint32_t end = l + take < lv.L ? l + take : lv.L;
+        if (levels_per_block == 0)                                                        // a group never mixes coarse and fine
+            for (uint32_t k = l + 1; k < end; k++)
+                if (lv.lv[k].resolution > cres) { end = k; break; }
+        l = end;
+    }
+    g.lo[g.n] = (uint8_t)lv.L;
+    return g;
+}
+
 // layout: 0 = [L][N*S][C] with b = ray*S+s; 1 = [N*S][L*C]; 2 = [L][S*N][C] with b = s*N+ray
 template <uint32_t C>
 __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
-                                                        uint32_t lpb, int layout, float *__restrict__ features,
+                                                        LevelGroups grp, int layout, float *__restrict__ features,
                                                         float *__restrict__ coord_out, float *__restrict__ tmean_out) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -392,8 +419,7 @@ __global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const fl
     else { ray = (uint32_t)(b / S); s = (uint32_t)(b - (size_t)ray * S); }
     float u[6][3], rs[6], csum[3], tsum;
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
-    const uint32_t lvl0 = blockIdx.y * lpb;
-    const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
+    const uint32_t lvl0 = grp.lo[blockIdx.y], lvl1 = grp.lo[blockIdx.y + 1];
     featurise<C>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
     if (blockIdx.y == 0) {
         const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
@@ -585,16 +611,16 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
-    if (levels_per_block == 0) levels_per_block = 1;
     const size_t B = (size_t)N * S;
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features: too many samples in one call (%zu)", B);
-    const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
+    const LevelGroups grp = make_groups(lv, levels_per_block);
+    const dim3 grid(ucn_div_up(B, 256), grp.n);
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     hipStream_t st = (hipStream_t)stream;
 #define UCN_MF(CC)                                                                                              \
     hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), 0, st, lv, f->embeddings, in, hx, std_scale, N, S, \
-                       levels_per_block, layout, features_out, coord_out, tmean_out)
+                       grp, layout, features_out, coord_out, tmean_out)
     switch (lv.C) {
         case 1: UCN_MF(1); break;
         case 2: UCN_MF(2); break;

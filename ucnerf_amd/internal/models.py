@@ -10,8 +10,9 @@ composite) instead of ~300 eager ops, and nothing of size [N*S*6, .] is ever mat
 
 Supported configuration = the reference's shipped one (configs/waymo.gin): disable_density_normals,
 no GLO, no reflections / diffuse / IDE, raydist_fn=None.  Anything else raises at construction.
-Forward is inference-grade (no autograd graph); the training backward is a later row of the
-scope table.  Without the HIP library or a GPU every entry point raises.
+With gradients disabled forward is the fused inference march; with gradients enabled it routes to
+internal/train_graph.py (same kernels for resampling and featurisation, HIP backward for the tables,
+autograd for the dense layers).  Without the HIP library or a GPU every entry point raises.
 """
 import ctypes
 
@@ -285,7 +286,9 @@ class Model(nn.Module):
     prop_desired_grid_size = [512, 2048]
     # ---- knobs of this implementation (not in the reference) ----
     max_chunk_rays: int = 1 << 16        # rays per internal pass (bounds the feature workspace)
-    levels_per_block: int = 1            # hash-grid levels handled per thread (1 = level-major)
+    levels_per_block: int = 0            # hash-grid levels per thread: 0 = auto (coarse levels together, fine alone)
+    overlap_streams: bool = False        # featurisation of pass i+1 beside the MLP of pass i on a second HIP stream:
+    #                                      measured +1 % only (both kernels want every CU), so off by default
     rays_fastest: bool = True            # wave lanes = neighbouring rays at one sample index (L1/L2 locality)
 
     def __init__(self, config=None, **kwargs):
@@ -394,27 +397,55 @@ class Model(nn.Module):
                                         sdist.data_ptr(), st))
             _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
             prof = getattr(self, '_prof', None)
-            for r0 in range(0, N, chunk):
+            # Two HIP streams: featurisation of pass i+1 (L2-request / VALU bound) runs beside the MLP of pass i
+            # (MFMA bound) on a second feature buffer; the hardware splits the CUs between the two kernels.
+            overlap = bool(self.overlap_streams) and N > chunk
+            cur = torch.cuda.current_stream()
+            feats = [feat]
+            if overlap:
+                feats.append(torch.empty_like(feat))
+                if getattr(self, '_side_stream', None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side = self._side_stream
+                side.wait_stream(cur)
+            mlp_done = [None, None]
+            for i_pass, r0 in enumerate(range(0, N, chunk)):
                 n = min(chunk, N - r0)
                 sl = slice(r0, r0 + n)
+                fb = feats[i_pass % len(feats)]
                 if prof is not None:
-                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                    e0.record()
+                    e0, e1, m0, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+                fstream = side if overlap else cur
+                if overlap and mlp_done[i_pass % 2] is not None:
+                    side.wait_event(mlp_done[i_pass % 2])             # the buffer's previous reader
+                if prof is not None:
+                    e0.record(fstream)
                 _lib.check(lib.ucn_march_features(
                     ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
                     float(self.std_scale), n, S, int(self.levels_per_block), 2 if self.rays_fastest else 0,
-                    feat.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, st))
+                    fb.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, fstream.cuda_stream))
                 if prof is not None:
-                    e1.record()
+                    e1.record(fstream)
+                if overlap:
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    cur.wait_event(ready)
+                if prof is not None:
+                    m0.record(cur)
                 _lib.check(lib.ucn_field_mlp(
-                    ctypes.byref(desc), feat.data_ptr(), n * S, S, int(bool(self.rays_fastest)),
+                    ctypes.byref(desc), fb.data_ptr(), n * S, S, int(bool(self.rays_fastest)),
                     None if is_prop else dirb[r0 * (dirb.numel() // N):].data_ptr(),
                     density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
+                if overlap:
+                    mlp_done[i_pass % 2] = torch.cuda.Event()
+                    mlp_done[i_pass % 2].record(cur)
                 if prof is not None:
-                    e2.record()
-                    prof.append((i_level, n, e0, e1, e2))
+                    e2.record(cur)
+                    prof.append((i_level, n, e0, e1, m0, e2))      # features: e0..e1 on its stream, MLP: m0..e2
+            if overlap:
+                cur.wait_stream(side)
             _lib.check(lib.ucn_composite(density.data_ptr(), _lib.ptr(rgbs), sdist.data_ptr(), near.data_ptr(),
                                          far.data_ptr(), d.data_ptr(), float(self.bg_intensity_range[0]),
                                          int(bool(self.opaque_background)), N, S, weights.data_ptr(),
