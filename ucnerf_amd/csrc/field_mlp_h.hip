@@ -1,25 +1,32 @@
 // Density + colour MLP of one field, split-f16 MFMA variant (mlp_mode 1; engine: mfma_chain_h.h).
-// Same network and interleaving as field_mlp.hip (models.py:507-508, :581, :599-674 of
-// /root/reference/nerf/internal/models.py); differences that matter for speed:
-//   * 3 x v_mfma_f32_32x32x16_f16 per 16 k's instead of 8 x v_mfma_f32_32x32x2_f32 (5.3x the rate);
-//   * the 27 view-direction inputs are one more 32-wide INPUT tile of both colour layers
-//     (k < 27: pos_enc(viewdir), k = 27: the constant 1 whose weight column is the layer's bias,
-//     k > 27: 0), produced per ray by k_dir_enc -- 128 B per ray instead of 2 KiB of folded biases;
-//   * all weights AND biases come through the LDS stream; the only global loads of a wave are its
-//     feature values and its direction tile, issued before the first barrier;
-//   * the whole network is ONE pipelined segment of the stream: A operands are requested kDepth steps
-//     ahead, across layer boundaries.
+// Network: models.py:507-508, :581, :599-674 of /root/reference/nerf/internal/models.py.
 //
-// Stream (1 KiB groups; a "pair" is [hi][lo]):
-//   B   groups 0-1: bias tiles [b_d0: 2 tiles][b_d1: NTB tiles]
-//   S0  density layer 0   pairs [s < kFirstSteps][o2]
-//   S1  density layer 1   pairs [otp < NTB/2][it < 2][s][o2]                           rows of W_d1
-//   S2  colour layer 1, skip part: pairs [otp < NTW/2][it < NTB+1][s][o2]   W_c1[:, NW : NW+NB+27 | b_c1]
-//   S3  per PAIR of hidden tiles (t, t+1):
-//         colour layer 0   pairs [it < NTB+1][s][o2]                   rows 32t..32t+63 of W_c0 | b_c0
-//         colour layer 1   pairs [otp < NTW/2][it < 2][s][o2]          W_c1[:, 32t : 32t+64]
+// 1. COMPOSED LAYERS.  The reference's bottleneck x = W_d1 h0 + b_d1 (models.py:508, Linear(64, 256) with
+//    NO activation behind it) is consumed only by linear maps -- the first colour layer and, through the
+//    skip connection, the second (models.py:599-656; bottleneck_noise = 0 is enforced at construction).
+//    So, exactly in real arithmetic,
+//        h1 = relu( (W_c0[:, x] W_d1) h0 + W_c0[:, dir] d + (W_c0[:, x] b_d1 + b_c0) )
+//        h2 = relu( W_c1[:, h1] h1 + (W_c1[:, x] W_d1) h0 + W_c1[:, dir] d + (W_c1[:, x] b_d1 + b_c1) )
+//        raw density = W_d1[0, :] h0 + b_d1[0]
+//    and the 256-wide x never has to exist: ucn_field_pack composes the two 256x64 products once per
+//    weight update (double accumulation, then rounded to fp32), and the kernel runs 118,784 MACs per
+//    sample instead of 229,632, with 3 input tiles (h0: 2, direction: 1) live instead of 9.  The
+//    difference to the reference is the fp32 rounding of x (~6e-8 relative) -- below the split-f16
+//    product error.  (The bottleneck OUTPUT of predict_density is served by the fp32 kernel.)
+// 2. 3 x v_mfma_f32_32x32x16_f16 per 16 k's instead of 8 x v_mfma_f32_32x32x2_f32 (5.3x the rate).
+// 3. The 27 view-direction inputs are one 32-wide input tile (k < 27: pos_enc(viewdir), k = 27: the
+//    constant 1 whose weight column is the composed bias, k > 27: 0), produced per ray by k_dir_enc.
+// 4. All weights and biases come through ONE pipelined LDS stream (A operands kDepth pairs ahead); the only
+//    global loads of a wave are its feature values and its direction tile, issued before the first barrier.
+//
+// Stream (1 KiB groups; a "pair" is [hi][lo]; output tiles go in pairs, o2 innermost):
+//   B   groups 0-1: floats [0,64) b_d0 as 2 bias tiles; [64,128) density head W_d1[0, :] in accumulator-slot
+//       order; [128] b_d1[0]
+//   S0  density layer 0      pairs [s < kFirstSteps][o2]
+//   A   composed layer 0     pairs [otp < NTW/2][it < 3][s][o2]     M_A = [W_c0x W_d1 | W_c0 dir | bias | 0]
+//   B2  composed skip part   pairs [otp < NTW/2][it < 3][s][o2]     M_B = [W_c1x W_d1 | W_c1 dir | bias | 0]
+//   B1  colour layer 1       pairs [otp < NTW/2][it < NTW][s][o2]   W_c1[:, 0:NW]
 //   S4  rgb head {w_r, w_g, w_b, 0} per accumulator slot (4 groups)
-// Output tiles always go in pairs (o2 innermost): consecutive MFMAs alternate between two accumulators.
 #include "field_plan.h"
 #include "mfma_chain_h.h"
 
@@ -48,26 +55,41 @@ __global__ __launch_bounds__(256) void k_dir_enc(const float *__restrict__ viewd
     out[i] = v;
 }
 
-template <int T, int NTB, int NTW>
-__device__ __forceinline__ void hidden_tiles_h(const int G3, const int GEND, f32x16 (&h2)[NTW], const HTile (&xin)[NTB + 1],
-                                               APipe &p, WeightStream &ws) {
-    // hidden tiles T, T+1 together (two independent accumulators, see dstep_h)
-    constexpr int PER_PAIR = (NTB + 1) * 8 + NTW * 8;
-    const int base = G3 + (T / 2) * PER_PAIR;
-    f32x16 h1[2];
-#pragma unroll
-    for (int r = 0; r < 16; r++) h1[0][r] = h1[1][r] = 0.0f;   // b_c0 rides in the direction tile's slot 27
-    chain_h<2, NTB + 1>(base, GEND, h1, xin, p, ws);
-    relu_tile(h1[0]);
-    relu_tile(h1[1]);
-    HTile t[2];
-    split_tile(h1[0], t[0]);
-    split_tile(h1[1], t[1]);
-    chain_h<NTW, 2>(base + (NTB + 1) * 8, GEND, h2, t, p, ws);
-    if constexpr (T + 2 < NTW) hidden_tiles_h<T + 2, NTB, NTW>(G3, GEND, h2, xin, p, ws);
+// M[j][c], j < NW, c < kCompCols:  c < 64: sum_i Wout[j][col0+i] W_d1[i][c]  |  c-64 < ND: Wout[j][col0+NB+c-64]
+//                                  c == 64+ND: bias_out[j] + sum_i Wout[j][col0+i] b_d1[i]  |  else 0
+__global__ __launch_bounds__(256) void k_compose(const float *__restrict__ Wout, uint32_t ldo, uint32_t col0,
+                                                 const float *__restrict__ bias_out, const float *__restrict__ Wd1,
+                                                 const float *__restrict__ bd1, uint32_t NB, uint32_t ND, uint32_t NW,
+                                                 float *__restrict__ M) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= NW * kCompCols) return;
+    const uint32_t j = i / kCompCols, c = i - j * kCompCols;
+    const float *wr = Wout + (size_t)j * ldo + col0;
+    float v = 0.0f;
+    if (c < 64u) {
+        double acc = 0.0;
+        for (uint32_t k = 0; k < NB; k++) acc += (double)wr[k] * (double)Wd1[(size_t)k * 64 + c];
+        v = (float)acc;
+    } else if (c - 64u < ND) {
+        v = wr[NB + c - 64u];
+    } else if (c == 64u + ND) {
+        double acc = (double)bias_out[j];
+        for (uint32_t k = 0; k < NB; k++) acc += (double)wr[k] * (double)bd1[k];
+        v = (float)acc;
+    }
+    M[i] = v;
 }
 
-template <int NTB, int NTW>
+// density head weights in accumulator-slot order + its bias, behind the two b_d0 tiles of group 0
+__global__ __launch_bounds__(64) void k_pack_density_head(const float *__restrict__ Wd1, const float *__restrict__ bd1,
+                                                          float *__restrict__ dst) {
+    const uint32_t i = threadIdx.x;                          // slot = (it*16 + r)*2 + h
+    const uint32_t h = i & 1u, r = (i >> 1) & 15u, it = i >> 5;
+    dst[64 + i] = Wd1[acc_row(it, r, h)];                    // row 0 of W_d1 [NB, 64]
+    if (i == 0) dst[128] = bd1[0];
+}
+
+template <int NTW>
 __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // 2 x 64 KiB weight chunks
     const int lane = threadIdx.x & 63;
@@ -80,11 +102,12 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     const uint32_t b = live ? b0 + j : a.B - 1;
     const uint32_t oi = out_index(a, b);                 // position in the [ray][sample]-ordered outputs
 
-    constexpr int G0 = 2;                                // after the bias tiles
-    constexpr int G1 = G0 + 2 * kKS * 2;
-    constexpr int G2 = G1 + NTB * 2 * 4;
-    constexpr int G3 = G2 + NTW * (NTB + 1) * 4;
-    constexpr int GH = G3 + NTW * ((NTB + 1) * 4 + NTW * 4);   // end of the pipelined segment, rgb head
+    constexpr int G0 = 2;                                // after the bias group pair
+    constexpr int GA = G0 + 2 * kKS * 2;
+    constexpr int GB2 = GA + NTW * 3 * 4;
+    constexpr int GB1 = GB2 + NTW * 3 * 4;
+    constexpr int GH = GB1 + NTW * NTW * 4;              // end of the pipelined segment, rgb head
+    static_assert(GH % kChunkGroups == 0 || GH % kChunkGroups + 4 <= kChunkGroups, "rgb head straddles a chunk");
 
     // ---- the wave's only global loads: its feature values and the ray's direction tile
     float fv[kKS][8];
@@ -108,19 +131,14 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     ws.issue(0);
     ws.sync();
     if (kChunkGroups < GH + kTailGroups) ws.piece_unchecked(1, 0);   // the rest of chunk 1 rides on pipe_fetch
-    static_assert(GH % kChunkGroups == 0 || GH % kChunkGroups + 4 <= kChunkGroups, "rgb head straddles a chunk");
 
-    // ---- accumulators of both density layers start from their biases (chunk 0 is resident now)
-    f32x16 acc0[2], x[NTB];
+    // ---- density layer 0: F -> 64, ReLU (accumulators start from the bias tiles; chunk 0 is resident)
+    f32x16 acc0[2];
     bias_tile_h(0, acc0[0], h, ws);
     bias_tile_h(1, acc0[1], h, ws);
-#pragma unroll
-    for (int t = 0; t < NTB; t++) bias_tile_h(2 + t, x[t], h, ws);
     APipe p;
     pipe_prime(G0, GH, p, ws);
-
-    // ---- density layer 0: F -> 64, ReLU
-    HTile h0[2];
+    HTile in[3];                                         // h0 (2 tiles) and the direction tile
     {
         h8 fhi[kKS], flo[kKS];
 #pragma unroll
@@ -129,37 +147,43 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
         for (int s = 0; s < kKS; s++) dstep_h(G0 + 4 * s, GH, acc0[0], acc0[1], fhi[s], flo[s], p, ws);
         relu_tile(acc0[0]);
         relu_tile(acc0[1]);
-        split_tile(acc0[0], h0[0]);
-        split_tile(acc0[1], h0[1]);
     }
-
-    // ---- density layer 1: 64 -> NB, no activation; x[0] is the raw density (models.py:508,581)
-    chain_h<NTB, 2>(G1, GH, x, h0, p, ws);
-    if (live && h == 0) a.density[oi] = softplus(x[0][0] + a.density_bias);
-    if (a.bott && live) {
+    // ---- raw density = row 0 of the second density layer, on the VALU (models.py:508,581): this lane holds
+    //      32 of the 64 hidden units of its sample
+    {
+        const float *pd = ws.group_ptr(0) + 64;
+        float part = 0.0f;
 #pragma unroll
-        for (int t = 0; t < NTB; t++)
+        for (int it = 0; it < 2; it++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) a.bott[(size_t)oi * (NTB * 32) + acc_row(t, r, h)] = x[t][r];
+            for (int r = 0; r < 16; r++) part = fmaf(acc0[it][r], pd[(it * 16 + r) * 2 + h], part);
+        const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
+        if (live && h == 0) a.density[oi] = softplus(raw + a.density_bias);
     }
     if (a.rgb == nullptr) {                       // density-only query: uniform over the grid
         ws.drain();                               // retire the in-flight weight DMA before exit
         __syncthreads();
         return;
     }
-    HTile xin[NTB + 1];
-#pragma unroll
-    for (int t = 0; t < NTB; t++) split_tile(x[t], xin[t]);
-    split_tile(ev, xin[NTB]);
+    split_tile(acc0[0], in[0]);
+    split_tile(acc0[1], in[1]);
+    split_tile(ev, in[2]);
 
-    // ---- colour layers
-    f32x16 h2[NTW];
+    // ---- composed colour layer 0 and the skip part of layer 1: both read only `in`
+    f32x16 h1[NTW], h2[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) h2[t][r] = 0.0f;     // b_c1 rides in the direction tile's slot 27
-    chain_h<NTW, NTB + 1>(G2, GH, h2, xin, p, ws);
-    hidden_tiles_h<0, NTB, NTW>(G3, GH, h2, xin, p, ws);
+        for (int r = 0; r < 16; r++) h1[t][r] = h2[t][r] = 0.0f;     // biases ride in the direction tile's slot 27
+    chain_h<NTW, 3>(GA, GH, h1, in, p, ws);
+    chain_h<NTW, 3>(GB2, GH, h2, in, p, ws);
+    HTile h1s[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        relu_tile(h1[t]);
+        split_tile(h1[t], h1s[t]);
+    }
+    chain_h<NTW, NTW>(GB1, GH, h2, h1s, p, ws);
 
     // ---- rgb head NW -> 3 on the VALU, weights broadcast from the stream's tail (models.py:657-674)
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -197,37 +221,34 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
 int ucn_h_pack(const ucn_field_t *f, const PackPlan &pl, hipStream_t st) {
     const uint32_t NB = f->n_bottleneck, NW = f->n_width, ND = f->n_dir;
     float *base = f->packed + pl.pstream;
+    float *MA = f->packed + pl.pcomp, *MB = MA + (size_t)NW * kCompCols;
     const uint64_t n_floats = (uint64_t)pl.n_groups * 256;
     hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up(n_floats, 256)), dim3(256), 0, st, base, (uint32_t)n_floats);
+    // composed matrices (fp32, double-accumulated)
+    const dim3 cg(ucn_div_up((uint64_t)NW * kCompCols, 256));
+    hipLaunchKernelGGL(k_compose, cg, dim3(256), 0, st, f->w_c0, NB + ND, 0u, f->b_c0, f->w_d1, f->b_d1, NB, ND, NW, MA);
+    hipLaunchKernelGGL(k_compose, cg, dim3(256), 0, st, f->w_c1, NW + NB + ND, NW, f->b_c1, f->w_d1, f->b_d1, NB, ND, NW, MB);
     uint64_t g = 0;                                                     // position in groups
-    auto chainpack = [&](const float *W, uint32_t ld, uint32_t col0, uint32_t row_tile0, uint32_t nto, uint32_t nti,
-                         const float *bias) {
+    auto chainpack = [&](const float *W, uint32_t ld, uint32_t col0, uint32_t nto, uint32_t nti) {
         hipLaunchKernelGGL(k_pack_chain_h, dim3(ucn_div_up((uint64_t)nto * nti * 2048, 256)), dim3(256), 0, st, W, ld,
-                           col0, row_tile0, nto, nti, bias, reinterpret_cast<_Float16 *>(base + g * 256));
+                           col0, 0u, nto, nti, (const float *)nullptr, reinterpret_cast<_Float16 *>(base + g * 256));
         g += (uint64_t)nto * nti * 4;
     };
-    // bias tiles
+    // bias tiles + density head
     hipLaunchKernelGGL(k_pack_bias_h, dim3(1), dim3(256), 0, st, f->b_d0, 2u, base);
-    hipLaunchKernelGGL(k_pack_bias_h, dim3(ucn_div_up(pl.NTB * 32, 256)), dim3(256), 0, st, f->b_d1, pl.NTB, base + 64);
+    hipLaunchKernelGGL(k_pack_density_head, dim3(1), dim3(64), 0, st, f->w_d1, f->b_d1, base);
     g += 2;
     // S0
     hipLaunchKernelGGL(k_pack_first_h, dim3(ucn_div_up(2ull * kFirstSteps * 1024, 256)), dim3(256), 0, st, f->w_d0, pl.F,
                        kFirstSteps, reinterpret_cast<_Float16 *>(base + g * 256));
     g += 2 * kFirstSteps * 2;
-    // S1
-    chainpack(f->w_d1, 64, 0, 0, pl.NTB, 2, nullptr);
-    // S2: x columns, then the direction columns + bias column (col == ld) + zeros
-    chainpack(f->w_c1, NW + NB + ND, NW, 0, pl.NTW, pl.NTB + 1, f->b_c1);
-    // S3
-    for (uint32_t t = 0; t < pl.NTW; t += 2) {
-        chainpack(f->w_c0, NB + ND, 0, t, 2, pl.NTB + 1, f->b_c0);
-        chainpack(f->w_c1, NW + NB + ND, 32 * t, 0, pl.NTW, 2, nullptr);
-    }
-    // S4
+    chainpack(MA, kCompCols, 0, pl.NTW, 3);                              // A
+    chainpack(MB, kCompCols, 0, pl.NTW, 3);                              // B2
+    chainpack(f->w_c1, NW + NB + ND, 0, pl.NTW, pl.NTW);                 // B1
     hipLaunchKernelGGL(k_pack_head, dim3(ucn_div_up((uint64_t)NW * 4, 256)), dim3(256), 0, st, f->w_rgb, NW, 0u, NW, 3u,
                        4u, base + g * 256);
     g += 4;
-    UCN_REQUIRE(g == stream_groups_h(pl.NTB, pl.NTW), "field_pack: internal stream length mismatch (%llu)", (unsigned long long)g);
+    UCN_REQUIRE(g == stream_groups_h(pl.NTW), "field_pack: internal stream length mismatch (%llu)", (unsigned long long)g);
     UCN_LAUNCH_CHECK("field_pack (split-f16)");
     return 0;
 }
@@ -239,9 +260,10 @@ int ucn_h_dir_enc(const ucn_field_t *f, const float *viewdirs, uint32_t N, float
 }
 
 int ucn_h_launch(const PackPlan &pl, const MlpArgs &a, dim3 grid, hipStream_t st) {
+    UCN_REQUIRE(a.bott == nullptr, "field_mlp: mlp_mode 1 composes the bottleneck away; request bottleneck_out with mlp_mode 0");
     const size_t lds = 2 * kChunkGroups * 256 * sizeof(float);
-    if (pl.NTB == 8) hipLaunchKernelGGL((k_field_mlp_h<8, 8>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_field_mlp_h<2, 2>), grid, dim3(256), lds, st, a);
+    if (pl.NTW == 8) hipLaunchKernelGGL((k_field_mlp_h<8>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_field_mlp_h<2>), grid, dim3(256), lds, st, a);
     UCN_LAUNCH_CHECK("field_mlp (split-f16)");
     return 0;
 }

@@ -4,7 +4,7 @@
 #include "mfma_chain.h"
 
 struct PackPlan {
-    uint64_t p0, pstream, phead, total;               // float offsets into ucn_field_t::packed
+    uint64_t p0, pstream, phead, pcomp, total;        // float offsets into ucn_field_t::packed
     uint32_t F, KQ, NTB, NTW, n_groups;               // n_groups: weight-stream length of the ACTIVE mode
     bool prop;
 };
@@ -13,12 +13,13 @@ struct PackPlan {
 static inline uint32_t stream_groups_f32(uint32_t NTB, uint32_t NTW) {
     return NTB * 2 * 4 + NTW * NTB * 4 + NTW * (NTB * 4 + NTW * 4);
 }
-// split-f16 stream (field_mlp_h.hip): 2 groups of bias tiles, first layer (2 out tiles x kFirstSteps
-// k-steps), S1 over 2 input tiles, S2/S3 over NTB activation tiles + 1 direction/bias tile, then 4 groups
-// of rgb-head weights
+// split-f16 stream (field_mlp_h.hip): 2 groups of bias tiles + density head, first layer (2 out tiles x
+// kFirstSteps k-steps), the two composed 96-input layers (3 input tiles each), colour layer 1 from the
+// hidden layer, then 4 groups of rgb-head weights
 constexpr uint32_t kFirstSteps = 4;                   // first layer: F <= 16*kFirstSteps inputs (zero padded)
-static inline uint32_t stream_groups_h(uint32_t NTB, uint32_t NTW) {
-    return (2 + 2 * kFirstSteps * 2) + NTB * 2 * 4 + NTW * (NTB + 1) * 4 + NTW * ((NTB + 1) * 4 + NTW * 4) + 4;
+constexpr uint32_t kCompCols = 96;                    // composed layers: [64 hidden | 27 direction | bias | 0...]
+static inline uint32_t stream_groups_h(uint32_t NTW) {
+    return (2 + 2 * kFirstSteps * 2) + 2 * NTW * 3 * 4 + NTW * NTW * 4 + 4;
 }
 
 static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
@@ -38,6 +39,7 @@ static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
         pl->n_groups = 0;
         pl->pstream = o;
         pl->phead = o; o += 64;
+        pl->pcomp = o;
     } else {
         UCN_REQUIRE((f->n_bottleneck == 256 && f->n_width == 256) || (f->n_bottleneck == 64 && f->n_width == 64),
                     "field: supported (bottleneck_width, net_width_viewdirs) are (256,256) and (64,64), got (%u,%u)",
@@ -49,10 +51,11 @@ static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
         pl->NTB = f->n_bottleneck / 32;
         pl->NTW = f->n_width / 32;
         const uint32_t g0 = (stream_groups_f32(pl->NTB, pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
-        const uint32_t g1 = (stream_groups_h(pl->NTB, pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
+        const uint32_t g1 = (stream_groups_h(pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
         pl->n_groups = f->mlp_mode == 1 ? g1 : g0;
         pl->pstream = o; o += (uint64_t)(g0 > g1 ? g0 : g1) * 256;
         pl->phead = o; o += (uint64_t)pl->NTW * 128;
+        pl->pcomp = o; o += 2ull * f->n_width * kCompCols;             // composed fp32 matrices (mode 1)
     }
     pl->total = o;
     return 0;

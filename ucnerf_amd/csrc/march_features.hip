@@ -138,6 +138,52 @@ __device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float
     }
 }
 
+// Fine hashed levels, C = 2, power-of-two table: the kernel is bound by the L2 request rate there (one
+// request per gathered corner, ~16 per clock per XCD), so corners that are adjacent in memory are fetched
+// together.  For an even lattice x the corners (x, y, z) and (x+1, y, z) hash to rows r and r^1 -- one
+// aligned 16-byte pair; for an odd x they are unrelated and cost two requests.  6 requests per point on
+// average instead of 8.  Same values, same fmaf order as level_accumulate.
+__device__ __forceinline__ void level_accumulate_pairs(const UcnLevel &lv, const float *__restrict__ tab,
+                                                       const float (&u)[6][3], const float (&rs)[6], float (&acc)[2]) {
+    acc[0] = acc[1] = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            float fx, fy, fz, w[8];
+            uint32_t rows[8];
+            corner_rows<true, true>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+            const bool even = ((rows[0] ^ rows[1]) == 1u);          // x0 even <=> the two rows differ in bit 0 only
+            float v[8][2];
+            if (even) {                                             // one divergent branch per point
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {                  // (y, z) choice; corners 2q (x0) and 2q+1 (x0+1)
+                    const uint32_t r0 = rows[2 * q];
+                    const float4 t = *reinterpret_cast<const float4 *>(tab + (size_t)(r0 & ~1u) * 2);
+                    const bool hi = (r0 & 1u) != 0u;
+                    v[2 * q][0] = hi ? t.z : t.x; v[2 * q][1] = hi ? t.w : t.y;
+                    v[2 * q + 1][0] = hi ? t.x : t.z; v[2 * q + 1][1] = hi ? t.y : t.w;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const float2 t = *reinterpret_cast<const float2 *>(tab + (size_t)rows[k] * 2);
+                    v[k][0] = t.x; v[k][1] = t.y;
+                }
+            }
+            corner_weights(fx, fy, fz, w);
+            float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                f0 = fmaf(w[k], v[k][0], f0);
+                f1 = fmaf(w[k], v[k][1], f1);
+            }
+            const float damp = erf_pos(rs[j] * lv.inv_gs);
+            acc[0] += f0 * damp;
+            acc[1] += f1 * damp;
+        }
+    }
+}
+
 // Backward of level_accumulate w.r.t. the table: grad_table[row_k] += w_k * damp_j * g
 // (gridencoder.cu:304-339 composed with models.py:495-496).  When all multisamples of the sample share
 // one lattice cell (coarse levels) their corner weights are summed first: 8*C atomics instead of 48*C
@@ -253,8 +299,14 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
         float acc[C];
         // wave-uniform dispatch on the level's addressing mode (lv lives in SGPRs)
         if (lv.hashed) {
-            if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
-            else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
+            if constexpr (C == 2) {
+                if (lv.mask && lv.resolution > 2048u && G == 6) level_accumulate_pairs(lv, tab, u, rs, acc);
+                else if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
+                else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
+            } else {
+                if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
+                else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
+            }
         } else {
             if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
             else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);

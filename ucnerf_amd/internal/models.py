@@ -205,6 +205,13 @@ class MLP(nn.Module):
                     normals_pred=None, roughness=None)
 
     def _evaluate(self, means, stds, viewdirs, no_warp, want_x):
+        if want_x and self.mlp_mode != 0 and not self.disable_rgb:
+            # the split-f16 kernel composes the bottleneck away; the API that returns it uses the fp32 kernel
+            mode, self.mlp_mode = self.mlp_mode, 0
+            try:
+                return self._evaluate(means, stds, viewdirs, no_warp, want_x)
+            finally:
+                self.mlp_mode = mode
         lib = _lib.load()
         _lib.require_device(means, "means")
         prefix = means.shape[:-2]
