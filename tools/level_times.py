@@ -3,6 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from ucnerf_amd import _lib
+if os.environ.get("UCN_TOOL_LIB"):               # experiment builds (tools/build_exp.sh); the product loads the in-tree library
+    _lib.LIB_PATH = os.path.abspath(os.environ["UCN_TOOL_LIB"])
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 model, cfg, sd = bench.build_model(dev)

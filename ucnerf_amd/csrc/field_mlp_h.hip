@@ -137,14 +137,13 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     bias_tile_h(0, acc0[0], h, ws);
     bias_tile_h(1, acc0[1], h, ws);
     APipe p;
-    pipe_prime(G0, GH, p, ws);
+    pipe_prime<G0, GH>(p, ws);
     HTile in[3];                                         // h0 (2 tiles) and the direction tile
     {
         h8 fhi[kKS], flo[kKS];
 #pragma unroll
         for (int s = 0; s < kKS; s++) split8(fv[s], fhi[s], flo[s]);
-#pragma unroll
-        for (int s = 0; s < kKS; s++) dstep_h(G0 + 4 * s, GH, acc0[0], acc0[1], fhi[s], flo[s], p, ws);
+        static_for<kKS>([&](auto s) { dstep_h<G0 + 4 * s.value, GH>(acc0[0], acc0[1], fhi[s.value], flo[s.value], p, ws); });
         relu_tile(acc0[0]);
         relu_tile(acc0[1]);
     }
@@ -175,15 +174,19 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     for (int t = 0; t < NTW; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) h1[t][r] = h2[t][r] = 0.0f;     // biases ride in the direction tile's slot 27
-    chain_h<NTW, 3>(GA, GH, h1, in, p, ws);
-    chain_h<NTW, 3>(GB2, GH, h2, in, p, ws);
+    chain_h<NTW, 3, GA, GH>(h1, in, p, ws);
+    // B2 does not depend on h1: the ReLU + hi/lo split of h1 (2*NTW half tiles of ~40 VALU instructions)
+    // rides in the MFMA shadow of B2's first 2*NTW double steps
     HTile h1s[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; t++) {
-        relu_tile(h1[t]);
-        split_tile(h1[t], h1s[t]);
-    }
-    chain_h<NTW, NTW>(GB1, GH, h2, h1s, p, ws);
+    static_for<NTW / 2 * 6>([&](auto ic) {                   // [otp][it < 3][s]
+        constexpr int i = ic.value, otp = i / 6, it = (i % 6) / 2, s = i % 2;
+        if constexpr (i < 2 * NTW)
+            dstep_h_with<GB2 + 4 * i, GH>(h2[2 * otp], h2[2 * otp + 1], in[it].hi[s], in[it].lo[s], p, ws,
+                                          [&] { relu_split_half(h1[i / 2], i % 2, h1s[i / 2]); });
+        else
+            dstep_h<GB2 + 4 * i, GH>(h2[2 * otp], h2[2 * otp + 1], in[it].hi[s], in[it].lo[s], p, ws);
+    });
+    chain_h<NTW, NTW, GB1, GH>(h2, h1s, p, ws);
 
     // ---- rgb head NW -> 3 on the VALU, weights broadcast from the stream's tail (models.py:657-674)
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;

@@ -126,8 +126,6 @@ struct WeightStream {
     __device__ __forceinline__ const float *group_ptr(int g) const {   // g = index in the whole stream
         return lds + ((g / kChunkGroups) & 1) * kChunkGroups * 256 + (g % kChunkGroups) * 256;
     }
-    // two per-lane base addresses (one per buffer) + an immediate offset < 64 KiB: ds_read_b128's offset
-    // field is 16 bits, so a single base would need a separate address register for every group of buffer 1
     __device__ __forceinline__ float4 group(int g) const {
         const float *b0 = lds + lane * 4, *b1 = lds + kChunkGroups * 256 + lane * 4;
         const float *l = ((g / kChunkGroups) & 1) ? b1 : b0;

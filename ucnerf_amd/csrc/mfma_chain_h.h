@@ -15,11 +15,19 @@
 // 16 k's of a step are the rows (r&3)+8(r>>2)+4g -- a fixed permutation that the packers apply to
 // the weight columns.  Stream: a PAIR of 1 KiB groups [hi][lo] per (out tile, in tile, s).
 //
-// With one wave per SIMD nothing but the wave's own instruction stream hides latency, so the steady
-// state has NO global loads (biases ride in the weight stream: either as broadcast bias tiles at its
-// head or as the weight column that multiplies a constant-1 input) and the A operands are requested
-// from LDS kDepth steps ahead of their MFMAs (APipe), across layer boundaries as well.
+// With one wave per SIMD nothing but the wave's own instruction stream hides latency, and every
+// instruction between two MFMAs costs issue time.  Hence:
+//   * the steady state has NO global loads (biases ride in the weight stream: as broadcast bias tiles at
+//     its head or as the weight column that multiplies a constant-1 input);
+//   * A operands are requested from LDS kDepth pairs ahead of their MFMAs (APipe), across layer boundaries;
+//   * stream positions are TEMPLATE arguments: one s_waitcnt lgkmcnt per double step with a compile-time
+//     count (a hint on top of the compiler's own tracking of the reads), ring slots and chunk boundaries
+//     resolved at compile time, and the L2 -> LDS DMA of the next chunk spread over the steps.
+//     (Hand-written ds_read_b128 with immediate offsets were tried and returned wrong data; the compiler's
+//     loads are just as fast here.)
 #pragma once
+#include <utility>
+
 #include "mfma_chain.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -31,6 +39,16 @@ constexpr int kDepth = 6;   // A-operand pairs in flight: pair i + kDepth is req
 struct APipe {              // ring of A operands, slot = (pair index) % kDepth
     h8 hi[kDepth], lo[kDepth];
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 __device__ __forceinline__ f32x16 mfma16h(h8 a, h8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -53,75 +71,103 @@ __device__ __forceinline__ void split_tile(const f32x16 &a, HTile &t) {
         split8(v, t.hi[s], t.lo[s]);
     }
 }
-
-__device__ __forceinline__ h8 group_h(const WeightStream &ws, int g) {
-    const float4 v = ws.group(g);
-    return __builtin_bit_cast(h8, v);
+// ReLU + split of the 8 accumulator registers that form k-step s of a tile
+__device__ __forceinline__ void relu_split_half(const f32x16 &a, const int s, HTile &t) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = fmaxf(a[8 * s + e], 0.0f);
+    split8(v, t.hi[s], t.lo[s]);
 }
-// request pair g (even group index) into its ring slot.  The DMA of the NEXT chunk is spread over this
+
+// lgkmcnt-only wait (vmcnt = 63, expcnt = 7 left alone)
+template <int N>
+__device__ __forceinline__ void wait_lds() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+}
+
+// Request pair G (even group index) into its ring slot.  The DMA of the NEXT chunk is spread over this
 // chunk's requests, one piece per 4 groups: issued as a burst of 16 behind the barrier, the pieces cost
 // the issuing (= computing) wave 100-185 cycles each while the address queue is full of them.
 // (piece 0 of chunk 1 is the kernel's job: group 0 holds the biases and is never requested here)
 // GEND = end of the pipelined segment; the stream carries kTailGroups more groups behind it, so chunk
-// c exists iff c * kChunkGroups < GEND + kTailGroups -- a compile-time fact at every call site.
+// c exists iff c * kChunkGroups < GEND + kTailGroups.
 constexpr int kTailGroups = 4;
-__device__ __forceinline__ void pipe_fetch(const int g, const int GEND, APipe &p, WeightStream &ws) {
-    if (g % kChunkGroups == 0) ws.sync();
-    if (g % 4 == 0 && (g / kChunkGroups + 1) * kChunkGroups < GEND + kTailGroups)
-        ws.piece_unchecked(g / kChunkGroups + 1, (g % kChunkGroups) / 4);
-    p.hi[(g / 2) % kDepth] = group_h(ws, g);
-    p.lo[(g / 2) % kDepth] = group_h(ws, g + 1);
+template <int G, int GEND>
+__device__ __forceinline__ void pipe_fetch(APipe &p, WeightStream &ws) {
+    if constexpr (G % kChunkGroups == 0) ws.sync();
+    if constexpr (G % 4 == 0 && (G / kChunkGroups + 1) * kChunkGroups < GEND + kTailGroups)
+        ws.piece_unchecked(G / kChunkGroups + 1, (G % kChunkGroups) / 4);
+    p.hi[(G / 2) % kDepth] = __builtin_bit_cast(h8, ws.group(G));
+    p.lo[(G / 2) % kDepth] = __builtin_bit_cast(h8, ws.group(G + 1));
 }
-// start of a pipelined segment [G0, GEND)
-__device__ __forceinline__ void pipe_prime(const int G0, const int GEND, APipe &p, WeightStream &ws) {
-#pragma unroll
-    for (int d = 0; d < kDepth; d++)
-        if (G0 + 2 * d < GEND) pipe_fetch(G0 + 2 * d, GEND, p, ws);
+// reads still in flight that are YOUNGER than the four operands of the double step at G, once everything up to
+// `fetched` (exclusive, group index) has been requested
+template <int G, int FETCHED>
+constexpr int younger_reads() { return FETCHED - (G + 4) > 0 ? FETCHED - (G + 4) : 0; }
+constexpr int imin(int a, int b) { return a < b ? a : b; }
+
+// start of a pipelined segment [G0, GEND): kDepth pairs in flight, the first double step's operands landed
+template <int G0, int GEND>
+__device__ __forceinline__ void pipe_prime(APipe &p, WeightStream &ws) {
+    static_for<kDepth>([&](auto d) {
+        if constexpr (G0 + 2 * d.value < GEND) pipe_fetch<G0 + 2 * d.value, GEND>(p, ws);
+    });
+    wait_lds<younger_reads<G0, imin(GEND, G0 + 2 * kDepth)>()>();
 }
-// One double step: two OUTPUT tiles (A pairs g and g+2) against the same 16 k's of the input,
-//   acc0 += A(g) . B,  acc1 += A(g+2) . B,
+
+// One double step: two OUTPUT tiles (A pairs G and G+2) against the same 16 k's of the input,
+//   acc0 += A(G) . B,  acc1 += A(G+2) . B,
 // six MFMAs alternating between the two accumulators, then the two pairs kDepth ahead are requested
-// into the slots just consumed.  The alternation is the point: an MFMA that accumulates into the
-// register block the previous MFMA is still writing does not issue back to back -- a chain of 54
-// dependent v_mfma_f32_32x32x16_f16 with ds_reads/waitcnts between them measured 67 cycles per MFMA
-// instead of 32 (MI355X_MICROARCH.md: "+43 cyc for the first extra state between two MFMAs on the
-// SAME accumulator").  With two accumulators every MFMA's predecessor on its own block is 64 cycles old.
-__device__ __forceinline__ void dstep_h(const int g, const int GEND, f32x16 &acc0, f32x16 &acc1, const h8 bhi,
-                                        const h8 blo, APipe &p, WeightStream &ws) {
-    const int s0 = (g / 2) % kDepth, s1 = (g / 2 + 1) % kDepth;
+// into the slots just consumed, then ONE wait for the next double step's four operands.  The alternation
+// matters: an MFMA that accumulates into the register block the previous MFMA is still writing does not
+// issue back to back (MI355X_MICROARCH.md: "+43 cyc for the first extra state between two MFMAs on the
+// SAME accumulator").  `valu_work` is independent VALU work (~40 instructions) that rides in the shadow
+// of the six MFMAs: the sched_group_barriers ask for 1 MFMA, 7 VALU, 1 MFMA, 7 VALU ... so that each
+// 32-cycle MFMA covers 28 cycles of VALU issue instead of the VALU phase idling the matrix pipe.
+template <int G, int GEND, bool WITH_VALU, class F>
+__device__ __forceinline__ void dstep_impl(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, APipe &p,
+                                           WeightStream &ws, F &&valu_work) {
+    constexpr int s0 = (G / 2) % kDepth, s1 = (G / 2 + 1) % kDepth;
     acc0 = mfma16h(p.hi[s0], bhi, acc0);
     acc1 = mfma16h(p.hi[s1], bhi, acc1);
     acc0 = mfma16h(p.hi[s0], blo, acc0);
     acc1 = mfma16h(p.hi[s1], blo, acc1);
     acc0 = mfma16h(p.lo[s0], bhi, acc0);
     acc1 = mfma16h(p.lo[s1], bhi, acc1);
-    if (g + 2 * kDepth < GEND) pipe_fetch(g + 2 * kDepth, GEND, p, ws);
-    if (g + 2 * kDepth + 2 < GEND) pipe_fetch(g + 2 * kDepth + 2, GEND, p, ws);
-    // one wait for the NEXT step's four operands (the oldest of the 2*kDepth reads now in flight) instead
-    // of the compiler's one-per-first-use: every instruction between two MFMAs costs issue time here
-    __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * kDepth - 4) << 8));
+    if constexpr (WITH_VALU) {
+        valu_work();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // VALU
+        }
+    }
+    if constexpr (G + 2 * kDepth < GEND) pipe_fetch<G + 2 * kDepth, GEND>(p, ws);
+    if constexpr (G + 2 * kDepth + 2 < GEND) pipe_fetch<G + 2 * kDepth + 2, GEND>(p, ws);
+    if constexpr (G + 4 < GEND) wait_lds<younger_reads<G + 4, imin(GEND, G + 2 * kDepth + 4)>()>();
     __builtin_amdgcn_sched_barrier(0);   // keep each step's MFMAs and its requests together, in program order
 }
+template <int G, int GEND>
+__device__ __forceinline__ void dstep_h(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, APipe &p, WeightStream &ws) {
+    dstep_impl<G, GEND, false>(acc0, acc1, bhi, blo, p, ws, [] {});
+}
+template <int G, int GEND, class F>
+__device__ __forceinline__ void dstep_h_with(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, APipe &p,
+                                             WeightStream &ws, F &&valu_work) {
+    dstep_impl<G, GEND, true>(acc0, acc1, bhi, blo, p, ws, valu_work);
+}
 
-// Two output tiles from NT_IN input tiles; pairs [it][s][o2] start at stream position G0.  Loops stay
-// <= 32 iterations so that hipcc unrolls them completely (see mfma_chain.h).
-template <int NT_IN>
-__device__ __forceinline__ void chain_two_h(const int G0, const int GEND, f32x16 &acc0, f32x16 &acc1,
-                                            const HTile (&in)[NT_IN], APipe &p, WeightStream &ws) {
-#pragma unroll
-    for (int i = 0; i < NT_IN * 2; i++) dstep_h(G0 + 4 * i, GEND, acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ws);
-}
-template <int OTP, int NT_OUT, int NT_IN>
-__device__ __forceinline__ void chain_rec_h(const int G0, const int GEND, f32x16 (&acc)[NT_OUT], const HTile (&in)[NT_IN],
-                                            APipe &p, WeightStream &ws) {
-    chain_two_h<NT_IN>(G0 + OTP * NT_IN * 8, GEND, acc[2 * OTP], acc[2 * OTP + 1], in, p, ws);
-    if constexpr (2 * OTP + 2 < NT_OUT) chain_rec_h<OTP + 1, NT_OUT, NT_IN>(G0, GEND, acc, in, p, ws);
-}
-// all NT_OUT x NT_IN tiles (NT_OUT even), order [ot pair][it][s][o2]
-template <int NT_OUT, int NT_IN>
-__device__ __forceinline__ void chain_h(const int G0, const int GEND, f32x16 (&acc)[NT_OUT], const HTile (&in)[NT_IN],
-                                        APipe &p, WeightStream &ws) {
-    chain_rec_h<0, NT_OUT, NT_IN>(G0, GEND, acc, in, p, ws);
+// all NT_OUT x NT_IN tiles (NT_OUT even), stream order [ot pair][it][s][o2] from G0
+template <int NT_OUT, int NT_IN, int G0, int GEND>
+__device__ __forceinline__ void chain_h(f32x16 (&acc)[NT_OUT], const HTile (&in)[NT_IN], APipe &p, WeightStream &ws) {
+    static_for<NT_OUT / 2>([&](auto otp) {
+        static_for<NT_IN * 2>([&](auto i) {
+            dstep_h<G0 + (otp.value * NT_IN * 2 + i.value) * 4, GEND>(acc[2 * otp.value], acc[2 * otp.value + 1],
+                                                                      in[i.value / 2].hi[i.value % 2],
+                                                                      in[i.value / 2].lo[i.value % 2], p, ws);
+        });
+    });
 }
 
 // Broadcast biases: groups 0..1 of the stream hold floats [tile < 16][h][16] = bias[acc_row(tile, r, h)]
@@ -139,7 +185,7 @@ __device__ __forceinline__ void bias_tile_h(int tile, f32x16 &acc, int h, const 
 // Weight pairs: dst halfs
 //   [(((otp*n_in + it)*2 + s)*2 + o2)*2 + part][lane][e] =
 //        part(V[32(row_tile0 + 2otp + o2) + (lane&31)][col0 + 32it + perm(8s+e, lane>>5)])
-// (output tiles go in PAIRS, the pair innermost: see dstep_h; nt_out must be even)
+// (output tiles go in PAIRS, the pair innermost: see dstep_impl; nt_out must be even)
 // with perm(r, g) = (r&3) + 8(r>>2) + 4g, part 0 = f16(v), part 1 = f16(v - f16(v)), and
 //   V[row][col] = W[row][col] for col < ld;  bias[row] for col == ld (if bias);  0 beyond
 // (col == ld is the slot of the constant-1 input that follows the layer's real inputs).
