@@ -2,55 +2,97 @@
 //
 // Replaces models.py:326-337 (call), :852-904 (render_rays), :822-850 (raw2outputs) and
 // :743-820 (NeRF, D=8, W=256, skips=[4], multires_view=4) of /root/reference/nerf/internal/models.py.
-// 562,688 MAC per sample x 120 samples: the largest FLOP term of the path when model_sky is on, so
-// it runs on the same register-chained fp32 MFMA engine as the field MLP (mfma_chain.h): a wave
-// owns 32 samples, the eight 256-wide layers ping-pong between two 128-register tile sets, the
-// 3-d input layers and the 1/3-wide heads stay on the VALU, weights stream once per workgroup
-// through LDS.  The 27-d view encoding is per RAY (it encodes cam_dirs, models.py:331,866): its
-// product with views_linears is folded into a per-ray bias.
+// 562,688 MAC per sample x 120 samples: the largest FLOP term of the path when model_sky is on.
+//
+// It runs on the split-f16 MFMA engine (mfma_chain_h.h: fp32-class products as 3 f16 MFMAs, fp32
+// accumulation), as ONE software-pipelined sequence of "pair chains": a wave owns 32 samples; a pair
+// chain produces two 32-neuron output tiles of a layer from the layer's input tiles (16 or 18 double
+// steps of six MFMAs), and carries in the MFMA shadow of its first four double steps the ReLU + hi/lo
+// split of the PREVIOUS pair's accumulators into the other activation buffer (XA <-> XB ping-pong), so
+// the matrix pipe never waits for an activation pass.  Weights stream L2 -> LDS once per workgroup.
+//   * feature_linear (256 -> 256, no activation) feeds only views_linears.0 and is composed into it at
+//     pack time: W_view[:, :256] W_feat (128 x 256), like the field MLP's bottleneck (field_mlp_h.hip);
+//   * one auxiliary input tile per sample [px, py, pz, 1, embed(cam_dir) (27), 0] carries the skip
+//     connection's point (layer 5), the view encoding (views layer) and, through the constant 1, the
+//     biases of those two layers; the other layers' biases, the 3-wide input layer and the 1/3-wide heads
+//     live in a 14 KiB side table that stays in LDS next to the weight double buffer (VALU work).
 //
 // Reference quirks kept: z = near(1-t) + t/far with near = batch.far and
 // far = 1.5*near[0], i.e. z DEcreases; the last interval is 1e10; 1e-10 is added inside the
 // transmittance product.
-//
-// Weight stream: pts_linears.1..7 ([ot<8][it<8][r4] each; layer 5 reads columns 3..258),
-// feature_linear (same shape), views_linears.0 ([ot<4][it<8][r4], columns 0..255).
-#include "mfma_chain.h"
+#include "mfma_chain_h.h"
 
 namespace {
 
 constexpr int kSkySamples = 120;
-constexpr uint64_t kSkyStreamGroups = 7 * 256 + 256 + 128;             // 2176 = 68 chunks
-constexpr uint64_t kOffIn0 = kSkyStreamGroups * 256;                    // {w0,w1,w2,b} of pts_linears.0
-constexpr uint64_t kOffIn5 = kOffIn0 + 1024;                            // {w0,w1,w2,b} of pts_linears.5[:, :3]
-constexpr uint64_t kOffAlpha = kOffIn5 + 1024;                          // alpha_linear, 256 floats
-constexpr uint64_t kOffRgb = kOffAlpha + 256;                           // rgb_linear, 128 x float4
-constexpr uint64_t kSkyPackedFloats = kOffRgb + 512;
+// ---- weight stream (1 KiB groups, pairs [otp][it][s][o2]): pts_linears 1..4, 5 (9 input tiles), 6, 7, views (9 tiles)
+constexpr int kGL1 = 0, kGL2 = 256, kGL3 = 512, kGL4 = 768, kGL5 = 1024, kGL6 = kGL5 + 288, kGL7 = kGL6 + 256;
+constexpr int kGV = kGL7 + 256, kGEnd = kGV + 144;                       // 1968
+constexpr uint64_t kSkyStreamGroups = (kGEnd + kTailGroups + kChunkGroups - 1) / kChunkGroups * kChunkGroups;   // 1984
+// ---- side table (floats), resident in LDS behind the two stream buffers
+constexpr int kSB = 0;            // 6 x 256: biases of pts_linears 1,2,3,4,6,7 as bias tiles [t][h][16]
+constexpr int kSL0 = 1536;        // 256 x {w0,w1,w2,b} of pts_linears.0, accumulator-slot order
+constexpr int kSAlpha = 2560;     // 256 alpha_linear weights (slot order), then b_alpha
+constexpr int kSRgb = 2820;       // 128 x {w_r,w_g,w_b,0} (slot order), then b_rgb[3]
+constexpr int kSideFloats = 3584; // 14 KiB
+// ---- ucn_sky_t::packed
+constexpr uint64_t kOffSide = kSkyStreamGroups * 256;
+constexpr uint64_t kOffM5 = kOffSide + kSideFloats;                       // [256][288] composed layer 5
+constexpr uint64_t kOffMv = kOffM5 + 256 * 288;                           // [128][288] composed views layer
+constexpr uint64_t kSkyPackedFloats = kOffMv + 128 * 288;
+
+constexpr int kLayerG[7] = {kGL1, kGL2, kGL3, kGL4, kGL5, kGL6, kGL7};
+constexpr int kBiasIdx[7] = {0, 1, 2, 3, -1, 4, 5};              // side-table bias block; layer 5's bias rides in the aux tile
 
 struct SkyArgs {
     const float *packed;
-    const float *b_pts[8];
-    const float *b_alpha, *b_feat, *b_view, *b_rgb;
-    const float *view_bias;      // [N,128]
+    const float *aux;            // [N,32] per ray: [0,0,0,1, embed(cam_dir) (27), 0]
     const float *origins, *dirs, *far_, *t_vals;
     float inv_sky_far;
     uint32_t N;
     float *raw;                  // [N*120, 4] = rgb(3), sigma
 };
 
-// acc[t][r] = w0*x + w1*y + w2*z + b with {w0,w1,w2,b} float4 per accumulator slot (VALU)
-__device__ __forceinline__ void input3(f32x16 (&acc)[8], const float4 *__restrict__ p, float x, float y, float z, int h) {
+template <int P>
+__device__ __forceinline__ HTile (&pick(HTile (&a)[9], HTile (&b)[9]))[9] {
+    if constexpr (P == 0) return a;
+    else return b;
+}
+
+// One pair chain: acc pair (already initialised) += W[pair] . in, NT_IN input tiles from stream position G;
+// `carry(i)`, i < 4, is the previous pair's activation work for its i-th half tile.
+template <int G, int NT_IN, class F>
+__device__ __forceinline__ void pair_chain(f32x16 &acc0, f32x16 &acc1, const HTile (&in)[9], APipe &p, WeightStream &ws,
+                                           F &&carry) {
+    static_for<NT_IN * 2>([&](auto ic) {
+        constexpr int i = ic.value;
+        if constexpr (i < 4)
+            dstep_h_with<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ws, [&] { carry(ic); });
+        else
+            dstep_h<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ws);
+    });
+}
+
+// alpha head (256 -> 1, VALU) on the fp32 ReLU output of layer 7, taken half a tile at a time while that half is
+// being split anyway: sig += sum_e relu(acc[8S+e]) * w[slot(TILE, 8S+e)]
+template <int TILE, int S>
+__device__ __forceinline__ void alpha_partial(const f32x16 &acc, const float *__restrict__ pa_h, float &sig) {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int e = 0; e < 8; e++) sig = fmaf(fmaxf(acc[8 * S + e], 0.0f), pa_h[(TILE * 16 + 8 * S + e) * 2], sig);
+}
+
+__device__ __forceinline__ void side_bias_tile(const float *side, int off, int tile, f32x16 &acc, int h) {
+    const float4 *p = reinterpret_cast<const float4 *>(side + off + tile * 32 + h * 16);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float4 w = p[(t * 16 + r) * 2 + h];
-            acc[t][r] = ((w.x * x + w.y * y) + w.z * z) + w.w;
-        }
+    for (int r4 = 0; r4 < 4; r4++) {
+        const float4 v = p[r4];
+        acc[4 * r4 + 0] = v.x; acc[4 * r4 + 1] = v.y; acc[4 * r4 + 2] = v.z; acc[4 * r4 + 3] = v.w;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // 2 x 64 KiB stream buffers + side table
+    const float *side = s_w + 2 * kChunkGroups * 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -60,77 +102,182 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
     const uint64_t b = live ? b0 + j : B - 1;
     const uint32_t ray = (uint32_t)(b / kSkySamples), s = (uint32_t)(b - (uint64_t)ray * kSkySamples);
 
-    WeightStream ws{a.packed, s_w, lane, wave, (uint32_t)(kSkyStreamGroups / kChunkGroups)};
-    ws.issue(0);
-
+    // ---- global loads of the wave: its sample's point and the ray's auxiliary tile
     const float tv = a.t_vals[s];
     const float z = a.far_[ray] * (1.0f - tv) + a.inv_sky_far * tv;                    // models.py:872
     const float px = a.origins[ray * 3 + 0] + a.dirs[ray * 3 + 0] * z;
     const float py = a.origins[ray * 3 + 1] + a.dirs[ray * 3 + 1] * z;
     const float pz = a.origins[ray * 3 + 2] + a.dirs[ray * 3 + 2] * z;
+    f32x16 av;
+    {
+        const float4 *ap = reinterpret_cast<const float4 *>(a.aux + (size_t)ray * 32 + 4 * h);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 v = ap[2 * r4];
+            av[4 * r4 + 0] = v.x; av[4 * r4 + 1] = v.y; av[4 * r4 + 2] = v.z; av[4 * r4 + 3] = v.w;
+        }
+        if (h == 0) { av[0] = px; av[1] = py; av[2] = pz; }                             // slots k = 0,1,2 (k = 3 is the 1)
+    }
 
-    f32x16 hA[8], hB[8];
-    input3(hA, reinterpret_cast<const float4 *>(a.packed + kOffIn0), px, py, pz, h);   // layer 0
-    relu_tiles<8>(hA);
-    init_bias<8>(hB, a.b_pts[1], nullptr, h); chain<8, 8>(0 * 256, hB, hA, ws); relu_tiles<8>(hB);
-    init_bias<8>(hA, a.b_pts[2], nullptr, h); chain<8, 8>(1 * 256, hA, hB, ws); relu_tiles<8>(hA);
-    init_bias<8>(hB, a.b_pts[3], nullptr, h); chain<8, 8>(2 * 256, hB, hA, ws); relu_tiles<8>(hB);
-    init_bias<8>(hA, a.b_pts[4], nullptr, h); chain<8, 8>(3 * 256, hA, hB, ws); relu_tiles<8>(hA);
-    // layer 5 reads cat[pts, h] (skip at 4): pts columns on the VALU (bias folded), h via MFMA
-    input3(hB, reinterpret_cast<const float4 *>(a.packed + kOffIn5), px, py, pz, h);
-    chain<8, 8>(4 * 256, hB, hA, ws); relu_tiles<8>(hB);
-    init_bias<8>(hA, a.b_pts[6], nullptr, h); chain<8, 8>(5 * 256, hA, hB, ws); relu_tiles<8>(hA);
-    init_bias<8>(hB, a.b_pts[7], nullptr, h); chain<8, 8>(6 * 256, hB, hA, ws); relu_tiles<8>(hB);
-    // alpha head 256 -> 1 (VALU)
-    const float *pa = a.packed + kOffAlpha;
-    float sig = 0.0f;
+    WeightStream ws{a.packed, s_w, lane, wave, (uint32_t)(kSkyStreamGroups / kChunkGroups)};
+    ws.issue(0);
+    {   // side table: 14 pieces of 1 KiB, DMA'd once; published by the first sync of the stream
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + 2u * kChunkGroups * 1024u;
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+        for (int k = 0; k < 4; k++) {
+            const int piece = k * 4 + wave;
+            if (piece < kSideFloats / 256)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :
+                             : "s"(lside + piece * 1024u), "v"(lane * 16u), "s"(a.packed + kOffSide + piece * 256)
+                             : "memory");
+        }
+    }
+    APipe p;
+    pipe_prime<0, kGEnd>(p, ws);
+
+    // ---- layer 0 (3 -> 256) on the VALU, straight into XA
+    HTile XA[9], XB[9];
+    {
+        const float4 *p0 = reinterpret_cast<const float4 *>(side + kSL0) + h;   // lane part in the base: offsets stay immediates
 #pragma unroll
-        for (int r = 0; r < 16; r++) sig = fmaf(hB[t][r], pa[(t * 16 + r) * 2 + h], sig);
-    sig = (sig + __shfl_xor(sig, 32, 64)) + a.b_alpha[0];
-    // feature_linear 256 -> 256 (no activation)
-    init_bias<8>(hA, a.b_feat, nullptr, h); chain<8, 8>(7 * 256, hA, hB, ws);
-    // views_linears.0: [feature, enc(cam_dir)] -> 128, ReLU; the encoding part is a per-ray bias
+        for (int t = 0; t < 8; t++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float4 w = p0[(t * 16 + r) * 2];
+                acc[r] = ((w.x * px + w.y * py) + w.z * pz) + w.w;
+            }
+            relu_split_half(acc, 0, XA[t]);
+            relu_split_half(acc, 1, XA[t]);
+            __builtin_amdgcn_sched_barrier(0);          // one tile at a time: 8 tiles of float4 operands in flight spill
+        }
+        split_tile(av, XA[8]);
+        XB[8] = XA[8];
+    }
+
+    // ---- the pair-chain sequence.  Layer li (0..6 = pts_linears 1..7) reads pick<li%2>, writes pick<(li+1)%2>.
+    f32x16 cur[2], prev[2];
+    float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
+    const float *pa = side + kSAlpha + h;                         // alpha_linear weights, accumulator-slot order
+    static_for<7>([&](auto lic) {
+        constexpr int li = lic.value, NT_IN = li == 4 ? 9 : 8;
+        HTile (&in)[9] = pick<li % 2>(XA, XB);
+        HTile (&out)[9] = pick<(li + 1) % 2>(XA, XB);
+        static_for<4>([&](auto pc) {
+            constexpr int pr = pc.value;
+            if constexpr (kBiasIdx[li] >= 0) {
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr, cur[0], h);
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr + 1, cur[1], h);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) cur[0][r] = cur[1][r] = 0.0f;
+            }
+            // carry: the previous pair's ReLU + split.  For (li, pr) it is pair pr-1 of this layer (-> out), or pair 3
+            // of the previous layer (-> in, tiles 6,7: read by this chain only from double step 12 on).
+            pair_chain<kLayerG[li] + pr * NT_IN * 8, NT_IN>(cur[0], cur[1], in, p, ws, [&](auto hc) {
+                constexpr int hi = hc.value;                     // half tile 0..3 of the carried pair
+                if constexpr (pr > 0) {
+                    relu_split_half(prev[hi / 2], hi % 2, out[2 * (pr - 1) + hi / 2]);
+                    if constexpr (li == 6) alpha_partial<2 * (pr - 1) + hi / 2, hi % 2>(prev[hi / 2], pa, sig);
+                }
+                else if constexpr (li > 0) relu_split_half(prev[hi / 2], hi % 2, in[6 + hi / 2]);
+            });
+            prev[0] = cur[0];
+            prev[1] = cur[1];
+        });
+    });
+    // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = pick<1> (7 layers); the first chain carries
+    //      the split of layer 7's last pair; the alpha head (VALU, fp32 h7) rides along
+    HTile (&h7)[9] = pick<1>(XA, XB);
     f32x16 v[4];
-    init_bias<4>(v, a.b_view, a.view_bias + (size_t)ray * 128, h);
-    chain<4, 8>(8 * 256, v, hA, ws);
-    const float4 *pr = reinterpret_cast<const float4 *>(a.packed + kOffRgb);
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
+        for (int r = 0; r < 16; r++) v[t][r] = 0.0f;
+    pair_chain<kGV, 9>(v[0], v[1], h7, p, ws, [&](auto hc) {
+        constexpr int hi = hc.value;
+        relu_split_half(prev[hi / 2], hi % 2, h7[6 + hi / 2]);
+        alpha_partial<6 + hi / 2, hi % 2>(prev[hi / 2], pa, sig);
+    });
+    pair_chain<kGV + 9 * 8, 9>(v[2], v[3], h7, p, ws, [&](auto) {});
+    sig = (sig + __shfl_xor(sig, 32, 64)) + side[kSAlpha + 256];
+    const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float4 w = pr[(t * 16 + r) * 2 + h];
+            const float4 w = prgb[(t * 16 + r) * 2];
             const float x = fmaxf(v[t][r], 0.0f);
             c0 = fmaf(x, w.x, c0); c1 = fmaf(x, w.y, c1); c2 = fmaf(x, w.z, c2);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+    const float *brgb = side + kSRgb + 512;
     if (live && h == 0)
-        *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + a.b_rgb[0], c1 + a.b_rgb[1], c2 + a.b_rgb[2], sig);
+        *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);
 }
 
-// per-ray view bias: W_view[:, 256:283] . embed(cam_dir), embed = [x, sin(f x), cos(f x) for f in 1,2,4,8]
-__global__ __launch_bounds__(128) void k_sky_view_bias(const float *__restrict__ cam, const float *__restrict__ w_view,
-                                                       uint32_t N, float *__restrict__ out) {
-    __shared__ float enc[27];
-    const uint32_t ray = blockIdx.x;
-    if (threadIdx.x < 27) {
-        const uint32_t k = threadIdx.x;
-        float v;
-        if (k < 3) v = cam[ray * 3 + k];
+// per-ray auxiliary tile: [0, 0, 0, 1, embed(cam_dir) = x, sin(f x), cos(f x) for f in 1,2,4,8 (27), 0]
+__global__ __launch_bounds__(256) void k_sky_aux(const float *__restrict__ cam, uint32_t N, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= N * 32u) return;
+    const uint32_t ray = i >> 5, k = i & 31u;
+    float v = 0.0f;
+    if (k == 3u) v = 1.0f;
+    else if (k >= 4u && k < 31u) {
+        const uint32_t e = k - 4u;
+        if (e < 3u) v = cam[ray * 3 + e];
         else {
-            const uint32_t kk = k - 3, a = kk % 3, fn = (kk / 3) & 1u, fi = kk / 6;
+            const uint32_t kk = e - 3u, a = kk % 3u, fn = (kk / 3u) & 1u, fi = kk / 6u;
             const float x = cam[ray * 3 + a] * (float)(1u << fi);
             v = fn ? cosf(x) : sinf(x);
         }
-        enc[k] = v;
     }
-    __syncthreads();
-    const float *row = w_view + (size_t)threadIdx.x * 283 + 256;
-    float s = 0.0f;
-    for (int k = 0; k < 27; k++) s = fmaf(row[k], enc[k], s);
-    out[(size_t)ray * 128 + threadIdx.x] = s;
+    out[i] = v;
+}
+
+// Composed fp32 matrices behind the two 9-tile layers, columns in input-tile order [h (256) | aux (32)]:
+//   M5[j] = [W5[j, 3:259] | W5[j, 0:3] | b5[j] | 0 (28)]
+//   Mv[j] = [(W_view[:, :256] W_feat)[j] | 0,0,0 | b_view[j] + W_view[j, :256] b_feat | W_view[j, 256:283] | 0]
+__global__ __launch_bounds__(256) void k_sky_compose(const float *__restrict__ w5, const float *__restrict__ b5,
+                                                     const float *__restrict__ w_view, const float *__restrict__ b_view,
+                                                     const float *__restrict__ w_feat, const float *__restrict__ b_feat,
+                                                     float *__restrict__ M5, float *__restrict__ Mv) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 256u * 288u) {
+        const uint32_t jr = i / 288u, c = i - jr * 288u;
+        float v = 0.0f;
+        if (c < 256u) v = w5[(size_t)jr * 259 + 3 + c];
+        else if (c < 259u) v = w5[(size_t)jr * 259 + (c - 256u)];
+        else if (c == 259u) v = b5[jr];
+        M5[i] = v;
+    }
+    if (i < 128u * 288u) {
+        const uint32_t jr = i / 288u, c = i - jr * 288u;
+        const float *wr = w_view + (size_t)jr * 283;
+        float v = 0.0f;
+        if (c < 256u) {
+            double acc = 0.0;
+            for (uint32_t k = 0; k < 256u; k++) acc += (double)wr[k] * (double)w_feat[(size_t)k * 256 + c];
+            v = (float)acc;
+        } else if (c == 259u) {
+            double acc = (double)b_view[jr];
+            for (uint32_t k = 0; k < 256u; k++) acc += (double)wr[k] * (double)b_feat[k];
+            v = (float)acc;
+        } else if (c >= 260u && c < 287u) {
+            v = wr[256 + (c - 260u)];
+        }
+        Mv[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sky_side_scalars(const float *__restrict__ b_alpha, const float *__restrict__ b_rgb,
+                                                          float *__restrict__ side) {
+    if (threadIdx.x == 0) side[kSAlpha + 256] = b_alpha[0];
+    if (threadIdx.x < 3) side[kSRgb + 512 + threadIdx.x] = b_rgb[threadIdx.x];
 }
 
 // raw2outputs (models.py:822-850): one thread per ray, 120 sequential samples
@@ -176,19 +323,26 @@ extern "C" int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream) {
     UCN_REQUIRE(s->w_alpha && s->b_alpha && s->w_feat && s->b_feat && s->w_view && s->b_view && s->w_rgb && s->b_rgb,
                 "sky_pack: head weights missing");
     hipStream_t st = (hipStream_t)stream;
-    uint64_t off = 0;
-    auto chainpack = [&](const float *W, uint32_t ld, uint32_t col0, uint32_t nto, uint32_t nti) {
-        hipLaunchKernelGGL(k_pack_chain, dim3(ucn_div_up((uint64_t)nto * nti * 1024, 256)), dim3(256), 0, st, W, ld, col0,
-                           0u, nto, nti, s->packed + off);
-        off += (uint64_t)nto * nti * 1024;
+    float *side = s->packed + kOffSide, *M5 = s->packed + kOffM5, *Mv = s->packed + kOffMv;
+    hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up(kOffM5, 256)), dim3(256), 0, st, s->packed, (uint32_t)kOffM5);
+    hipLaunchKernelGGL(k_sky_compose, dim3(ucn_div_up(256 * 288, 256)), dim3(256), 0, st, s->w_pts[5], s->b_pts[5], s->w_view,
+                       s->b_view, s->w_feat, s->b_feat, M5, Mv);
+    auto chainpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t group) {
+        hipLaunchKernelGGL(k_pack_chain_h, dim3(ucn_div_up((uint64_t)nto * nti * 2048, 256)), dim3(256), 0, st, W, ld, 0u,
+                           0u, nto, nti, (const float *)nullptr, reinterpret_cast<_Float16 *>(s->packed + group * 256));
     };
-    for (int i = 1; i < 8; i++) chainpack(s->w_pts[i], i == 5 ? 259 : 256, i == 5 ? 3 : 0, 8, 8);
-    chainpack(s->w_feat, 256, 0, 8, 8);
-    chainpack(s->w_view, 283, 0, 4, 8);
-    hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, s->w_pts[0], 3u, s->b_pts[0], 256u, s->packed + kOffIn0);
-    hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, s->w_pts[5], 259u, s->b_pts[5], 256u, s->packed + kOffIn5);
-    hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, s->w_alpha, 256u, 0u, 256u, 1u, 1u, s->packed + kOffAlpha);
-    hipLaunchKernelGGL(k_pack_head, dim3(2), dim3(256), 0, st, s->w_rgb, 128u, 0u, 128u, 3u, 4u, s->packed + kOffRgb);
+    const int plain[6] = {1, 2, 3, 4, 6, 7};
+    const int plain_g[6] = {kGL1, kGL2, kGL3, kGL4, kGL6, kGL7};
+    for (int i = 0; i < 6; i++) {
+        chainpack(s->w_pts[plain[i]], 256, 8, 8, plain_g[i]);
+        hipLaunchKernelGGL(k_pack_bias_h, dim3(1), dim3(256), 0, st, s->b_pts[plain[i]], 8u, side + kSB + i * 256);
+    }
+    chainpack(M5, 288, 8, 9, kGL5);
+    chainpack(Mv, 288, 4, 9, kGV);
+    hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, s->w_pts[0], 3u, s->b_pts[0], 256u, side + kSL0);
+    hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, s->w_alpha, 256u, 0u, 256u, 1u, 1u, side + kSAlpha);
+    hipLaunchKernelGGL(k_pack_head, dim3(2), dim3(256), 0, st, s->w_rgb, 128u, 0u, 128u, 3u, 4u, side + kSRgb);
+    hipLaunchKernelGGL(k_sky_side_scalars, dim3(1), dim3(64), 0, st, s->b_alpha, s->b_rgb, side);
     UCN_LAUNCH_CHECK("sky_pack");
     return 0;
 }
@@ -204,18 +358,17 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
                 "sky_render: null pointer argument");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    float *view_bias = workspace;
+    float *aux = workspace;                                   // [N,32]
     float *raw = workspace + (size_t)N * 128;
-    hipLaunchKernelGGL(k_sky_view_bias, dim3(N), dim3(128), 0, st, cam_dirs, s->w_view, N, view_bias);
+    hipLaunchKernelGGL(k_sky_aux, dim3(ucn_div_up((uint64_t)N * 32, 256)), dim3(256), 0, st, cam_dirs, N, aux);
     SkyArgs a;
     a.packed = s->packed;
-    for (int i = 0; i < 8; i++) a.b_pts[i] = s->b_pts[i];
-    a.b_alpha = s->b_alpha; a.b_feat = s->b_feat; a.b_view = s->b_view; a.b_rgb = s->b_rgb;
-    a.view_bias = view_bias; a.origins = origins; a.dirs = directions; a.far_ = far_; a.t_vals = t_vals;
+    a.aux = aux; a.origins = origins; a.dirs = directions; a.far_ = far_; a.t_vals = t_vals;
     a.inv_sky_far = 1.0f / far0_times_1p5;
     a.N = N; a.raw = raw;
     const uint64_t B = (uint64_t)N * kSkySamples;
-    hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), 2 * kChunkGroups * 256 * sizeof(float), st, a);
+    const size_t lds = (2 * kChunkGroups * 256 + kSideFloats) * sizeof(float);
+    hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite, dim3(ucn_div_up(N, 256)), dim3(256), 0, st, raw, directions, far_, t_vals,
                        a.inv_sky_far, N, sky_rgb_out);
     UCN_LAUNCH_CHECK("sky_render");
