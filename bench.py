@@ -115,6 +115,31 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192
                 rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
 
 
+def sky_layer_ms(batch_flat, device, n_rays=65536, steps=3):
+    """SURVEY 8 row a12 / cfg5's extra term: the sky NeRF (120 samples x 562,688 MAC) on n_rays of the frame,
+    random-init weights of the reference architecture (models.py:85-92).  Outside the timed region."""
+    from ucnerf_amd.internal.sky import NeRF
+    torch.manual_seed(1)
+    net = NeRF(D=8, d_in_view=3, W=256, multires_view=4, output_ch=4, skips=[4]).to(device)
+    tot = batch_flat["origins"].shape[0]
+    idx = torch.arange(0, tot, tot // n_rays, device=device)[:n_rays]
+    o, d, cam = (batch_flat[k][idx].contiguous() for k in ("origins", "directions", "cam_dirs"))
+    far = batch_flat["far"][idx].reshape(-1).contiguous()
+    for _ in range(2):
+        net.render(o, d, cam, far)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        net.render(o, d, cam, far)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    flops = 2.0 * 562688 * 120 * n_rays
+    return dict(ms=ms, rays=n_rays, rays_per_s=n_rays / ms * 1e3, algorithmic_tflops=flops / ms / 1e9,
+                frac_of_f16_mfma_peak=flops / ms / 1e9 / PEAK_F16_MFMA_TF, ms_per_frame=ms * tot / n_rays,
+                kernel="k_sky_mlp (split-f16 MFMA, composed views layer) + k_sky_composite")
+
+
 def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
     """BASELINE configs[2]: one training step on an 8192-ray batch -- Model.forward(rand=True) under bf16
     autocast, the losses of train.py:173-216 with waymo defaults, backward, nan_to_num on grads
@@ -171,11 +196,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
+    # UCN_DIST_BACKEND=gloo lets two ranks share one GPU: a functional check of the multi-rank flow on a 1-GPU box
+    backend = os.environ.get("UCN_DIST_BACKEND", "nccl")             # nccl == RCCL on ROCm
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     from ucnerf_amd.internal import models, dist as udist
     if args.mlp_mode is not None:
         models.MLP.mlp_mode = args.mlp_mode
@@ -268,6 +299,7 @@ def main():
         if world == 1 and not args.no_train:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
+            res["sky_layer"] = sky_layer_ms(flat, device)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
