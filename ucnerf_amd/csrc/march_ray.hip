@@ -100,26 +100,43 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
     uint32_t idx = 0;
     float prev_c = 0.0f, prev_mid = 0.0f, c0 = 0.0f;
     float *out = sd_out + (size_t)ray * (S + 1);
-    for (uint32_t k = 0; k < S; k++) {
-        float u = u_table[k];
-        if (jitter) u = u + (jcols > 1 ? jitter[(size_t)ray * jcols + k] : jit) * max_jitter;
-        while (idx + 1 <= nw && w[idx + 1] <= u) idx++;
-        const uint32_t i1 = idx + 1 <= nw ? idx + 1 : nw;
-        const float x0 = w[idx], x1 = w[i1];
-        float fr = (u - x0) / (x1 - x0);
-        if (fr != fr) fr = 0.0f;                               // nan_to_num(.., 0); +-inf clip below
-        fr = fminf(fmaxf(fr, 0.0f), 1.0f);
-        const float f0 = sd[idx], f1 = sd[i1];
-        const float c = f0 + fr * (f1 - f0);
-        if (k == 0) {
-            c0 = c;
-        } else {
-            const float mid = (c + prev_c) / 2.0f;
-            if (k == 1) out[0] = fmaxf(2.0f * c0 - mid, 0.0f);
-            out[k] = mid;
-            prev_mid = mid;
+    // Outputs leave in blocks of 16 consecutive floats per thread: a thread's row is its own 516-byte strip, and
+    // dword stores trickling out one per iteration let every 64-byte sector be evicted half-written from L2
+    // (measured: 7 GB fetched + 14 GB written per call for 1.3 GB of output, 9.5 ms); sixteen back-to-back stores
+    // complete the sector while it is still resident.
+    for (uint32_t kb = 0; kb < S; kb += 16) {
+        float ob[16];
+#pragma unroll
+        for (uint32_t kk = 0; kk < 16; kk++) {
+            const uint32_t k = kb + kk;
+            ob[kk] = 0.0f;
+            if (k < S) {
+                float u = u_table[k];
+                if (jitter) u = u + (jcols > 1 ? jitter[(size_t)ray * jcols + k] : jit) * max_jitter;
+                while (idx + 1 <= nw && w[idx + 1] <= u) idx++;
+                const uint32_t i1 = idx + 1 <= nw ? idx + 1 : nw;
+                const float x0 = w[idx], x1 = w[i1];
+                float fr = (u - x0) / (x1 - x0);
+                if (fr != fr) fr = 0.0f;                               // nan_to_num(.., 0); +-inf clip below
+                fr = fminf(fmaxf(fr, 0.0f), 1.0f);
+                const float f0 = sd[idx], f1 = sd[i1];
+                const float c = f0 + fr * (f1 - f0);
+                if (k == 0) {
+                    c0 = c;
+                } else {
+                    const float mid = (c + prev_c) / 2.0f;
+                    if (k == 1) ob[0] = fmaxf(2.0f * c0 - mid, 0.0f);  // k == 1 is (kb, kk) = (0, 1): a static slot
+                    ob[kk] = mid;
+                    prev_mid = mid;
+                }
+                prev_c = c;
+            }
         }
-        prev_c = c;
+#pragma unroll
+        for (uint32_t kk = 0; kk < 16; kk++) {
+            const uint32_t k = kb + kk;
+            if (k < S && !(k == 0 && S == 1)) out[k] = ob[kk];         // (S == 1 never writes out[0] upstream either)
+        }
     }
     out[S] = fminf(2.0f * prev_c - prev_mid, 1.0f);
 }
