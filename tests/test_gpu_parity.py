@@ -297,6 +297,28 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
     torch.set_grad_enabled(True)
 
 
+def test_model_forward_empty_single_and_ragged_batches():
+    """0 rays (empty tensors through every entry point), 1 ray, and a batch that is not a multiple of any tile
+    size (partial wave, partial workgroup, ragged last pass) against the CPU oracle."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=21)
+    model, _ = H.hip_model(spec, sd, max_chunk_rays=40)
+    torch.set_grad_enabled(False)
+    for n in (0, 1, 131):
+        rays = rm.synthetic_rays(max(n, 1), seed=22)
+        rays = {k: v[:n] for k, v in rays.items()}
+        noise = [rm.draw_level_noise(spec, max(n, 1), l, False, torch.Generator().manual_seed(23 + l)) for l in range(2)]
+        for nz in noise:
+            nz.rand_vec = nz.rand_vec[:n]
+        got, hist = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+        assert got[-1]["rgb"].shape == (n, 3) and hist[-1]["sdist"].shape[0] == n
+        if n:
+            want, _ = rm.model_forward(spec, sd, rays, noise)
+            assert H.maxdiff(got[-1]["rgb"].cpu(), want[-1]["rgb"]) <= H.RGB_TOL
+            assert H.maxdiff(got[-1]["acc"].cpu(), want[-1]["acc"]) <= 1e-4
+    torch.set_grad_enabled(True)
+
+
 def test_features_backward_algorithms_agree():
     """Table gradient of the fused featurisation: row-block ownership (no global atomics) == atomic scatter,
     in both gradient layouts; the atomic scatter itself is pinned to the reference's training step by

@@ -230,7 +230,7 @@ extern "C" int ucn_field_dir_bias(const ucn_field_t *f, const float *viewdirs, u
     PackPlan pl;
     if (int rc = make_plan(f, &pl)) return rc;
     UCN_REQUIRE(!pl.prop, "field_dir_bias: field has no colour MLP (disable_rgb)");
-    UCN_REQUIRE(viewdirs && dir_bias_out, "field_dir_bias: null pointer argument");
+    UCN_REQUIRE(N == 0 || (viewdirs && dir_bias_out), "field_dir_bias: null pointer argument");
     UCN_REQUIRE((f->n_dir - 3) % 6 == 0, "field_dir_bias: n_dir must be 3+6*deg, got %u", f->n_dir);
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -249,10 +249,10 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
                              float *bottleneck_out, ucn_stream_t stream) {
     PackPlan pl;
     if (int rc = make_plan(f, &pl)) return rc;
-    UCN_REQUIRE(features && density_out && f->packed, "field_mlp: null pointer argument");
+    UCN_REQUIRE(B == 0 || (features && density_out && f->packed), "field_mlp: null pointer argument");
     UCN_REQUIRE(samples_per_ray >= 1, "field_mlp: samples_per_ray must be >= 1");
     UCN_REQUIRE(pl.prop ? rgb_out == nullptr : true, "field_mlp: a disable_rgb field has no colour output");
-    UCN_REQUIRE(rgb_out == nullptr || dir_bias != nullptr, "field_mlp: colour output needs the per-ray direction terms");
+    UCN_REQUIRE(B == 0 || rgb_out == nullptr || dir_bias != nullptr, "field_mlp: colour output needs the per-ray direction terms");
     if (B == 0) return 0;
     MlpArgs a;
     a.feat = features; a.packed = f->packed;

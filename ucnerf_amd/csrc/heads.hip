@@ -58,7 +58,7 @@ extern "C" int ucn_dense(const float *x, const float *w, const float *b, uint32_
 extern "C" int ucn_apply_affine(const float *rgb_in, const float *affine, const int64_t *ray_to_row,
                                 const float *weights_last, uint32_t S, const float *sky_rgb, const float *affine_sky,
                                 uint32_t N, float *rgb_out, ucn_stream_t stream) {
-    UCN_REQUIRE(rgb_in && affine && rgb_out, "apply_affine: null pointer argument");
+    UCN_REQUIRE(N == 0 || (rgb_in && affine && rgb_out), "apply_affine: null pointer argument");
     UCN_REQUIRE(!sky_rgb || (weights_last && affine_sky), "apply_affine: the sky blend needs weights and the sky affine");
     if (N == 0) return 0;
     hipLaunchKernelGGL(k_apply_affine, dim3(ucn_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, rgb_in, affine, ray_to_row,

@@ -656,7 +656,7 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
                                   const float *radii, const float *flip, const float *spin, float std_scale,
                                   uint32_t N, uint32_t S, uint32_t levels_per_block, int layout,
                                   float *features_out, float *coord_out, float *tmean_out, ucn_stream_t stream) {
-    UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && features_out,
+    UCN_REQUIRE(N == 0 || (sdist && near_ && far_ && origins && directions && basis && radii && features_out),
                 "march_features: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
     UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");

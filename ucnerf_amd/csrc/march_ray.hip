@@ -309,8 +309,8 @@ extern "C" int ucn_resample(const float *sdist_prev, const float *weights_prev, 
                             uint32_t jitter_cols, float max_jitter, uint32_t N, uint32_t S, float *sdist_out,
                             ucn_stream_t stream) {
     UCN_REQUIRE(S > 1, "num_samples must be > 1, is %u.", S);                      // stepfun.py:271-272
-    UCN_REQUIRE(u_table && sdist_out, "resample: null pointer argument");
-    UCN_REQUIRE(n_prev == 0 || (sdist_prev && weights_prev), "resample: previous level missing");
+    UCN_REQUIRE(N == 0 || (u_table && sdist_out), "resample: null pointer argument");
+    UCN_REQUIRE(N == 0 || n_prev == 0 || (sdist_prev && weights_prev), "resample: previous level missing");
     UCN_REQUIRE(n_prev <= 256, "resample: at most 256 intervals per level are supported, got %u", n_prev);
     UCN_REQUIRE(!jitter || jitter_cols == 1 || jitter_cols == S, "resample: jitter must be [N,1] or [N,S]");
     if (N == 0) return 0;
@@ -329,7 +329,7 @@ extern "C" int ucn_resample(const float *sdist_prev, const float *weights_prev, 
 
 extern "C" int ucn_cone_basis(const float *cam_dirs, const float *rand_vec, uint32_t N, float *basis_out,
                               ucn_stream_t stream) {
-    UCN_REQUIRE(cam_dirs && rand_vec && basis_out, "cone_basis: null pointer argument");
+    UCN_REQUIRE(N == 0 || (cam_dirs && rand_vec && basis_out), "cone_basis: null pointer argument");
     if (N == 0) return 0;
     hipLaunchKernelGGL(k_cone_basis, dim3(ucn_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, cam_dirs, rand_vec, N, basis_out);
     UCN_LAUNCH_CHECK("cone_basis");
@@ -340,7 +340,7 @@ extern "C" int ucn_composite(const float *density, const float *rgbs, const floa
                              const float *far_, const float *directions, float bg_intensity, int opaque_background,
                              uint32_t N, uint32_t S, float *weights_out, float *out_main, float *out_extras,
                              ucn_stream_t stream) {
-    UCN_REQUIRE(density && sdist && near_ && far_ && directions && weights_out && out_main, "composite: null pointer argument");
+    UCN_REQUIRE(N == 0 || (density && sdist && near_ && far_ && directions && weights_out && out_main), "composite: null pointer argument");
     UCN_REQUIRE(S >= 1 && S <= 512, "composite: samples per ray must be in [1,512], got %u", S);
     if (N == 0) return 0;
     const dim3 grid(ucn_div_up(N, 4));

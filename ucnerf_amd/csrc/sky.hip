@@ -354,7 +354,7 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
                                  const float *t_vals /*DEVICE [120] = linspace(0,1,120)*/, uint32_t N,
                                  float *workspace /*DEVICE N*(128+480) floats*/, float *sky_rgb_out,
                                  ucn_stream_t stream) {
-    UCN_REQUIRE(s && s->packed && origins && directions && cam_dirs && far_ && t_vals && workspace && sky_rgb_out,
+    UCN_REQUIRE(N == 0 || (s && s->packed && origins && directions && cam_dirs && far_ && t_vals && workspace && sky_rgb_out),
                 "sky_render: null pointer argument");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
