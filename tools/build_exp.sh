@@ -1,10 +1,12 @@
 #!/bin/bash
 # Experiment builds of libucnerf_march.so for kernel diagnosis (NOT the product): copies csrc/ to
-# tools/_exp/<name>/, applies a sed patch to the split-f16 engine and builds there.
-#   nolo   : the lo half of every A pair is not read from LDS (halves LDS read traffic; wrong numerics)
-#   onemf  : one MFMA per step instead of three, same LDS reads (wrong numerics)
-#   nodma  : no weight DMA after chunk 0 (stale LDS contents; wrong numerics): what the DMA pieces cost the waves
-#   nosb   : without the sched_barrier that pins the prefetch above the MFMAs
+# tools/_exp/<name>/, applies a sed patch to the split-f16 engine (mfma_chain_h.h) and builds there.
+# Run with tools/mlp_bench.py --lib tools/_exp/<name>/ucnerf_amd/csrc/libucnerf_march.so (numerics are
+# wrong by construction in nodma / noread; they only answer "what does this part of the stream cost").
+#   nodma   : no weight DMA after the first chunks (stale LDS contents)
+#   noread  : A operands are read from LDS only for the first 16 groups (ring keeps stale values)
+#   depth4 / depth8 : ring depth of the A-operand prefetch (default 6)
+#   base    : unpatched copy
 set -euo pipefail
 cd "$(dirname "$0")/.."
 for name in "$@"; do
@@ -14,15 +16,11 @@ for name in "$@"; do
   cp include/*.h "$dst/include/"
   h=$dst/ucnerf_amd/csrc/mfma_chain_h.h
   case $name in
-    nolo)  sed -i 's|    p.lo = group_h(ws, g + 1);|    p.lo = p.hi;|' "$h" ;;
-    onemf) sed -i 's|    acc = mfma16h(p.hi, blo, acc);||; s|    acc = mfma16h(p.lo, bhi, acc);||; s|    acc = mfma16h(p.hi, bhi, acc);|    acc = mfma16h(p.hi + p.lo, bhi + blo, acc);|' "$h" ;;
-    nosb)  sed -i 's|    __builtin_amdgcn_sched_barrier(0);.*||' "$h" ;;
-    nodma) sed -i 's|    if (g % 4 == 0 \&\& |    if (false \&\& |' "$h" ;;
-    noread) sed -i 's|    if (G0 + 2 \* d < GEND) pipe_fetch(G0 + 2 \* d, p, ws);|    { p.hi[d] = group_h(ws, G0 + 2 * d); p.lo[d] = group_h(ws, G0 + 2 * d + 1); }|; s|    p.hi\[(g / 2) % kDepth\] = group_h(ws, g);||; s|    p.lo\[(g / 2) % kDepth\] = group_h(ws, g + 1);||' "$h" ;;
-    nodma_noread) sed -i 's|    if (g % 4 == 0 \&\& |    if (false \&\& |; s|    if (G0 + 2 \* d < GEND) pipe_fetch(G0 + 2 \* d, p, ws);|    { p.hi[d] = group_h(ws, G0 + 2 * d); p.lo[d] = group_h(ws, G0 + 2 * d + 1); }|; s|    p.hi\[(g / 2) % kDepth\] = group_h(ws, g);||; s|    p.lo\[(g / 2) % kDepth\] = group_h(ws, g + 1);||' "$h" ;;
-    depth6) sed -i 's|constexpr int kDepth = 4;|constexpr int kDepth = 6;|' "$h" ;;
-    depth8) sed -i 's|constexpr int kDepth = 4;|constexpr int kDepth = 8;|' "$h" ;;
-    base)  ;;
+    nodma)  sed -i 's|    if constexpr (G % 4 == 0 \&\& |    if constexpr (false \&\& G % 4 == 0 \&\& |' "$h" ;;
+    noread) sed -i 's|    p.hi\[(G / 2) % kDepth\] = __builtin_bit_cast(h8, ws.group(G));|    if constexpr (G < 16) p.hi[(G / 2) % kDepth] = __builtin_bit_cast(h8, ws.group(G));|; s|    p.lo\[(G / 2) % kDepth\] = __builtin_bit_cast(h8, ws.group(G + 1));|    if constexpr (G < 16) p.lo[(G / 2) % kDepth] = __builtin_bit_cast(h8, ws.group(G + 1));|' "$h" ;;
+    depth4) sed -i 's|constexpr int kDepth = 6;|constexpr int kDepth = 4;|' "$h" ;;
+    depth8) sed -i 's|constexpr int kDepth = 6;|constexpr int kDepth = 8;|' "$h" ;;
+    base)   ;;
     *) echo "unknown experiment $name"; exit 1 ;;
   esac
   bash "$dst/ucnerf_amd/csrc/build.sh" | tail -1
