@@ -256,10 +256,51 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
 
 // Row-block variant of level_scatter: only corners whose row lies in [row_lo, row_lo + nrows) count, and
 // they go to the workgroup's LDS copy of that row block (ds_add_f32).
-template <uint32_t C, bool HASHED, bool POW2>
+template <uint32_t C, bool HASHED, bool POW2, bool MERGE>
 __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo,
                                                     uint32_t nrows, const float (&u)[6][3], const float (&rs)[6],
                                                     const float (&gout)[C]) {
+    if constexpr (MERGE) {
+        // Coarse levels: the six multisamples mostly sit in one lattice cell, and so do the neighbouring
+        // samples of the wave -- the LDS atomics of such a level serialise on a handful of addresses (level 0 of
+        // the benchmark grid took 16x a fine level).  Runs of multisamples with the same 8 rows are summed in
+        // registers first: 8*C atomics per run instead of per multisample.
+        uint32_t cur[8];
+        float wsum[8];
+        bool have = false;
+        auto flush = [&]() {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t r = cur[k] - row_lo;
+                if (r < nrows) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) atomicAdd(acc + r * C + c, wsum[k] * gout[c]);
+                }
+            }
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+                float fx, fy, fz, w[8];
+                uint32_t rows[8];
+                corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+                corner_weights(fx, fy, fz, w);
+                const float damp = erf_pos(rs[j] * lv.inv_gs);
+                bool same = have;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) same = same && rows[k] == cur[k];
+                if (have && !same) flush();
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    wsum[k] = same ? wsum[k] + w[k] * damp : w[k] * damp;
+                    cur[k] = rows[k];
+                }
+                have = true;
+            }
+        }
+        if (have) flush();
+        return;
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
         if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
@@ -577,11 +618,15 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
             cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
         }
         if (lv.hashed) {
-            if (lv.mask) level_scatter_block<C, true, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
-            else level_scatter_block<C, true, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
-        } else {
-            if (lv.mask) level_scatter_block<C, false, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
-            else level_scatter_block<C, false, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            if (lv.mask && lv.resolution <= 2048u) level_scatter_block<C, true, true, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else if (lv.mask) level_scatter_block<C, true, true, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else level_scatter_block<C, true, false, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+        } else if (lv.resolution <= 2048u) {
+            if (lv.mask) level_scatter_block<C, false, true, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else level_scatter_block<C, false, false, true>(lv, s_acc, row_lo, nrows, u, rs, gout);
+        } else {                                   // the strided fine levels of the uint32-wrap quirk: nothing to merge
+            if (lv.mask) level_scatter_block<C, false, true, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
+            else level_scatter_block<C, false, false, false>(lv, s_acc, row_lo, nrows, u, rs, gout);
         }
     }
     __syncthreads();
