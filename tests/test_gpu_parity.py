@@ -297,6 +297,31 @@ def test_model_forward_vs_oracle_larger_batch_and_chunks():
     torch.set_grad_enabled(True)
 
 
+def test_mlp_modes_agree():
+    """mlp_mode 0 (exact fp32 products on the fp32-input MFMA, the reference's layer-by-layer form) against
+    mlp_mode 1 (split-f16 MFMA + composed colour layers, the default): same pixels to a few fp32 ulps, and both
+    against the CPU oracle."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=31)
+    n = 600
+    rays = rm.synthetic_rays(n, seed=32)
+    noise = [rm.draw_level_noise(spec, n, l, False, torch.Generator().manual_seed(33 + l)) for l in range(2)]
+    with torch.no_grad():
+        want, _ = rm.model_forward(spec, sd, rays, noise)
+    model, _ = H.hip_model(spec, sd)
+    torch.set_grad_enabled(False)
+    out = {}
+    for mode in (0, 1):
+        model.nerf_mlp.mlp_mode = mode
+        got, hist = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+        out[mode] = (got[-1]["rgb"].cpu(), hist[-1]["density"].cpu())
+        assert H.maxdiff(out[mode][0], want[-1]["rgb"]) <= H.RGB_TOL
+    torch.set_grad_enabled(True)
+    assert H.maxdiff(out[0][0], out[1][0]) <= 2e-6                      # pixels
+    rel = (out[0][1] - out[1][1]).abs() / (out[0][1].abs() + 1e-3)
+    assert float(rel.max()) <= 2e-5                                     # per-sample densities
+
+
 def test_model_forward_empty_single_and_ragged_batches():
     """0 rays (empty tensors through every entry point), 1 ray, and a batch that is not a multiple of any tile
     size (partial wave, partial workgroup, ragged last pass) against the CPU oracle."""
