@@ -88,7 +88,9 @@ def field_heads(mlp, feat, viewdirs, N, S):
     density = F.softplus(x[..., 0] + mlp.density_bias)
     if mlp.disable_rgb:
         return density, torch.zeros(N, S, 3, device=feat.device)
-    enc = view_encoding(viewdirs, mlp.deg_view)[:, None, :].expand(N, S, -1)
+    # under autocast x is bf16 and the next Linear rounds its whole input to bf16 anyway: casting the encoding first
+    # gives the same numbers without the fp32 [N,S,283] / [N,S,539] concatenations and their re-casts
+    enc = view_encoding(viewdirs, mlp.deg_view).to(x.dtype)[:, None, :].expand(N, S, -1)
     h = torch.cat([x, enc], dim=-1)
     skip = h
     for i in range(mlp.net_depth_viewdirs):
