@@ -133,3 +133,26 @@ def test_hip_train_graph_matches_reference_step(name, over):
             assert abs(float(p.grad.double().abs().sum()) - float(fx[f"grad_{pname}.abs"])) <= 2e-2 * float(fx[f"grad_{pname}.abs"])
         else:
             check_grad(fx, pname, p.grad, 2e-2)
+
+
+@pytest.mark.gpu
+def test_tall_linear_matches_library_linear_under_autocast():
+    """_TallLinear (chunked weight-gradient reduction, bf16 operands) against F.linear + autograd under the
+    same autocast: outputs identical, gradients equal to bf16 rounding of a 65536-term reduction."""
+    from ucnerf_amd.internal import train_graph as tg
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(283, 256).cuda()
+    x = torch.randn(65536, 283, device="cuda", requires_grad=True)
+    gy = torch.randn(65536, 256, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_ref = torch.nn.functional.linear(x, lin.weight, lin.bias)
+        gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, lin.weight, lin.bias), gy.to(y_ref.dtype))
+        y = tg.tall_linear(lin, x)
+        gx, gw, gb = torch.autograd.grad(y, (x, lin.weight, lin.bias), gy.to(y.dtype))
+    assert y.dtype == y_ref.dtype and torch.equal(y, y_ref)
+    assert gx.dtype == x.dtype and gw.dtype == lin.weight.dtype and gb.dtype == lin.bias.dtype
+    assert float((gx - gx_ref).abs().max()) <= 1e-2 * float(gx_ref.abs().max())
+    assert float((gw - gw_ref).abs().max()) <= 1e-2 * float(gw_ref.abs().max())
+    assert float((gb - gb_ref).abs().max()) <= 1e-2 * float(gb_ref.abs().max())
+    y32 = tg.tall_linear(lin, x)                              # no autocast: the plain fp32 library path
+    assert y32.dtype == torch.float32

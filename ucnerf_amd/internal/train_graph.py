@@ -75,6 +75,48 @@ class GradientScaler(torch.autograd.Function):
         return g_colors * k[..., None], g_sigmas * k, None
 
 
+class _TallLinear(torch.autograd.Function):
+    """F.linear for a tall activation matrix [M ~ 1e6, K] and a small weight [N <= 256, K].
+
+    The library's weight-gradient GEMM dY^T X (N x K output, reduction over the M samples) gets a single
+    64x64 macro-tile grid -- 36 workgroups on a 256-CU part, 1.75 ms per call -- because nothing splits the
+    reduction.  Here the reduction is cut into chunks that run as one batched GEMM and are summed afterwards
+    (the same addends in a different order; fp32 accumulation inside each chunk and across chunks)."""
+    CHUNK = 8192
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dt = torch.get_autocast_dtype("cuda")                      # bf16 under the reference's accelerator.autocast()
+        xb, wb = x.to(dt), weight.to(dt)
+        ctx.save_for_backward(xb, wb)
+        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        with torch.autocast("cuda", enabled=False):
+            return F.linear(xb, wb, None if bias is None else bias.to(dt))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        x_dt, w_dt, b_dt = ctx.dtypes
+        with torch.autocast("cuda", enabled=False):
+            gy2 = gy.reshape(-1, gy.shape[-1]).to(x.dtype)
+            x2 = x.reshape(-1, x.shape[-1])
+            gx = (gy2 @ weight).reshape(x.shape).to(x_dt) if ctx.needs_input_grad[0] else None
+            m, c = x2.shape[0], _TallLinear.CHUNK
+            if m >= 4 * c and m % c == 0:
+                gw = torch.bmm(gy2.reshape(m // c, c, -1).transpose(1, 2), x2.reshape(m // c, c, -1)).float().sum(0)
+            else:
+                gw = (gy2.t() @ x2).float()
+            gb = None if b_dt is None else gy2.float().sum(0).to(b_dt)
+        return gx, gw.to(w_dt), gb
+
+
+def tall_linear(lin, x):
+    """nn.Linear `lin` applied through _TallLinear (autocast: operands in bf16 like F.linear under autocast)."""
+    if torch.is_autocast_enabled():
+        return _TallLinear.apply(x, lin.weight, lin.bias)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 def view_encoding(d, deg):
     """coord.py:214-225 pos_enc(min_deg=0, max_deg=deg, append_identity=True)."""
     scales = 2 ** torch.arange(0, deg, device=d.device)
@@ -84,7 +126,7 @@ def view_encoding(d, deg):
 
 def field_heads(mlp, feat, viewdirs, N, S):
     """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs)."""
-    x = mlp.density_layer(feat).reshape(N, S, -1)
+    x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat))).reshape(N, S, -1)
     density = F.softplus(x[..., 0] + mlp.density_bias)
     if mlp.disable_rgb:
         return density, torch.zeros(N, S, 3, device=feat.device)
@@ -94,10 +136,10 @@ def field_heads(mlp, feat, viewdirs, N, S):
     h = torch.cat([x, enc], dim=-1)
     skip = h
     for i in range(mlp.net_depth_viewdirs):
-        h = F.relu(mlp.get_submodule(f"lin_second_stage_{i}")(h))
+        h = F.relu(tall_linear(mlp.get_submodule(f"lin_second_stage_{i}"), h))
         if i == mlp.skip_layer_dir:
             h = torch.cat([h, skip], dim=-1)
-    rgb = torch.sigmoid(mlp.rgb_premultiplier * mlp.rgb_layer(h) + mlp.rgb_bias)
+    rgb = torch.sigmoid(mlp.rgb_premultiplier * tall_linear(mlp.rgb_layer, h) + mlp.rgb_bias)
     return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
 
 
