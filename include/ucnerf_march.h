@@ -141,11 +141,12 @@ int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const 
                                 const float *radii, const float *flip, const float *spin, float std_scale,
                                 uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
                                 const float *grad_features, float *grad_embeddings,
-                                float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(N,S) floats, or NULL:
-                                                   the row-block algorithm then re-derives the sample geometry in
-                                                   every workgroup instead of reading it back (3x slower)*/,
+                                float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(f,N,S) floats (24 planes of
+                                                   sample geometry + per-level row-block masks), or NULL: the row-block
+                                                   algorithm then re-derives the geometry in every workgroup and
+                                                   cannot compact its work (several times slower)*/,
                                 ucn_stream_t stream);
-uint64_t ucn_march_features_backward_ws_floats(uint32_t N, uint32_t S);
+uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S);
 
 /* Same featurisation for caller-supplied Gaussians (ref: models.py:485-512 predict_density as
  * called by extract.py:56-57,96): means [B,G,3], stds [B,G]; warp=0 skips the contraction. */

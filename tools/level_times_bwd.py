@@ -3,6 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from ucnerf_amd import _lib
+if os.environ.get("UCN_TOOL_LIB"):               # experiment builds; the product loads the in-tree library
+    _lib.LIB_PATH = os.path.abspath(os.environ["UCN_TOOL_LIB"])
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 model, cfg, sd = bench.build_model(dev)
@@ -21,10 +23,11 @@ near, far = flat["near"].reshape(-1).contiguous(), flat["far"].reshape(-1).conti
 rad = flat["radii"].reshape(-1).contiguous()
 feat = torch.randn(n * S * 2, device=dev)
 grad = torch.zeros_like(enc.embeddings)
-ws = torch.empty(24 * n * S, device=dev)
+ws = torch.empty(32 * n * S, device=dev)     # >= ucn_march_features_backward_ws_floats of any 1-level field
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 tot = 0.0
-for l in range(enc.num_levels):
+levels = [int(a) for a in sys.argv[2:]] or range(enc.num_levels)
+for l in levels:
     d = _lib.UcnField()
     off = np.array([0, int(enc._offsets_np[l + 1] - enc._offsets_np[l])], dtype=np.int32)
     gs = np.array([int(enc._sizes_np[l])], dtype=np.int32)

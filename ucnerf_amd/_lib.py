@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -60,7 +60,7 @@ SIGNATURES = {
                            c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
-    "ucn_march_features_backward_ws_floats": [c_u32, c_u32],
+    "ucn_march_features_backward_ws_floats": [ctypes.POINTER(UcnField), c_u32, c_u32],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
     "ucn_field_dir_floats": [ctypes.POINTER(UcnField), c_u32],
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],

@@ -254,8 +254,41 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
     }
 }
 
+// acc[r][0..C) += v in the workgroup's LDS row block.  ds_add_f32 is serialised per LANE on gfx950 (measured with
+// tools/lds_atomic_bench.hip: 193 clk per wave instruction, 3 clk per active lane, whatever the addresses -- 40x
+// the integer ds_add_u32), so a row is updated with an 8-byte compare-and-swap loop instead: two channels per
+// ds_cmpst_rtn_b64, 37 clk per wave for 64 random rows, and still an exact fp32 add per addend (a lane only
+// retries when another lane changed the same row in between).
+template <uint32_t C>
+__device__ __forceinline__ void lds_row_add(float *acc, uint32_t r, const float (&v)[C]) {
+#if defined(UCN_EXP_NOADD)
+    if (v[0] == 123.456f) acc[r * C] = v[0];
+    return;
+#endif
+#pragma unroll
+    for (uint32_t c = 0; c + 1 < C; c += 2) {
+        unsigned long long *p = reinterpret_cast<unsigned long long *>(acc + r * C + c);
+        unsigned long long old = *p, seen;
+        do {
+            seen = old;
+            float2 t = __builtin_bit_cast(float2, seen);
+            t.x += v[c];
+            t.y += v[c + 1];
+            old = atomicCAS(p, seen, __builtin_bit_cast(unsigned long long, t));
+        } while (old != seen);
+    }
+    if constexpr (C & 1u) {
+        uint32_t *p = reinterpret_cast<uint32_t *>(acc + r * C + (C - 1));
+        uint32_t old = *p, seen;
+        do {
+            seen = old;
+            old = atomicCAS(p, seen, __float_as_uint(__uint_as_float(seen) + v[C - 1]));
+        } while (old != seen);
+    }
+}
+
 // Row-block variant of level_scatter: only corners whose row lies in [row_lo, row_lo + nrows) count, and
-// they go to the workgroup's LDS copy of that row block (ds_add_f32).
+// they go to the workgroup's LDS copy of that row block (lds_row_add).
 template <uint32_t C, bool HASHED, bool POW2, bool MERGE>
 __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo,
                                                     uint32_t nrows, const float (&u)[6][3], const float (&rs)[6],
@@ -275,8 +308,10 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
             for (uint32_t k = 0; k < 8; k++) {
                 const uint32_t r = cur[k] - row_lo;
                 if (r < nrows) {
+                    float v[C];
 #pragma unroll
-                    for (uint32_t c = 0; c < C; c++) atomicAdd(acc + r * C + c, wsum[k] * gout[c]);
+                    for (uint32_t c = 0; c < C; c++) v[c] = wsum[k] * gout[c];
+                    lds_row_add<C>(acc, r, v);
                 }
             }
         };
@@ -322,8 +357,10 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++)
                     if (rows[k] < nrows) {
+                        float v[C];
 #pragma unroll
-                        for (uint32_t c = 0; c < C; c++) atomicAdd(acc + rows[k] * C + c, (w[k] * damp) * gout[c]);
+                        for (uint32_t c = 0; c < C; c++) v[c] = (w[k] * damp) * gout[c];
+                        lds_row_add<C>(acc, rows[k], v);
                     }
             }
         }
@@ -569,6 +606,105 @@ __global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx,
     }
 }
 
+// ---- block masks: which row blocks of a level a sample touches.  Planes of [N*S] uint32 behind the 24 geometry
+// planes; a COARSE level (resolution <= 2048, the run-merging path) has one plane = union over its 48 corners,
+// a fine level six planes, one per multisample.  Bit p = some corner's row lies in block p (rows >> shift).
+struct MaskPlan {
+    uint16_t plane[UCN_MAX_LEVELS];
+    uint8_t coarse[UCN_MAX_LEVELS];
+    uint32_t n_planes, shift;
+};
+static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
+    uint32_t shift = 0;
+    while ((1u << shift) < rpb) shift++;
+    if ((1u << shift) != rpb) return false;
+    mp->shift = shift;
+    mp->n_planes = 0;
+    for (uint32_t l = 0; l < lv.L; l++) {
+        if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
+        mp->coarse[l] = lv.lv[l].resolution <= 2048u ? 1 : 0;
+        mp->plane[l] = (uint16_t)mp->n_planes;
+        mp->n_planes += mp->coarse[l] ? 1u : 6u;
+    }
+    return true;
+}
+
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ uint32_t point_block_mask(const UcnLevel &lv, uint32_t shift, const float (&p)[3]) {
+    if (!in_unit_cube(p[0], p[1], p[2])) return 0u;
+    float fx, fy, fz;
+    uint32_t rows[8], m = 0u;
+    corner_rows<HASHED, POW2>(lv, p[0], p[1], p[2], fx, fy, fz, rows);
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) m |= 1u << (rows[k] >> shift);
+    return m;
+}
+
+// geometry planes + block masks of every sample, once per backward call
+__global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInputs in, HexPattern hx, float std_scale,
+                                                          uint32_t N, uint32_t S, MaskPlan plan,
+                                                          const float *__restrict__ grad_features /*[L][N*S][C]*/, uint32_t C,
+                                                          float *__restrict__ geom, uint32_t *__restrict__ masks) {
+    const size_t B = (size_t)N * S;
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    float u[6][3], rs[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) geom[(size_t)(j * 3 + d) * B + b] = u[j][d];
+        geom[(size_t)(18 + j) * B + b] = rs[j];
+    }
+    for (uint32_t lvl = 0; lvl < lvls.L; lvl++) {
+        const UcnLevel lv = lvls.lv[lvl];
+        uint32_t m[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            if (lv.hashed) m[j] = lv.mask ? point_block_mask<true, true>(lv, plan.shift, u[j]) : point_block_mask<true, false>(lv, plan.shift, u[j]);
+            else m[j] = lv.mask ? point_block_mask<false, true>(lv, plan.shift, u[j]) : point_block_mask<false, false>(lv, plan.shift, u[j]);
+        }
+        // a sample whose feature gradient on this level is exactly zero contributes nothing: clear its masks here
+        // so that the scanning workgroups never have to look at the gradient
+        bool nz = false;
+        for (uint32_t c = 0; c < C; c++) nz |= grad_features[((size_t)lvl * B + b) * C + c] != 0.0f;
+        if (!nz) {
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
+        }
+        uint32_t *mp = masks + (size_t)plan.plane[lvl] * B + b;
+        if (plan.coarse[lvl]) {
+            mp[0] = m[0] | m[1] | m[2] | m[3] | m[4] | m[5];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 6; j++) mp[(size_t)j * B] = m[j];
+        }
+    }
+}
+
+// Direct (no run merging) scatter of ONE multisample point into the workgroup's row block.
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+                                                    const float (&p)[3], float rsj, const float (&gout)[C]) {
+    if (!in_unit_cube(p[0], p[1], p[2])) return;
+    float fx, fy, fz, w[8];
+    uint32_t rows[8];
+    corner_rows<HASHED, POW2>(lv, p[0], p[1], p[2], fx, fy, fz, rows);
+    corner_weights(fx, fy, fz, w);
+    const float damp = erf_pos(rsj * lv.inv_gs);
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t r = rows[k] - row_lo;
+        if (r < nrows) {
+            float v[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) v[c] = (w[k] * damp) * gout[c];
+            lds_row_add<C>(acc, r, v);
+        }
+    }
+}
+
 __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level) {
     return blocks_in_level >= 128u ? 1u : 128u / blocks_in_level;        // ~128 workgroups per level
 }
@@ -632,6 +768,168 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
         }
     }
     __syncthreads();
+    float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
+        const float v = s_acc[i];
+        if (v != 0.0f) {
+            if (split == 1) gtab[i] += v;
+            else atomicAdd(gtab + i, v);
+        }
+    }
+}
+
+// The same row-block ownership with COMPACTION.  A cell touches at most 8 of a level's 32 row blocks, a single
+// multisample point of a fine level 7 on average: in the plain kernel 78 % of the hash/weight work of a
+// workgroup is for corners that are not its own, and a per-lane "skip" does not help a 64-wide wave.  Here every
+// wave reads the block masks of 64 samples at a time, appends the items that DO touch the block -- samples on
+// coarse levels, (sample, multisample) pairs on fine ones -- to a ring in LDS (ballot + prefix count), and runs
+// the expensive part on 64 dense items whenever the ring holds that many.
+//
+// Code shape matters as much as the algorithm here: the scan/process loop is ONE function template per addressing
+// variant with ONE process site, everything force-inlined.  (With lambdas called from several unrolled sites the
+// compiler outlined the scatter into a real function: the level descriptor then lived behind a flat pointer --
+// a global load + vmcnt(0) in front of every point -- and the LDS base came from the dynamic-LDS offset table,
+// an s_load per corner; that version spent 80 % of its time waiting on those.)
+constexpr uint32_t kQueue = 512;                               // items per wave; 16 waves x 2 KiB beside the 128 KiB block
+constexpr uint32_t kScan = 4;                                  // samples per thread and scan step
+
+template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
+__device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, const float *__restrict__ gl,
+                                          const float *__restrict__ geom, float (&u)[6][3], float (&rs)[6], float (&gout)[C]) {
+    const uint32_t b = valid ? item & 0x1FFFFFFFu : 0u, j = valid ? item >> 29 : 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) gout[c] = gl[(size_t)b * C + c] / 6.0f;               // d(mean over the 6 multisamples)
+    if constexpr (COARSE) {
+#pragma unroll
+        for (uint32_t jj = 0; jj < 6; jj++) {
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) u[jj][d] = geom[(size_t)(jj * 3 + d) * B + b];
+            rs[jj] = geom[(size_t)(18 + jj) * B + b];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) u[0][d] = geom[(size_t)(j * 3 + d) * B + b];
+        rs[0] = geom[(size_t)(18 + j) * B + b];
+    }
+}
+
+template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
+__device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
+                                          uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
+                                          const uint32_t *__restrict__ mp, const float *__restrict__ gl,
+                                          const float *__restrict__ geom) {
+    constexpr uint32_t P = COARSE ? 1u : 6u;                                  // mask planes of this level
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t head = 0, tail = 0;                                              // wave-uniform ring positions
+    const size_t stride = (size_t)split * kScan * 1024u;
+    size_t base = (size_t)part * kScan * 1024u;
+    uint32_t cur[kScan][P], nxt[kScan][P];
+#pragma unroll
+    for (uint32_t u = 0; u < kScan; u++) {
+        const size_t b = base + u * 1024u + threadIdx.x;
+#pragma unroll
+        for (uint32_t j = 0; j < P; j++) cur[u][j] = b < B ? mp[(size_t)j * B + b] : 0u;
+    }
+    // `split` workgroups share a block; they take the samples in interleaved units of kScan x 1024 (flush: atomic).
+    // One workgroup per CU: the masks of the NEXT unit are requested before this unit's items are processed.
+    uint32_t u = 0;
+    bool more = base < B;
+    while (more || tail != head) {
+        if (more) {
+            if (u == 0) {
+                const size_t nb = base + stride;
+#pragma unroll
+                for (uint32_t uu = 0; uu < kScan; uu++) {
+                    const size_t b = nb + uu * 1024u + threadIdx.x;
+#pragma unroll
+                    for (uint32_t j = 0; j < P; j++) nxt[uu][j] = b < B ? mp[(size_t)j * B + b] : 0u;
+                }
+            }
+            const uint32_t b = (uint32_t)(base + u * 1024u + threadIdx.x);
+#pragma unroll
+            for (uint32_t j = 0; j < P; j++) {
+                uint32_t m = cur[0][j];                                       // u is wave-uniform: selects, no scratch
+#pragma unroll
+                for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu][j] : m;
+                const bool act = (m >> blk) & 1u;
+                const uint64_t bal = __ballot(act);
+                const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (act) q[pos & (kQueue - 1u)] = b | (j << 29);
+                tail += (uint32_t)__popcll(bal);
+            }
+            if (++u == kScan) {
+                u = 0;
+                base += stride;
+                more = base < B;
+#pragma unroll
+                for (uint32_t uu = 0; uu < kScan; uu++) {
+#pragma unroll
+                    for (uint32_t j = 0; j < P; j++) cur[uu][j] = nxt[uu][j];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // up to 128 ring items, two per lane: both items' loads are in flight before the first scatter starts.
+        // Ring: <= 127 left over + <= 384 appended per step <= kQueue.
+        const uint32_t thr = more ? 128u : 1u;
+        while (tail - head >= thr && tail != head) {
+            const uint32_t avail = tail - head < 128u ? tail - head : 128u;
+            const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
+            const bool v0 = lane < avail, v1 = lane + 64u < avail;
+            float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
+            cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0);
+            cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
+            if (v0) {
+                if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
+                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
+            }
+            if (v1) {
+                if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
+                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+            }
+            head += avail;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <uint32_t C>
+__global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls, float *__restrict__ grad_table, uint32_t N,
+                                                                 uint32_t S, uint32_t rpb, MaskPlan plan,
+                                                                 const float *__restrict__ grad_features /*[L][N*S][C]*/,
+                                                                 const float *__restrict__ geom,
+                                                                 const uint32_t *__restrict__ masks) {
+    extern __shared__ float s_acc[];
+    uint32_t task = blockIdx.x, lvl = 0, nb = 1, split = 1;
+    for (;; lvl++) {
+        nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
+        split = bwd_sample_split(nb);
+        if (task < nb * split || lvl + 1 == lvls.L) break;
+        task -= nb * split;
+    }
+    const UcnLevel lv = lvls.lv[lvl];
+    const uint32_t blk = task / split, part = task % split;
+    const uint32_t row_lo = blk * rpb;
+    const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) s_acc[i] = 0.0f;
+    __syncthreads();
+    uint32_t *q = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C) + (threadIdx.x >> 6) * kQueue;
+    const size_t B = (size_t)N * S;
+    const uint32_t *mp = masks + (size_t)plan.plane[lvl] * B;
+    const float *gl = grad_features + (size_t)lvl * B * C;
+#define UCN_CMP(H, P2, CO) cmp_block<C, H, P2, CO>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+    if (plan.coarse[lvl]) {                                                   // all workgroup-uniform
+        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true); else UCN_CMP(true, false, true); }
+        else { if (lv.mask) UCN_CMP(false, true, true); else UCN_CMP(false, false, true); }
+    } else {
+        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false); else UCN_CMP(true, false, false); }
+        else { if (lv.mask) UCN_CMP(false, true, false); else UCN_CMP(false, false, false); }
+    }
+#undef UCN_CMP
+    __syncthreads();
+#if defined(UCN_EXP_NOFLUSH)
+    return;
+#endif
     float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
     for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
         const float v = s_acc[i];
@@ -731,7 +1029,13 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     return 0;
 }
 
-extern "C" uint64_t ucn_march_features_backward_ws_floats(uint32_t N, uint32_t S) { return 24ull * N * S; }
+extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S) {
+    UcnLevels lv;
+    if (field_levels(f, &lv)) return 0;
+    MaskPlan plan;
+    const bool masks = make_mask_plan(lv, 128u * 1024u / (lv.C * 4u), &plan);
+    return (24ull + (masks ? plan.n_planes : 0u)) * N * S;      // geometry planes + block-mask planes
+}
 
 extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                            const float *origins, const float *directions, const float *basis,
@@ -761,6 +1065,25 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
             blocks += nb;
             tasks += nb * bwd_sample_split(nb);
+        }
+        MaskPlan plan;
+        if (workspace && layout == 0 && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
+            // compacting variant: block masks next to the geometry planes, dense items from a per-wave ring in LDS
+            uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
+            hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
+                               grad_features, lv.C, workspace, masks);
+#define UCN_MBC(CC)                                                                                              \
+    hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, \
+                       lv, grad_embeddings, N, S, rpb, plan, grad_features, workspace, masks)
+            switch (lv.C) {
+                case 1: UCN_MBC(1); break;
+                case 2: UCN_MBC(2); break;
+                case 4: UCN_MBC(4); break;
+                case 8: UCN_MBC(8); break;
+            }
+#undef UCN_MBC
+            UCN_LAUNCH_CHECK("march_features_backward (row blocks, compacted)");
+            return 0;
         }
         if (blocks <= 64u * lv.L) {
             if (workspace)

@@ -54,7 +54,7 @@ class _FieldFeatures(torch.autograd.Function):
         # backward then streams its own level's 8 bytes per sample instead of striding through [N*S][L*C]
         enc = mlp.encoder
         g = g_feat.float().reshape(N * S, enc.num_levels, enc.level_dim).permute(1, 0, 2).contiguous()
-        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(N, S), device=g.device)
+        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.field()), N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
                                                    N, S, 0, 0, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
         return grad, None, None, None, None, None, None
