@@ -256,34 +256,80 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
 
 // acc[r][0..C) += v in the workgroup's LDS row block.  ds_add_f32 is serialised per LANE on gfx950 (measured with
 // tools/lds_atomic_bench.hip: 193 clk per wave instruction, 3 clk per active lane, whatever the addresses -- 40x
-// the integer ds_add_u32), so a row is updated with an 8-byte compare-and-swap loop instead: two channels per
-// ds_cmpst_rtn_b64, 37 clk per wave for 64 random rows, and still an exact fp32 add per addend (a lane only
-// retries when another lane changed the same row in between).
-template <uint32_t C>
+// the integer ds_add_u32).  An 8-byte compare-and-swap updates two channels per ds_cmpst_rtn_b64 in 24-37 clk per
+// wave when the lanes hit different rows, and is still an exact fp32 add per addend -- but a lane whose row was
+// changed in between has to retry, and on the coarser levels neighbouring lanes DO share rows.  So:
+//   CAS = false (coarse levels, run-merged updates): plain ds_add_f32, contention-proof;
+//   CAS = true  (fine levels): one compare-and-swap attempt, the lanes that lose fall back to ds_add_f32.
+template <uint32_t C, bool CAS>
 __device__ __forceinline__ void lds_row_add(float *acc, uint32_t r, const float (&v)[C]) {
-#if defined(UCN_EXP_NOADD)
-    if (v[0] == 123.456f) acc[r * C] = v[0];
-    return;
-#endif
+    if constexpr (CAS && (C % 2u == 0u)) {
 #pragma unroll
-    for (uint32_t c = 0; c + 1 < C; c += 2) {
-        unsigned long long *p = reinterpret_cast<unsigned long long *>(acc + r * C + c);
-        unsigned long long old = *p, seen;
-        do {
-            seen = old;
+        for (uint32_t c = 0; c < C; c += 2) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(acc + r * C + c);
+            const unsigned long long seen = *p;
             float2 t = __builtin_bit_cast(float2, seen);
             t.x += v[c];
             t.y += v[c + 1];
-            old = atomicCAS(p, seen, __builtin_bit_cast(unsigned long long, t));
-        } while (old != seen);
+            if (atomicCAS(p, seen, __builtin_bit_cast(unsigned long long, t)) != seen) {
+                atomicAdd(acc + r * C + c, v[c]);
+                atomicAdd(acc + r * C + c + 1, v[c + 1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) atomicAdd(acc + r * C + c, v[c]);
     }
-    if constexpr (C & 1u) {
-        uint32_t *p = reinterpret_cast<uint32_t *>(acc + r * C + (C - 1));
-        uint32_t old = *p, seen;
-        do {
-            seen = old;
-            old = atomicCAS(p, seen, __float_as_uint(__uint_as_float(seen) + v[C - 1]));
-        } while (old != seen);
+}
+
+// Run merging for coarse levels: the six multisamples of a sample mostly sit in one lattice cell, and so do the
+// neighbouring samples of the ray -- the LDS updates of such a level serialise on a handful of rows (level 0 of
+// the benchmark grid took 16x a fine level).  Consecutive points with the same 8 rows are summed in registers
+// first: 8 row updates per RUN instead of per point.  The state is carried by the caller, so a lane that walks
+// several consecutive samples (the compacted kernel) keeps merging across them.
+// (A rows-only pre-pass that drops samples without a corner in this block was tried: with 64 lanes per wave
+//  some lane almost always stays, so the wave pays the pre-pass AND the full path -- 25 % slower.)
+template <uint32_t C>
+struct RowRun {
+    uint32_t cur[8];
+    float v[8][C];
+    bool have;
+};
+
+template <uint32_t C>
+__device__ __forceinline__ void run_flush(float *__restrict__ acc, uint32_t row_lo, uint32_t nrows, const RowRun<C> &run) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t r = run.cur[k] - row_lo;
+        if (r < nrows) lds_row_add<C, false>(acc, r, run.v[k]);
+    }
+}
+
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void run_merge_sample(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+                                                 const float (&u)[6][3], const float (&rs)[6], const float (&gout)[C],
+                                                 RowRun<C> &run) {
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            float fx, fy, fz, w[8];
+            uint32_t rows[8];
+            corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+            corner_weights(fx, fy, fz, w);
+            const float damp = erf_pos(rs[j] * lv.inv_gs);
+            bool same = run.have;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) same = same && rows[k] == run.cur[k];
+            if (run.have && !same) run_flush<C>(acc, row_lo, nrows, run);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const float wd = w[k] * damp;
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) run.v[k][c] = same ? run.v[k][c] + wd * gout[c] : wd * gout[c];
+                run.cur[k] = rows[k];
+            }
+            run.have = true;
+        }
     }
 }
 
@@ -294,48 +340,10 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
                                                     uint32_t nrows, const float (&u)[6][3], const float (&rs)[6],
                                                     const float (&gout)[C]) {
     if constexpr (MERGE) {
-        // Coarse levels: the six multisamples mostly sit in one lattice cell, and so do the neighbouring
-        // samples of the wave -- the LDS atomics of such a level serialise on a handful of addresses (level 0 of
-        // the benchmark grid took 16x a fine level).  Runs of multisamples with the same 8 rows are summed in
-        // registers first: 8*C atomics per run instead of per multisample.
-        // (A rows-only pre-pass that drops samples without a corner in this block was tried: with 64 lanes per wave
-        //  some lane almost always stays, so the wave pays the pre-pass AND the full path -- 25 % slower.)
-        uint32_t cur[8];
-        float wsum[8];
-        bool have = false;
-        auto flush = [&]() {
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t r = cur[k] - row_lo;
-                if (r < nrows) {
-                    float v[C];
-#pragma unroll
-                    for (uint32_t c = 0; c < C; c++) v[c] = wsum[k] * gout[c];
-                    lds_row_add<C>(acc, r, v);
-                }
-            }
-        };
-#pragma unroll
-        for (uint32_t j = 0; j < 6; j++) {
-            if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
-                float fx, fy, fz, w[8];
-                uint32_t rows[8];
-                corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
-                corner_weights(fx, fy, fz, w);
-                const float damp = erf_pos(rs[j] * lv.inv_gs);
-                bool same = have;
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) same = same && rows[k] == cur[k];
-                if (have && !same) flush();
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) {
-                    wsum[k] = same ? wsum[k] + w[k] * damp : w[k] * damp;
-                    cur[k] = rows[k];
-                }
-                have = true;
-            }
-        }
-        if (have) flush();
+        RowRun<C> run;
+        run.have = false;
+        run_merge_sample<C, HASHED, POW2>(lv, acc, row_lo, nrows, u, rs, gout, run);
+        if (run.have) run_flush<C>(acc, row_lo, nrows, run);
         return;
     }
 #pragma unroll
@@ -360,7 +368,7 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
                         float v[C];
 #pragma unroll
                         for (uint32_t c = 0; c < C; c++) v[c] = (w[k] * damp) * gout[c];
-                        lds_row_add<C>(acc, rows[k], v);
+                        lds_row_add<C, true>(acc, rows[k], v);
                     }
             }
         }
@@ -607,8 +615,9 @@ __global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx,
 }
 
 // ---- block masks: which row blocks of a level a sample touches.  Planes of [N*S] uint32 behind the 24 geometry
-// planes; a COARSE level (resolution <= 2048, the run-merging path) has one plane = union over its 48 corners,
-// a fine level six planes, one per multisample.  Bit p = some corner's row lies in block p (rows >> shift).
+// planes; a COARSE level (resolution <= 512: items are whole samples, run-merged; coarse = 2 up to resolution 64:
+// a lane walks consecutive samples) has one plane = union over its 48 corners, a fine level six planes, one per
+// multisample.  Bit p = some corner's row lies in block p (rows >> shift).
 struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
     uint8_t coarse[UCN_MAX_LEVELS];
@@ -622,7 +631,10 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     mp->n_planes = 0;
     for (uint32_t l = 0; l < lv.L; l++) {
         if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
-        mp->coarse[l] = lv.lv[l].resolution <= 2048u ? 1 : 0;
+        // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
+        // resolution 512, walking consecutive samples in one lane up to 64
+        mp->coarse[l] = lv.lv[l].resolution <= 512u ? 1 : 0;
+        if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
         mp->plane[l] = (uint16_t)mp->n_planes;
         mp->n_planes += mp->coarse[l] ? 1u : 6u;
     }
@@ -700,7 +712,7 @@ __device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, float *_
             float v[C];
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) v[c] = (w[k] * damp) * gout[c];
-            lds_row_add<C>(acc, r, v);
+            lds_row_add<C, true>(acc, r, v);
         }
     }
 }
@@ -813,7 +825,7 @@ __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, c
     }
 }
 
-template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
+template <uint32_t C, bool HASHED, bool POW2, bool COARSE, bool RUNS>
 __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
                                           uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                           const uint32_t *__restrict__ mp, const float *__restrict__ gl,
@@ -869,23 +881,51 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // up to 128 ring items, two per lane: both items' loads are in flight before the first scatter starts.
-        // Ring: <= 127 left over + <= 384 appended per step <= kQueue.
-        const uint32_t thr = more ? 128u : 1u;
+        // Ring: <= kPer * 64 - 1 left over + <= 384 (fine) / 64 (coarse) appended per step <= kQueue.
+        constexpr uint32_t kPer = RUNS ? 6u : 2u;                              // ring items per lane and round
+        const uint32_t thr = more ? kPer * 64u : 1u;
         while (tail - head >= thr && tail != head) {
-            const uint32_t avail = tail - head < 128u ? tail - head : 128u;
-            const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
-            const bool v0 = lane < avail, v1 = lane + 64u < avail;
-            float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
-            cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0);
-            cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
-            if (v0) {
-                if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
-                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
-            }
-            if (v1) {
-                if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
-                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+            const uint32_t avail = tail - head < kPer * 64u ? tail - head : kPer * 64u;
+            if constexpr (RUNS) {
+                // the coarsest levels (every sample of the ring is a neighbour of the previous one):
+                // a lane walks kPer CONSECUTIVE ring items (neighbouring samples of a ray) and keeps merging runs
+                // across them; the next item's geometry is requested before the current one is scattered
+                RowRun<C> run;
+                run.have = false;
+                float un[6][3], rsn[6], gn[C];
+                cmp_fetch<C, HASHED, POW2, true>(q[(head + kPer * lane) & (kQueue - 1u)], kPer * lane < avail, B, gl, geom, un, rsn, gn);
+#pragma unroll 1
+                for (uint32_t k = 0; k < kPer; k++) {
+                    float uc[6][3], rsc[6], gc[C];
+#pragma unroll
+                    for (uint32_t j = 0; j < 6; j++) {
+#pragma unroll
+                        for (uint32_t d = 0; d < 3; d++) uc[j][d] = un[j][d];
+                        rsc[j] = rsn[j];
+                    }
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) gc[c] = gn[c];
+                    const uint32_t idx = kPer * lane + k;
+                    if (k + 1 < kPer)
+                        cmp_fetch<C, HASHED, POW2, true>(q[(head + idx + 1u) & (kQueue - 1u)], idx + 1u < avail, B, gl, geom, un, rsn, gn);
+                    if (idx < avail) run_merge_sample<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, uc, rsc, gc, run);
+                }
+                if (run.have) run_flush<C>(s_acc, row_lo, nrows, run);
+            } else {
+                // two items per lane: both items' loads are in flight before the first scatter starts
+                const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
+                const bool v0 = lane < avail, v1 = lane + 64u < avail;
+                float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
+                cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0);
+                cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
+                if (v0) {
+                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
+                    else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
+                }
+                if (v1) {
+                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
+                    else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+                }
             }
             head += avail;
         }
@@ -917,19 +957,19 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
     const size_t B = (size_t)N * S;
     const uint32_t *mp = masks + (size_t)plan.plane[lvl] * B;
     const float *gl = grad_features + (size_t)lvl * B * C;
-#define UCN_CMP(H, P2, CO) cmp_block<C, H, P2, CO>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
-    if (plan.coarse[lvl]) {                                                   // all workgroup-uniform
-        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true); else UCN_CMP(true, false, true); }
-        else { if (lv.mask) UCN_CMP(false, true, true); else UCN_CMP(false, false, true); }
+#define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+    if (plan.coarse[lvl] == 2) {                                              // all workgroup-uniform; the coarsest
+        if (lv.mask) UCN_CMP(false, true, true, true);                        // levels are never hashed
+        else UCN_CMP(false, false, true, true);
+    } else if (plan.coarse[lvl]) {
+        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true, false); else UCN_CMP(true, false, true, false); }
+        else { if (lv.mask) UCN_CMP(false, true, true, false); else UCN_CMP(false, false, true, false); }
     } else {
-        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false); else UCN_CMP(true, false, false); }
-        else { if (lv.mask) UCN_CMP(false, true, false); else UCN_CMP(false, false, false); }
+        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false, false); else UCN_CMP(true, false, false, false); }
+        else { if (lv.mask) UCN_CMP(false, true, false, false); else UCN_CMP(false, false, false, false); }
     }
 #undef UCN_CMP
     __syncthreads();
-#if defined(UCN_EXP_NOFLUSH)
-    return;
-#endif
     float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
     for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
         const float v = s_acc[i];
