@@ -76,38 +76,54 @@ class GradientScaler(torch.autograd.Function):
 
 
 class _TallLinear(torch.autograd.Function):
-    """F.linear for a tall activation matrix [M ~ 1e6, K] and a small weight [N <= 256, K].
+    """x @ weight.T (+ bias | + acc) for a tall activation matrix [M ~ 1e6, K] and a small weight [N <= 256, K].
 
-    The library's weight-gradient GEMM dY^T X (N x K output, reduction over the M samples) gets a single
-    64x64 macro-tile grid -- 36 workgroups on a 256-CU part, 1.75 ms per call -- because nothing splits the
-    reduction.  Here the reduction is cut into chunks that run as one batched GEMM and are summed afterwards
-    (the same addends in a different order; fp32 accumulation inside each chunk and across chunks)."""
+    * The library's weight-gradient GEMM dY^T X (N x K output, reduction over the M samples) gets a single
+      64x64 macro-tile grid -- 36 workgroups on a 256-CU part, 1.75 ms per call -- because nothing splits the
+      reduction.  Here the reduction is cut into chunks that run as one batched GEMM and are summed afterwards
+      (the same addends in a different order; fp32 accumulation inside each chunk and across chunks).
+    * The bias gradient (column sums of dY) is a batched ones-row GEMM over the same chunks instead of an fp32
+      copy of dY plus a reduction kernel.
+    * `extra` is either a bias [N] or an accumulator [M, N] (the partial sum of another GEMM of the same layer:
+      the concatenations of the reference's colour MLP are never materialised, see field_heads)."""
     CHUNK = 8192
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, extra):
         dt = torch.get_autocast_dtype("cuda")                      # bf16 under the reference's accelerator.autocast()
         xb, wb = x.to(dt), weight.to(dt)
         ctx.save_for_backward(xb, wb)
-        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.dtypes = (x.dtype, weight.dtype, None if extra is None else extra.dtype)
+        ctx.extra_is_acc = extra is not None and extra.dim() == 2
         with torch.autocast("cuda", enabled=False):
-            return F.linear(xb, wb, None if bias is None else bias.to(dt))
+            if ctx.extra_is_acc:
+                return torch.addmm(extra.to(dt), xb.reshape(-1, xb.shape[-1]), wb.t())
+            return F.linear(xb, wb, None if extra is None else extra.to(dt))
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        x_dt, w_dt, b_dt = ctx.dtypes
+        x_dt, w_dt, e_dt = ctx.dtypes
         with torch.autocast("cuda", enabled=False):
             gy2 = gy.reshape(-1, gy.shape[-1]).to(x.dtype)
             x2 = x.reshape(-1, x.shape[-1])
             gx = (gy2 @ weight).reshape(x.shape).to(x_dt) if ctx.needs_input_grad[0] else None
             m, c = x2.shape[0], _TallLinear.CHUNK
-            if m >= 4 * c and m % c == 0:
-                gw = torch.bmm(gy2.reshape(m // c, c, -1).transpose(1, 2), x2.reshape(m // c, c, -1)).float().sum(0)
+            chunked = m >= 4 * c and m % c == 0
+            if chunked:
+                gyc = gy2.reshape(m // c, c, -1)
+                gw = torch.bmm(gyc.transpose(1, 2), x2.reshape(m // c, c, -1)).float().sum(0)
             else:
                 gw = (gy2.t() @ x2).float()
-            gb = None if b_dt is None else gy2.float().sum(0).to(b_dt)
-        return gx, gw.to(w_dt), gb
+            if e_dt is None:
+                ge = None
+            elif ctx.extra_is_acc:
+                ge = gy2.to(e_dt)
+            elif chunked:
+                ge = torch.bmm(gy2.new_ones(m // c, 1, c), gyc).float().sum(dim=(0, 1)).to(e_dt)
+            else:
+                ge = gy2.float().sum(0).to(e_dt)
+        return gx, gw.to(w_dt), ge
 
 
 def tall_linear(lin, x):
@@ -115,6 +131,14 @@ def tall_linear(lin, x):
     if torch.is_autocast_enabled():
         return _TallLinear.apply(x, lin.weight, lin.bias)
     return F.linear(x, lin.weight, lin.bias)
+
+
+def tall_matmul(x, weight, acc=None):
+    """x @ weight.T (+ acc [M, N]) through _TallLinear under autocast."""
+    if torch.is_autocast_enabled():
+        return _TallLinear.apply(x, weight, acc)
+    y = x @ weight.t()
+    return y if acc is None else y + acc
 
 
 def view_encoding(d, deg):
@@ -125,21 +149,31 @@ def view_encoding(d, deg):
 
 
 def field_heads(mlp, feat, viewdirs, N, S):
-    """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs)."""
-    x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat))).reshape(N, S, -1)
-    density = F.softplus(x[..., 0] + mlp.density_bias)
+    """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs).
+
+    The reference concatenates [bottleneck, dir_enc] (and [h, bottleneck, dir_enc] after the skip layer) per SAMPLE
+    and multiplies by one weight.  The same product is formed here column block by column block: per-sample blocks
+    as GEMMs that accumulate into one output, the per-RAY direction block (and the layer bias) as one small
+    [N, 27] GEMM broadcast over the samples -- no [N*S, 283] / [N*S, 539] concatenations, 7 % fewer flops, and the
+    bias / direction-weight gradients reduce over rays instead of samples."""
+    x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
+    density = F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias)
     if mlp.disable_rgb:
         return density, torch.zeros(N, S, 3, device=feat.device)
-    # under autocast x is bf16 and the next Linear rounds its whole input to bf16 anyway: casting the encoding first
-    # gives the same numbers without the fp32 [N,S,283] / [N,S,539] concatenations and their re-casts
-    enc = view_encoding(viewdirs, mlp.deg_view).to(x.dtype)[:, None, :].expand(N, S, -1)
-    h = torch.cat([x, enc], dim=-1)
-    skip = h
+    enc = view_encoding(viewdirs, mlp.deg_view)                                                  # [N, 27], per ray
+    per_sample, skip, with_enc = [x], [x], True            # column blocks of the next layer's input, in cat order
     for i in range(mlp.net_depth_viewdirs):
-        h = F.relu(tall_linear(mlp.get_submodule(f"lin_second_stage_{i}"), h))
-        if i == mlp.skip_layer_dir:
-            h = torch.cat([h, skip], dim=-1)
-    rgb = torch.sigmoid(mlp.rgb_premultiplier * tall_linear(mlp.rgb_layer, h) + mlp.rgb_bias)
+        lin = mlp.get_submodule(f"lin_second_stage_{i}")
+        col, pre = 0, None
+        for blk in per_sample:
+            pre = tall_matmul(blk, lin.weight[:, col:col + blk.shape[-1]], pre)
+            col += blk.shape[-1]
+        per_ray = F.linear(enc, lin.weight[:, col:], lin.bias) if with_enc else lin.bias[None, :]   # [N | 1, width]
+        h = F.relu(pre.reshape(N, S, -1) + per_ray[:, None, :].to(pre.dtype)).reshape(N * S, -1)
+        with_enc = i == mlp.skip_layer_dir                  # the direction block enters at layer 0 and after the skip
+        per_sample = [h] + skip if with_enc else [h]
+    assert len(per_sample) == 1, "skip connection into the rgb layer is not part of the reference configs"
+    rgb = torch.sigmoid(mlp.rgb_premultiplier * tall_linear(mlp.rgb_layer, h).reshape(N, S, -1) + mlp.rgb_bias)
     return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
 
 
@@ -164,11 +198,35 @@ def composite(rgbs, weights, tdist, bg):
     return dict(rgb=rgb, depth=depth, acc=acc)
 
 
+class _HashDecay(torch.autograd.Function):
+    """sum_rows sum_c emb[r, c]^2 * w[r]: one pass over the table forward, one backward (the per-level slices of
+    the reference's formulation cost 16 full-table zero-fills and adds in autograd)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, emb, w):
+        ctx.save_for_backward(emb, w)
+        return torch.dot(emb.square().sum(dim=1), w)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        emb, w = ctx.saved_tensors
+        return emb * (w * (2.0 * g))[:, None], None
+
+
 def hash_decay(mlp):
     """models.py:297-306: mean over levels and channels of the per-level mean of embeddings^2
-    (torch_scatter.segment_coo(reduce='mean') over the sorted level index, restated with slices)."""
-    emb, off = mlp.encoder.embeddings, mlp.encoder._offsets_np
-    return torch.stack([(emb[int(off[i]):int(off[i + 1])] ** 2).mean(dim=0) for i in range(len(off) - 1)]).mean()
+    (torch_scatter.segment_coo(reduce='mean') over the sorted level index), restated as one weighted sum with
+    w[row] = 1 / (rows_of_its_level * L * C)."""
+    enc = mlp.encoder
+    w = getattr(enc, "_decay_w", None)
+    if w is None or w.device != enc.embeddings.device:
+        off = enc._offsets_np
+        n = torch.tensor([int(off[i + 1]) - int(off[i]) for i in range(len(off) - 1)], device=enc.embeddings.device)
+        w = torch.repeat_interleave(1.0 / (n.double() * len(n) * enc.embeddings.shape[1]), n).float()
+        enc._decay_w = w
+    return _HashDecay.apply(enc.embeddings, w)
 
 
 def sky_forward(net, origins, directions, cam_dirs, far):
