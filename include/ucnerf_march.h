@@ -135,14 +135,17 @@ int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, con
  * grad_embeddings [rows, level_dim] is accumulated into (pre-zero it, like grid.py:77).
  * levels_per_block = 0 picks the algorithm: row-block ownership in LDS without global atomics while the
  * table has <= 64 blocks of 128 KiB per level, else the atomic scatter; >= 1 forces the atomic scatter.
- * sample_major: 0 = grad_features [num_levels][N*S][level_dim] (preferred), 1 = [N*S][num_levels*level_dim]. */
+ * sample_major: 0 = grad_features [num_levels][N*S][level_dim], 1 = [N*S][num_levels*level_dim] (what autograd
+ * hands to grid.py:68), 3 = [num_levels*level_dim][N*S] (the output of a transposed dgrad GEMM; row-block
+ * algorithms only). */
 int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                 const float *origins, const float *directions, const float *basis,
                                 const float *radii, const float *flip, const float *spin, float std_scale,
                                 uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
                                 const float *grad_features, float *grad_embeddings,
                                 float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(f,N,S) floats (24 planes of
-                                                   sample geometry + per-level row-block masks), or NULL: the row-block
+                                                   sample geometry + per-level row-block masks + a level-major copy
+                                                   of a layout-1/3 gradient), or NULL: the row-block
                                                    algorithm then re-derives the geometry in every workgroup and
                                                    cannot compact its work (several times slower)*/,
                                 ucn_stream_t stream);

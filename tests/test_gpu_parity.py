@@ -387,9 +387,15 @@ def test_features_backward_algorithms_agree():
     want = run(1, 0, g0)                                      # atomic scatter
     assert float(want.abs().max()) > 0
     tol = 2e-5 * float(want.abs().max())                      # same addends, different summation order
-    assert H.maxdiff(run(0, 0, g0, ws), want) <= tol          # row blocks, cached geometry, level-major gradient
+    g3 = g0.permute(0, 2, 1).contiguous()                     # [L*C][N*S]
+    assert H.maxdiff(run(0, 0, g0, ws), want) <= tol          # compacted row blocks, level-major gradient
     assert H.maxdiff(run(0, 0, g0), want) <= tol              # row blocks, geometry re-derived per workgroup
-    assert H.maxdiff(run(0, 1, g1, ws), want) <= tol          # row blocks, sample-major gradient
+    assert H.maxdiff(run(0, 1, g1, ws), want) <= tol          # compacted row blocks, sample-major gradient (autograd's)
+    assert H.maxdiff(run(0, 1, g1), want) <= tol
+    assert H.maxdiff(run(0, 3, g3, ws), want) <= tol          # compacted row blocks, feature-major gradient
+    assert H.maxdiff(run(0, 3, g3), want) <= tol
+    with pytest.raises(RuntimeError, match="layout 3"):
+        run(1, 3, g3)
     assert H.maxdiff(run(4, 1, g1), want) <= tol
     twice = run(0, 0, g0, ws, run(0, 0, g0, ws))              # accumulates into grad_embeddings
     assert H.maxdiff(twice, 2 * want) <= 2 * tol

@@ -618,6 +618,17 @@ __global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx,
 // planes; a COARSE level (resolution <= 512: items are whole samples, run-merged; coarse = 2 up to resolution 64:
 // a lane walks consecutive samples) has one plane = union over its 48 corners, a fine level six planes, one per
 // multisample.  Bit p = some corner's row lies in block p (rows >> shift).
+// Where element (level, sample b, channel c) of the feature gradient lives: level * L + b * S + c * Cs floats.
+//   layout 0 = [L][B][C]   1 = [B][L*C] (what autograd hands over)   3 = [L*C][B] (a transposed dgrad GEMM)
+struct GradStrides {
+    size_t level, sample, chan;
+};
+static GradStrides grad_strides(int layout, size_t B, uint32_t L, uint32_t C) {
+    if (layout == 1) return {C, (size_t)L * C, 1};
+    if (layout == 3) return {(size_t)C * B, 1, B};
+    return {B * C, C, 1};
+}
+
 struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
     uint8_t coarse[UCN_MAX_LEVELS];
@@ -655,8 +666,9 @@ __device__ __forceinline__ uint32_t point_block_mask(const UcnLevel &lv, uint32_
 // geometry planes + block masks of every sample, once per backward call
 __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInputs in, HexPattern hx, float std_scale,
                                                           uint32_t N, uint32_t S, MaskPlan plan,
-                                                          const float *__restrict__ grad_features /*[L][N*S][C]*/, uint32_t C,
-                                                          float *__restrict__ geom, uint32_t *__restrict__ masks) {
+                                                          const float *__restrict__ grad_features, GradStrides gs, uint32_t C,
+                                                          float *__restrict__ geom, uint32_t *__restrict__ masks,
+                                                          float *__restrict__ grad_level_major /*[L][N*S][C] or NULL*/) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b >= B) return;
@@ -680,7 +692,12 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         // a sample whose feature gradient on this level is exactly zero contributes nothing: clear its masks here
         // so that the scanning workgroups never have to look at the gradient
         bool nz = false;
-        for (uint32_t c = 0; c < C; c++) nz |= grad_features[((size_t)lvl * B + b) * C + c] != 0.0f;
+        for (uint32_t c = 0; c < C; c++) {
+            const float g = grad_features[lvl * gs.level + b * gs.sample + c * gs.chan];
+            nz |= g != 0.0f;
+            // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample
+            if (grad_level_major) grad_level_major[((size_t)lvl * B + b) * C + c] = g;
+        }
         if (!nz) {
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
@@ -724,7 +741,7 @@ __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in
 template <uint32_t C>
 __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls, float *__restrict__ grad_table,
                                                                  RayInputs in, HexPattern hx, float std_scale, uint32_t N,
-                                                                 uint32_t S, int layout, uint32_t rpb,
+                                                                 uint32_t S, GradStrides gs, uint32_t rpb,
                                                                  const float *__restrict__ grad_features,
                                                                  const float *__restrict__ geom) {
     extern __shared__ float s_acc[];
@@ -741,16 +758,15 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
     for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) s_acc[i] = 0.0f;
     __syncthreads();
     const size_t B = (size_t)N * S;
-    const uint32_t F = lvls.L * C;
     // a level with few blocks (the dense coarse ones) is cut along the samples too: `split` workgroups per
     // block, interleaved in units of 1024 samples; they share the block, so their flush is atomic
     for (size_t b = (size_t)part * 1024u + threadIdx.x; b < B; b += (size_t)split * 1024u) {
-        const float *gp = layout == 1 ? grad_features + b * F + (size_t)lvl * C : grad_features + ((size_t)lvl * B + b) * C;
+        const float *gp = grad_features + lvl * gs.level + b * gs.sample;
         float gout[C];
         bool nz = false;
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) {
-            gout[c] = gp[c] / 6.0f;                                     // d(mean over the 6 multisamples)
+            gout[c] = gp[c * gs.chan] / 6.0f;                           // d(mean over the 6 multisamples)
             nz |= gout[c] != 0.0f;
         }
         if (!nz) continue;
@@ -1074,7 +1090,8 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     if (field_levels(f, &lv)) return 0;
     MaskPlan plan;
     const bool masks = make_mask_plan(lv, 128u * 1024u / (lv.C * 4u), &plan);
-    return (24ull + (masks ? plan.n_planes : 0u)) * N * S;      // geometry planes + block-mask planes
+    // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
+    return (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * N * S;
 }
 
 extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
@@ -1086,7 +1103,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
                 "march_features_backward: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
-    UCN_REQUIRE(layout == 0 || layout == 1, "march_features_backward: layout must be 0 or 1");
+    UCN_REQUIRE(layout == 0 || layout == 1 || layout == 3, "march_features_backward: layout must be 0, 1 or 3");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
@@ -1094,6 +1111,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
+    const GradStrides gs = grad_strides(layout, B, lv.L, lv.C);
     hipStream_t st = (hipStream_t)stream;
     if (levels_per_block == 0) {
         // row-block ownership (no global atomics) while the recomputation stays cheap: every block walks
@@ -1107,14 +1125,15 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             tasks += nb * bwd_sample_split(nb);
         }
         MaskPlan plan;
-        if (workspace && layout == 0 && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
+        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
             // compacting variant: block masks next to the geometry planes, dense items from a per-wave ring in LDS
             uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
+            float *glm = layout == 0 ? nullptr : workspace + (24ull + plan.n_planes) * B;     // level-major copy
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
-                               grad_features, lv.C, workspace, masks);
+                               grad_features, gs, lv.C, workspace, masks, glm);
 #define UCN_MBC(CC)                                                                                              \
     hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, \
-                       lv, grad_embeddings, N, S, rpb, plan, grad_features, workspace, masks)
+                       lv, grad_embeddings, N, S, rpb, plan, glm ? glm : grad_features, workspace, masks)
             switch (lv.C) {
                 case 1: UCN_MBC(1); break;
                 case 2: UCN_MBC(2); break;
@@ -1130,7 +1149,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
                 hipLaunchKernelGGL(k_cast_cache, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, in, hx, std_scale, N, S, workspace);
 #define UCN_MBB(CC)                                                                                              \
     hipLaunchKernelGGL(k_march_features_bwd_blk<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4, st, lv,      \
-                       grad_embeddings, in, hx, std_scale, N, S, layout, rpb, grad_features, workspace)
+                       grad_embeddings, in, hx, std_scale, N, S, gs, rpb, grad_features, workspace)
             switch (lv.C) {
                 case 1: UCN_MBB(1); break;
                 case 2: UCN_MBB(2); break;
@@ -1143,6 +1162,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
         }
         levels_per_block = 1;
     }
+    UCN_REQUIRE(layout != 3, "march_features_backward: layout 3 is a row-block layout (levels_per_block = 0, <= 64 blocks per level)");
     const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
 #define UCN_MB(CC)                                                                                                  \
     hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \

@@ -50,13 +50,18 @@ class _FieldFeatures(torch.autograd.Function):
         mlp = ctx.mlp
         emb = mlp.encoder.embeddings
         grad = torch.zeros_like(emb)                                   # dense, like grid.py:77
-        # level-major copy of the feature gradient ([L][N*S][C]): every (level, row block) workgroup of the
-        # backward then streams its own level's 8 bytes per sample instead of striding through [N*S][L*C]
-        enc = mlp.encoder
-        g = g_feat.float().reshape(N * S, enc.num_levels, enc.level_dim).permute(1, 0, 2).contiguous()
+        # the feature gradient is consumed where autograd left it: [N*S][L*C] (layout 1) or, if a producer hands a
+        # transposed view of [L*C][N*S] (_TallLinear grad_t; measured no faster than layout 1), layout 3 -- no
+        # permuted level-major copy
+        B = N * S
+        g = g_feat if g_feat.dtype == torch.float32 else g_feat.float()
+        if g.dim() == 2 and g.stride() == (1, B):
+            layout = 3
+        else:
+            g, layout = g.contiguous(), 1
         ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.field()), N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
-                                                   N, S, 0, 0, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
+                                                   N, S, 0, layout, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
         return grad, None, None, None, None, None, None
 
 
@@ -89,7 +94,8 @@ class _TallLinear(torch.autograd.Function):
     CHUNK = 8192
 
     @staticmethod
-    def forward(ctx, x, weight, extra):
+    def forward(ctx, x, weight, extra, grad_t=False):
+        ctx.grad_t = grad_t
         dt = torch.get_autocast_dtype("cuda")                      # bf16 under the reference's accelerator.autocast()
         xb, wb = x.to(dt), weight.to(dt)
         ctx.save_for_backward(xb, wb)
@@ -107,7 +113,12 @@ class _TallLinear(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             gy2 = gy.reshape(-1, gy.shape[-1]).to(x.dtype)
             x2 = x.reshape(-1, x.shape[-1])
-            gx = (gy2 @ weight).reshape(x.shape).to(x_dt) if ctx.needs_input_grad[0] else None
+            if not ctx.needs_input_grad[0]:
+                gx = None
+            elif ctx.grad_t:                                     # [K, M] written by the GEMM, handed on as its transpose
+                gx = (weight.t() @ gy2.t()).to(x_dt).t()
+            else:
+                gx = (gy2 @ weight).reshape(x.shape).to(x_dt)
             m, c = x2.shape[0], _TallLinear.CHUNK
             chunked = m >= 4 * c and m % c == 0
             if chunked:
@@ -123,13 +134,14 @@ class _TallLinear(torch.autograd.Function):
                 ge = torch.bmm(gy2.new_ones(m // c, 1, c), gyc).float().sum(dim=(0, 1)).to(e_dt)
             else:
                 ge = gy2.float().sum(0).to(e_dt)
-        return gx, gw.to(w_dt), ge
+        return gx, gw.to(w_dt), ge, None
 
 
-def tall_linear(lin, x):
-    """nn.Linear `lin` applied through _TallLinear (autocast: operands in bf16 like F.linear under autocast)."""
+def tall_linear(lin, x, grad_t=False):
+    """nn.Linear `lin` applied through _TallLinear (autocast: operands in bf16 like F.linear under autocast).
+    grad_t: the input gradient comes back as the transpose of a contiguous [K, M] matrix (for _FieldFeatures)."""
     if torch.is_autocast_enabled():
-        return _TallLinear.apply(x, lin.weight, lin.bias)
+        return _TallLinear.apply(x, lin.weight, lin.bias, grad_t)
     return F.linear(x, lin.weight, lin.bias)
 
 
