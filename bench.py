@@ -176,7 +176,8 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
     model.eval()
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
                 autocast="bf16 GEMMs, fp32 tables/compositing",
-                graph="HIP resample + fused featurisation fwd/bwd; dense layers via library GEMMs (round 1)")
+                graph="HIP resample + fused featurisation fwd / bwd (LDS row blocks, no global atomics); dense layers as split "
+                      "library GEMMs without materialised concatenations")
 
 
 def main():
