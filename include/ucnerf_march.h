@@ -185,6 +185,16 @@ int ucn_composite(const float *density /*[N,S]*/, const float *rgbs /*[N,S,3]|NU
                   uint32_t S, float *weights_out /*[N,S]*/, float *out_main, float *out_extras,
                   ucn_stream_t stream);
 
+/* Backward of ucn_composite's differentiable outputs w.r.t. density and rgbs: what autograd derives from
+ * render.py:155-174 + :203-216 in the reference's training step (train.py:165-221).  g_weights [N,S]|NULL is the
+ * gradient arriving at `weights` directly (interlevel / distortion losses), g_main [N,5] the gradient of
+ * out_main (r,g,b,depth,acc).  g_rgbs NULL iff rgbs NULL. */
+int ucn_composite_backward(const float *density, const float *rgbs, const float *sdist, const float *near_,
+                           const float *far_, const float *directions, float bg_intensity,
+                           int opaque_background, uint32_t N, uint32_t S, const float *g_weights,
+                           const float *g_main, float *g_density /*[N,S]*/, float *g_rgbs /*[N,S,3]|NULL*/,
+                           ucn_stream_t stream);
+
 /* ------------------------------------------------- sky layer + colour correction
  * ref: models.py:326-337,743-904 (sky NeRF, 120 samples, 8x256 MLP) and
  * extrinsic_optimizer.py:4-48 + models.py:339-363 (per-camera 3x4 affine). */

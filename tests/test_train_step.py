@@ -156,3 +156,44 @@ def test_tall_linear_matches_library_linear_under_autocast():
     assert float((gb - gb_ref).abs().max()) <= 1e-2 * float(gb_ref.abs().max())
     y32 = tg.tall_linear(lin, x)                              # no autocast: the plain fp32 library path
     assert y32.dtype == torch.float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,opaque", [(64, False), (128, False), (37, True), (128, True)])
+def test_composite_backward_matches_oracle_autograd(S, opaque):
+    """ucn_composite + ucn_composite_backward (the training graph's _Composite) vs torch autograd through the oracle's
+    alpha_weights / composite (render.py:155-216) on the host: weights, rgb, depth, acc and the gradients of a loss
+    that uses all four (so every branch of the backward -- direct weight gradient, colour, background, acc, depth,
+    the 300-sentinel below acc 0.6 -- is exercised)."""
+    from ucnerf_amd.internal.train_graph import _Composite
+    g = torch.Generator().manual_seed(S + int(opaque))
+    N = 300
+    sdist = torch.sort(torch.rand(N, S + 1, generator=g), dim=-1).values
+    sdist[:, 0], sdist[:, -1] = 0.0, 1.0
+    near, far = torch.full((N, 1), 0.2), torch.full((N, 1), 6.0) + torch.rand(N, 1, generator=g)
+    dirs = torch.randn(N, 3, generator=g)
+    density = torch.rand(N, S, generator=g) * torch.rand(N, 1, generator=g) * 3        # some rays stay below acc 0.6
+    rgbs = torch.rand(N, S, 3, generator=g)
+    cw, cr, cd, ca = (torch.randn(N, S, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, generator=g),
+                      torch.randn(N, generator=g))
+    bg = 0.7
+
+    def loss_of(weights, rgb, depth, acc):
+        return (weights * cw).sum() + (rgb * cr).sum() + (depth * cd).sum() * 0.1 + (acc * ca).sum()
+
+    d0, r0 = density.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+    tdist = sdist * far + (1 - sdist) * near
+    w = rm.alpha_weights(d0, tdist, dirs, opaque)
+    out = rm.composite(r0, w, tdist, bg, far, extras=False)
+    loss_of(w, out["rgb"], out["depth"], out["acc"]).backward()
+
+    d1, r1 = density.cuda().requires_grad_(True), rgbs.cuda().requires_grad_(True)
+    w1, rgb1, dep1, acc1 = _Composite.apply(d1, r1, sdist.cuda(), near.cuda(), far.cuda(), dirs.cuda().contiguous(), bg, opaque)
+    (w1 * cw.cuda()).sum().add((rgb1 * cr.cuda()).sum()).add((dep1 * cd.cuda()).sum() * 0.1).add((acc1 * ca.cuda()).sum()).backward()
+    assert float((w1.cpu() - w).abs().max()) <= 2e-6
+    assert float((rgb1.cpu() - out["rgb"]).abs().max()) <= 5e-6
+    assert float((acc1.cpu() - out["acc"]).abs().max()) <= 5e-6
+    assert float((dep1.cpu() - out["depth"]).abs().max()) <= 5e-5                    # incl. the exact 300 sentinels
+    assert opaque or (int((out["acc"] < 0.6).sum()) > 0 and int((out["acc"] >= 0.6).sum()) > 0)   # opaque: acc == 1
+    for got, want in ((d1.grad.cpu(), d0.grad), (r1.grad.cpu(), r0.grad)):
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

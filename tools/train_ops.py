@@ -19,3 +19,18 @@ for e in rows[:60]:
     tot += ms
     print(f"{e.key[:42]:42s} {e.count / 4:10.1f} {ms:9.3f}  {str(e.input_shapes)[:110]}")
 print("listed", tot, "all", sum(e.self_device_time_total for e in rows) / 1e3 / 4)
+# small-tensor glue: ops whose largest input has <= 8192 * 130 * 3 elements
+import math
+small_ms, small_n, by = 0.0, 0, {}
+for e in rows:
+    if e.key.startswith(("void ", "Cijk", "Custom", "Memcpy", "Memset")) or "(anonymous" in e.key or "k_" in e.key[:3]:
+        continue
+    sizes = [math.prod(s) for s in e.input_shapes if isinstance(s, (list, tuple)) and len(s) > 0 and all(isinstance(x, int) for x in s)]
+    if not sizes or max(sizes) > 8192 * 130 * 3:
+        continue
+    ms = e.self_device_time_total / 1e3 / 4
+    small_ms += ms; small_n += e.count / 4
+    by[e.key] = (by.get(e.key, (0, 0))[0] + ms, by.get(e.key, (0, 0))[1] + e.count / 4)
+print(f"small-tensor ops: {small_ms:.3f} ms/step in {small_n:.0f} calls/step")
+for k, (ms, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:25]:
+    print(f"   {k[:40]:40s} {ms:7.3f} ms {n:6.1f} calls")

@@ -302,6 +302,106 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
     }
 }
 
+// Backward of k_composite's differentiable outputs (weights, rgb, depth, acc) w.r.t. density and rgbs: what autograd
+// derives from render.py:155-174 + :203-216, as one wave per ray.  With tau_i = density_i * delta_i,
+// w_i = (1 - e^{-tau_i}) T_i, T_i = exp(-sum_{k<i} tau_k):
+//     dL/dtau_j = G_j e^{-tau_j} T_j - sum_{i>j} G_i w_i,      G_i = total gradient arriving at w_i
+// (the suffix sum is a wave scan).  G collects the direct weight gradient (the losses on `weights`), rgb
+// (sum_i w_i c_i + bg * clamp_min(1 - acc, 0)), acc and depth (clip(nan_to_num(sum_i w_i tm_i / max(acc, eps))), 300
+// where acc < 0.6 -- constant there).
+template <int CH>
+__global__ __launch_bounds__(256) void k_composite_bwd(const float *__restrict__ density, const float *__restrict__ rgbs,
+                                                       const float *__restrict__ sdist, const float *__restrict__ near_,
+                                                       const float *__restrict__ far_, const float *__restrict__ dirs,
+                                                       float bg, int opaque, uint32_t N, uint32_t S,
+                                                       const float *__restrict__ g_weights, const float *__restrict__ g_main,
+                                                       float *__restrict__ g_density, float *__restrict__ g_rgbs) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ray = blockIdx.x * 4u + wv;
+    if (ray >= N) return;                                 // wave-uniform, no barriers below
+    const float nr = near_[ray], fr = far_[ray];
+    const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float *sd = sdist + (size_t)ray * (S + 1);
+    const float *gm = g_main + (size_t)ray * 5;
+    const float gr = gm[0], gg = gm[1], gb = gm[2], gdepth = gm[3], gacc = gm[4];
+    float tm[CH], scale[CH], tau[CH], w[CH], att[CH];
+    float lane_tau = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        tm[c] = scale[c] = tau[c] = 0.0f;
+        if (i < S) {
+            const float s0 = sd[i], s1 = sd[i + 1];
+            const float tlo = s0 * fr + (1.0f - s0) * nr, thi = s1 * fr + (1.0f - s1) * nr;
+            tm[c] = 0.5f * (tlo + thi);
+            scale[c] = (thi - tlo) * dnorm;
+            float td = density[(size_t)ray * S + i] * scale[c];
+            if (opaque && i == S - 1) { td = INFINITY; scale[c] = 0.0f; }       // a constant: no gradient to that density
+            tau[c] = td;
+        }
+        lane_tau += tau[c];
+    }
+    float before = __shfl_up(wave_scan(lane_tau, lane), 1, 64);
+    if (lane == 0) before = 0.0f;
+    float lane_w = 0.0f, dnum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        w[c] = att[c] = 0.0f;
+        if (i < S) {
+            const float e = expf(-tau[c]), trans = expf(-before);
+            w[c] = (1.0f - e) * trans;
+            att[c] = e * trans;                                               // dw_i / dtau_i
+            dnum += w[c] * tm[c];
+            before += tau[c];
+        }
+        lane_w += w[c];
+    }
+    const float acc = wave_sum(lane_w);
+    dnum = wave_sum(dnum);
+    // depth = clip(nan_to_num(dnum / max(acc, eps)), t_0, t_S), overwritten by 300 where acc < 0.6
+    const float t_first = sd[0] * fr + (1.0f - sd[0]) * nr, t_last = sd[S] * fr + (1.0f - sd[S]) * nr;
+    const float denom = fmaxf(acc, UCN_EPS);
+    const float draw = dnum / denom;
+    const bool dlive = gdepth != 0.0f && !(acc < 0.6f) && draw == draw && fabsf(draw) != INFINITY && draw >= t_first &&
+                       draw <= t_last;
+    const float gd_num = dlive ? gdepth / denom : 0.0f;                                        // d depth / d dnum
+    const float gd_acc = dlive && acc >= UCN_EPS ? -gdepth * draw / denom : 0.0f;              // through max(acc, eps)
+    const float g_bgw = (1.0f - acc >= 0.0f) ? -(gr + gg + gb) * bg : 0.0f;                    // clamp_min(1 - acc, 0)
+    float G[CH], lane_p = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        G[c] = 0.0f;
+        if (i < S) {
+            float g = gacc + g_bgw + gd_acc + gd_num * tm[c];
+            if (g_weights) g += g_weights[(size_t)ray * S + i];
+            if (rgbs) {
+                const float *col = rgbs + ((size_t)ray * S + i) * 3;
+                g += (gr * col[0] + gg * col[1]) + gb * col[2];
+                float *o = g_rgbs + ((size_t)ray * S + i) * 3;
+                o[0] = w[c] * gr; o[1] = w[c] * gg; o[2] = w[c] * gb;
+            }
+            G[c] = g;
+            lane_p += g * w[c];
+        }
+    }
+    // sum_{i > j} G_i w_i = total - inclusive prefix
+    const float incl_lane = wave_scan(lane_p, lane);
+    const float total = __shfl(incl_lane, 63, 64);
+    float incl = incl_lane - lane_p;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t i = lane * CH + c;
+        if (i < S) {
+            incl += G[c] * w[c];
+            const float gtau = G[c] * att[c] - (total - incl);
+            g_density[(size_t)ray * S + i] = gtau * scale[c];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ucn_resample(const float *sdist_prev, const float *weights_prev, uint32_t n_prev, float dilation,
@@ -354,5 +454,27 @@ extern "C" int ucn_composite(const float *density, const float *rgbs, const floa
     else UCN_CP(8);
 #undef UCN_CP
     UCN_LAUNCH_CHECK("composite");
+    return 0;
+}
+
+extern "C" int ucn_composite_backward(const float *density, const float *rgbs, const float *sdist, const float *near_,
+                                      const float *far_, const float *directions, float bg_intensity, int opaque_background,
+                                      uint32_t N, uint32_t S, const float *g_weights, const float *g_main,
+                                      float *g_density, float *g_rgbs, ucn_stream_t stream) {
+    UCN_REQUIRE(N == 0 || (density && sdist && near_ && far_ && directions && g_main && g_density), "composite_backward: null pointer argument");
+    UCN_REQUIRE((rgbs == nullptr) == (g_rgbs == nullptr), "composite_backward: rgbs and g_rgbs come together");
+    UCN_REQUIRE(S >= 1 && S <= 512, "composite_backward: samples per ray must be in [1,512], got %u", S);
+    if (N == 0) return 0;
+    const dim3 grid(ucn_div_up(N, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define UCN_CB(CH)                                                                                                \
+    hipLaunchKernelGGL(k_composite_bwd<CH>, grid, dim3(256), 0, st, density, rgbs, sdist, near_, far_, directions, \
+                       bg_intensity, opaque_background, N, S, g_weights, g_main, g_density, g_rgbs)
+    if (S <= 64) UCN_CB(1);
+    else if (S <= 128) UCN_CB(2);
+    else if (S <= 256) UCN_CB(4);
+    else UCN_CB(8);
+#undef UCN_CB
+    UCN_LAUNCH_CHECK("composite_backward");
     return 0;
 }

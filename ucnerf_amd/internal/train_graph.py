@@ -189,25 +189,45 @@ def field_heads(mlp, feat, viewdirs, N, S):
     return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
 
 
-def alpha_weights(density, tdist, dirs, opaque_background):
-    """render.py:155-174."""
-    tau = density * ((tdist[..., 1:] - tdist[..., :-1]) * torch.norm(dirs[..., None, :], dim=-1))
-    if opaque_background:
-        tau = torch.cat([tau[..., :-1], torch.full_like(tau[..., -1:], torch.inf)], dim=-1)
-    trans = torch.exp(-torch.cat([torch.zeros_like(tau[..., :1]), torch.cumsum(tau[..., :-1], dim=-1)], dim=-1))
-    return (1 - torch.exp(-tau)) * trans
+class _Composite(torch.autograd.Function):
+    """render.py:155-174 + :203-216 as the rendering kernel `ucn_composite` (forward) and `ucn_composite_backward`:
+    weights, rgb, depth, acc of N rays from density [N,S] and rgbs [N,S,3]; sample positions carry no gradient."""
 
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, density, rgbs, sdist, near, far, dirs, bg, opaque):
+        lib = _lib.load()
+        N, S = density.shape
+        density, rgbs = density.contiguous(), rgbs.contiguous()
+        weights = torch.empty(N, S, device=density.device)
+        main = torch.empty(N, 5, device=density.device)
+        _lib.check(lib.ucn_composite(density.data_ptr(), rgbs.data_ptr(), sdist.data_ptr(), near.data_ptr(), far.data_ptr(),
+                                     dirs.data_ptr(), float(bg), int(bool(opaque)), N, S, weights.data_ptr(), main.data_ptr(),
+                                     None, _lib.stream()))
+        ctx.save_for_backward(density, rgbs, sdist, near, far, dirs)
+        ctx.consts = (float(bg), int(bool(opaque)))
+        return weights, main[:, :3].contiguous(), main[:, 3].contiguous(), main[:, 4].contiguous()
 
-def composite(rgbs, weights, tdist, bg):
-    """render.py:203-216 (rgb / depth / acc; the distance extras are display-only and not differentiated)."""
-    acc = weights.sum(dim=-1)
-    bg_w = (1 - acc[..., None]).clamp_min(0.)
-    rgb = (weights[..., None] * rgbs).sum(dim=-2) + bg_w * bg
-    t_mid = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
-    depth = torch.nan_to_num((weights * t_mid).sum(dim=-1) / acc.clamp_min(EPS), torch.inf)
-    depth = torch.clip(depth, tdist[..., 0], tdist[..., -1]).clone()
-    depth[acc < 0.6] = 300
-    return dict(rgb=rgb, depth=depth, acc=acc)
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_w, g_rgb, g_depth, g_acc):
+        lib = _lib.load()
+        density, rgbs, sdist, near, far, dirs = ctx.saved_tensors
+        N, S = density.shape
+        g_main = torch.zeros(N, 5, device=density.device)
+        if g_rgb is not None:
+            g_main[:, :3] = g_rgb
+        if g_depth is not None:
+            g_main[:, 3] = g_depth
+        if g_acc is not None:
+            g_main[:, 4] = g_acc
+        g_w = None if g_w is None else g_w.float().contiguous()
+        g_density = torch.empty_like(density)
+        g_rgbs = torch.empty_like(rgbs)
+        _lib.check(lib.ucn_composite_backward(density.data_ptr(), rgbs.data_ptr(), sdist.data_ptr(), near.data_ptr(),
+                                              far.data_ptr(), dirs.data_ptr(), *ctx.consts, N, S, _lib.ptr(g_w),
+                                              g_main.data_ptr(), g_density.data_ptr(), g_rgbs.data_ptr(), _lib.stream()))
+        return g_density, g_rgbs, None, None, None, None, None, None
 
 
 class _HashDecay(torch.autograd.Function):
@@ -325,9 +345,9 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         density, rgbs = field_heads(mlp, feat, vd, N, S)
         if getattr(cfg, 'brightness_correction', False):              # models.py:233-235 (gated on this flag)
             rgbs, density = GradientScaler.apply(rgbs, density, tmean)
-        tdist = sdist * far + (1 - sdist) * near
-        weights = alpha_weights(density.float(), tdist, d, model.opaque_background)
-        rendering = composite(rgbs.float(), weights, tdist, float(model.bg_intensity_range[0]))
+        weights, c_rgb, c_depth, c_acc = _Composite.apply(density, rgbs, sdist, near, far, d,
+                                                          float(model.bg_intensity_range[0]), model.opaque_background)
+        rendering = dict(rgb=c_rgb, depth=c_depth, acc=c_acc)
         rendering = {k: v.reshape(prefix + v.shape[1:]) for k, v in rendering.items()}
         rendering['weights'] = weights.reshape(prefix + (S,))
         if compute_extras:
