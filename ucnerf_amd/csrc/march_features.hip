@@ -596,8 +596,9 @@ __global__ __launch_bounds__(256) void k_march_features_bwd(UcnLevels lvls, floa
 // their corners (VALU is cheap here) and accumulates the ones that fall in its block with ds_add_f32;
 // the block is then added to the table gradient with plain coalesced read-modify-writes -- no other
 // workgroup touches those rows.  blockIdx.x enumerates (level, block) pairs, level-major.
-// The six contracted multisample positions and damping arguments of every sample, as 24 planes of
-// [N*S] floats: written once per backward call, read by every (level, row block) workgroup.
+// The six contracted multisample positions and damping arguments of every sample, as [N*S][6] float4
+// {x, y, z, std argument} (one 16-byte load per point for the compacted kernel's scattered items): written once
+// per backward call, read by every (level, row block) workgroup.
 __global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx, float std_scale, uint32_t N, uint32_t S,
                                                     float *__restrict__ geom) {
     const size_t B = (size_t)N * S;
@@ -608,16 +609,15 @@ __global__ __launch_bounds__(256) void k_cast_cache(RayInputs in, HexPattern hx,
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) geom[(size_t)(j * 3 + d) * B + b] = u[j][d];
-        geom[(size_t)(18 + j) * B + b] = rs[j];
+        reinterpret_cast<float4 *>(geom)[b * 6 + j] = make_float4(u[j][0], u[j][1], u[j][2], rs[j]);
     }
 }
 
-// ---- block masks: which row blocks of a level a sample touches.  Planes of [N*S] uint32 behind the 24 geometry
-// planes; a COARSE level (resolution <= 512: items are whole samples, run-merged; coarse = 2 up to resolution 64:
-// a lane walks consecutive samples) has one plane = union over its 48 corners, a fine level six planes, one per
-// multisample.  Bit p = some corner's row lies in block p (rows >> shift).
+// ---- block masks: which row blocks of a level a sample touches.  Planes of [N*S] uint32 behind the geometry
+// cache; a COARSE level (resolution <= 512: items are whole samples, run-merged; coarse = 2 up to resolution 64:
+// a lane walks consecutive samples) has one plane = union over its 48 corners, bit p = some corner's row lies in
+// block p (rows >> shift); a fine level one plane per GROUP of four blocks, bit 4 * j + (p & 3) of word p >> 2 =
+// multisample j has a corner in block p -- either way a workgroup reads one word per sample.
 // Where element (level, sample b, channel c) of the feature gradient lives: level * L + b * S + c * Cs floats.
 //   layout 0 = [L][B][C]   1 = [B][L*C] (what autograd hands over)   3 = [L*C][B] (a transposed dgrad GEMM)
 struct GradStrides {
@@ -647,7 +647,7 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         mp->coarse[l] = lv.lv[l].resolution <= 512u ? 1 : 0;
         if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
         mp->plane[l] = (uint16_t)mp->n_planes;
-        mp->n_planes += mp->coarse[l] ? 1u : 6u;
+        mp->n_planes += mp->coarse[l] ? 1u : ((lv.lv[l].rows + rpb - 1) / rpb + 3u) / 4u;
     }
     return true;
 }
@@ -677,9 +677,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) geom[(size_t)(j * 3 + d) * B + b] = u[j][d];
-        geom[(size_t)(18 + j) * B + b] = rs[j];
+        reinterpret_cast<float4 *>(geom)[b * 6 + j] = make_float4(u[j][0], u[j][1], u[j][2], rs[j]);
     }
     for (uint32_t lvl = 0; lvl < lvls.L; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
@@ -706,8 +704,14 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         if (plan.coarse[lvl]) {
             mp[0] = m[0] | m[1] | m[2] | m[3] | m[4] | m[5];
         } else {
+            // word k = blocks 4k..4k+3, bit 4 * j + (block & 3) for multisample j: a workgroup reads ONE word per sample
+            const uint32_t groups = (((lv.rows + (1u << plan.shift) - 1u) >> plan.shift) + 3u) / 4u;
+            for (uint32_t k = 0; k < groups; k++) {
+                uint32_t wk = 0u;
 #pragma unroll
-            for (uint32_t j = 0; j < 6; j++) mp[(size_t)j * B] = m[j];
+                for (uint32_t j = 0; j < 6; j++) wk |= ((m[j] >> (4u * k)) & 15u) << (4u * j);
+                mp[(size_t)k * B] = wk;
+            }
         }
     }
 }
@@ -774,9 +778,8 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
         if (geom) {                                   // k_cast_cache's planes: every task re-reads, nobody re-derives
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) {
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) u[j][d] = geom[(size_t)(j * 3 + d) * B + b];
-                rs[j] = geom[(size_t)(18 + j) * B + b];
+                const float4 q = reinterpret_cast<const float4 *>(geom)[b * 6 + j];
+                u[j][0] = q.x; u[j][1] = q.y; u[j][2] = q.z; rs[j] = q.w;
             }
         } else {
             const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
@@ -830,14 +833,12 @@ __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, c
     if constexpr (COARSE) {
 #pragma unroll
         for (uint32_t jj = 0; jj < 6; jj++) {
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) u[jj][d] = geom[(size_t)(jj * 3 + d) * B + b];
-            rs[jj] = geom[(size_t)(18 + jj) * B + b];
+            const float4 q = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + jj];
+            u[jj][0] = q.x; u[jj][1] = q.y; u[jj][2] = q.z; rs[jj] = q.w;
         }
     } else {
-#pragma unroll
-        for (uint32_t d = 0; d < 3; d++) u[0][d] = geom[(size_t)(j * 3 + d) * B + b];
-        rs[0] = geom[(size_t)(18 + j) * B + b];
+        const float4 q = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + j];
+        u[0][0] = q.x; u[0][1] = q.y; u[0][2] = q.z; rs[0] = q.w;
     }
 }
 
@@ -846,17 +847,19 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                                           uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                           const uint32_t *__restrict__ mp, const float *__restrict__ gl,
                                           const float *__restrict__ geom) {
-    constexpr uint32_t P = COARSE ? 1u : 6u;                                  // mask planes of this level
+    // one mask word per sample: coarse levels bit `blk`; fine levels the word of this block's group of four,
+    // bit 4 * j + (blk & 3) for multisample j (k_cast_cache_masks)
+    constexpr uint32_t P = COARSE ? 1u : 6u;                                  // items a sample can contribute
+    const uint32_t bit0 = COARSE ? blk : (blk & 3u);
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t head = 0, tail = 0;                                              // wave-uniform ring positions
     const size_t stride = (size_t)split * kScan * 1024u;
     size_t base = (size_t)part * kScan * 1024u;
-    uint32_t cur[kScan][P], nxt[kScan][P];
+    uint32_t cur[kScan], nxt[kScan];
 #pragma unroll
     for (uint32_t u = 0; u < kScan; u++) {
         const size_t b = base + u * 1024u + threadIdx.x;
-#pragma unroll
-        for (uint32_t j = 0; j < P; j++) cur[u][j] = b < B ? mp[(size_t)j * B + b] : 0u;
+        cur[u] = b < B ? mp[b] : 0u;
     }
     // `split` workgroups share a block; they take the samples in interleaved units of kScan x 1024 (flush: atomic).
     // One workgroup per CU: the masks of the NEXT unit are requested before this unit's items are processed.
@@ -869,17 +872,17 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
 #pragma unroll
                 for (uint32_t uu = 0; uu < kScan; uu++) {
                     const size_t b = nb + uu * 1024u + threadIdx.x;
-#pragma unroll
-                    for (uint32_t j = 0; j < P; j++) nxt[uu][j] = b < B ? mp[(size_t)j * B + b] : 0u;
+                    nxt[uu] = b < B ? mp[b] : 0u;
                 }
             }
             const uint32_t b = (uint32_t)(base + u * 1024u + threadIdx.x);
+            uint32_t m = cur[0];                                              // u is wave-uniform: selects, no scratch
+#pragma unroll
+            for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu] : m;
+            m >>= bit0;
 #pragma unroll
             for (uint32_t j = 0; j < P; j++) {
-                uint32_t m = cur[0][j];                                       // u is wave-uniform: selects, no scratch
-#pragma unroll
-                for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu][j] : m;
-                const bool act = (m >> blk) & 1u;
+                const bool act = (m >> (4u * j)) & 1u;
                 const uint64_t bal = __ballot(act);
                 const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                 if (act) q[pos & (kQueue - 1u)] = b | (j << 29);
@@ -890,10 +893,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 base += stride;
                 more = base < B;
 #pragma unroll
-                for (uint32_t uu = 0; uu < kScan; uu++) {
-#pragma unroll
-                    for (uint32_t j = 0; j < P; j++) cur[uu][j] = nxt[uu][j];
-                }
+                for (uint32_t uu = 0; uu < kScan; uu++) cur[uu] = nxt[uu];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
     __syncthreads();
     uint32_t *q = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C) + (threadIdx.x >> 6) * kQueue;
     const size_t B = (size_t)N * S;
-    const uint32_t *mp = masks + (size_t)plan.plane[lvl] * B;
+    const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? 0u : blk >> 2)) * B;
     const float *gl = grad_features + (size_t)lvl * B * C;
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
     if (plan.coarse[lvl] == 2) {                                              // all workgroup-uniform; the coarsest
