@@ -195,6 +195,21 @@ int ucn_composite_backward(const float *density, const float *rgbs, const float 
                            const float *g_main, float *g_density /*[N,S]*/, float *g_rgbs /*[N,S,3]|NULL*/,
                            ucn_stream_t stream);
 
+/* ------------------------------------------------- ray generation
+ * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
+ * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the
+ * final float32 cast).  Computed in float64 with the reference's operation order, rounded once at the store.
+ * pix_x / pix_y DEVICE int32 [n_rays] or both NULL = every pixel of a width x height frame in 'xy' meshgrid order
+ * (camera_utils.py:368-370, n_rays = width*height).  cam_idx DEVICE int32 [n_rays] or NULL = cam_idx_scalar.
+ * pixtocams DEVICE double [n_cams,3,3] (inverse intrinsics), camtoworlds DEVICE double [n_cams,3,4].
+ * Outputs float32: origins/directions/viewdirs/cam_dirs [n,3], radii [n,1], imageplane [n,2]|NULL, and the
+ * broadcast columns near/far/lossmult/cam_idx [n,1] (each may be NULL). */
+int ucn_generate_rays(const int32_t *pix_x, const int32_t *pix_y, const int32_t *cam_idx, int32_t cam_idx_scalar,
+                      const double *pixtocams, const double *camtoworlds, uint32_t n_cams, uint32_t width,
+                      uint32_t height, uint32_t n_rays, float near_, float far_, float *origins, float *directions,
+                      float *viewdirs, float *radii, float *imageplane, float *cam_dirs, float *near_out,
+                      float *far_out, float *lossmult_out, float *cam_idx_out, ucn_stream_t stream);
+
 /* ------------------------------------------------- sky layer + colour correction
  * ref: models.py:326-337,743-904 (sky NeRF, 120 samples, 8x256 MLP) and
  * extrinsic_optimizer.py:4-48 + models.py:339-363 (per-camera 3x4 affine). */

@@ -123,3 +123,18 @@ def test_g9_render_image_chunks():
     for k in [k[4:] for k in fx if k.startswith("out_")]:
         got = torch.cat([o[k] for o in outs]).reshape((Hh, Ww) + outs[0][k].shape[1:])
         assert H.maxdiff(got, fx["out_" + k]) <= (300 * TOL if k == "depth" else 8 * TOL), k
+
+
+def test_rays_oracle_vs_reference():
+    """oracle/rays.py (numpy float64 restatement of camera_utils.pixels_to_rays + datasets._make_ray_batch) against the
+    reference's own output (tests/golden/rays.npz, make_rays_golden.py): bit-exact after the float32 cast."""
+    import numpy as np
+    from oracle import rays
+    fx = np.load(H.GOLDEN + "/rays.npz")
+    for tag in ("frame", "batch"):
+        b = rays.make_ray_batch(fx[f"{tag}.pix_x"], fx[f"{tag}.pix_y"], fx[f"{tag}.cam_idx"], fx["pixtocams"],
+                                fx["camtoworlds"], 0.0, 8.0)
+        for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "cam_dirs"):
+            assert b[k].dtype == np.float32 and np.array_equal(b[k], fx[f"{tag}.{k}"]), (tag, k)
+        assert np.array_equal(b["cam_idx"][..., 0], fx[f"{tag}.cam_idx"].astype(np.float32))
+        assert float(b["near"].max()) == 0.0 and float(b["far"].min()) == 8.0 and float(b["lossmult"].min()) == 1.0
