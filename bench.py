@@ -37,27 +37,42 @@ PEAK_F16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 MAC_NERF_SPLIT = 64 * 64 + 96 * 256 + (256 + 96) * 256
 
 
-def frame_rays(device):
-    """One pinhole camera, pixel centres, Waymo-like intrinsics (formulas of
-    camera_utils.py:482-557, datasets.py:446), generated on the device, outside the timed region."""
-    ys, xs = torch.meshgrid(torch.arange(H_IMG, device=device, dtype=torch.float32),
-                            torch.arange(W_IMG, device=device, dtype=torch.float32), indexing="ij")
-
-    def cam(x, y):
-        return torch.stack([(x - W_IMG / 2 + 0.5) / FOCAL, -(y - H_IMG / 2 + 0.5) / FOCAL, -torch.ones_like(x)], -1)
+def frame_cameras():
+    """One pinhole camera with Waymo-like intrinsics: (pixtocams, camtoworlds, distortion, ndc) as the reference's
+    Dataset.cameras tuple (datasets.py:346-349; pixtocam = inv(K) in float64, datasets.py:855)."""
+    K = np.array([[FOCAL, 0.0, W_IMG / 2], [0.0, FOCAL, H_IMG / 2], [0.0, 0.0, 1.0]])
     yaw = 0.3
-    R = torch.tensor([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]], dtype=torch.float32,
-                     device=device)
-    d = cam(xs, ys) @ R.T
-    v = torch.nn.functional.normalize(d, dim=-1)
-    vx = torch.nn.functional.normalize(cam(xs + 1, ys) @ R.T, dim=-1)
-    vy = torch.nn.functional.normalize(cam(xs, ys + 1) @ R.T, dim=-1)
-    radii = (0.5 * ((v - vx).norm(dim=-1) + (v - vy).norm(dim=-1)))[..., None] * 2 / np.sqrt(12)
-    o = torch.tensor([0.1, -0.05, 0.2], device=device).expand(H_IMG, W_IMG, 3).contiguous()
-    return dict(origins=o, directions=d.contiguous(), viewdirs=v.contiguous(),
-                cam_dirs=(-R[:, 2]).expand(H_IMG, W_IMG, 3).contiguous(), radii=radii.contiguous(),
-                near=torch.zeros(H_IMG, W_IMG, 1, device=device), far=torch.full((H_IMG, W_IMG, 1), 8.0, device=device),
-                cam_idx=torch.zeros(H_IMG, W_IMG, 1, device=device), lossmult=torch.ones(H_IMG, W_IMG, 1, device=device))
+    R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    c2w = np.concatenate([R, np.array([[0.1], [-0.05], [0.2]])], axis=1)
+    return (np.linalg.inv(K)[None], c2w[None], None, None)
+
+
+def frame_rays(device):
+    """Every pixel of the frame as the model's ray batch, generated ON the device by the path's own ray generator
+    (ucnerf_amd/internal/camera_utils.py -> ucn_generate_rays, bit-identical to the reference's
+    camera_utils.pixels_to_rays + datasets._make_ray_batch); outside the timed region, timed separately."""
+    from ucnerf_amd.internal import camera_utils
+    b = camera_utils.generate_ray_batch(frame_cameras(), 0, W_IMG, H_IMG, 0.0, 8.0, device=device)
+    return {k: b[k] for k in ("origins", "directions", "viewdirs", "cam_dirs", "radii", "near", "far", "cam_idx", "lossmult")}
+
+
+def ray_generation_ms(device, steps=20):
+    """one full frame of rays per launch; 68 B written per ray, nothing read but two 3x4 matrices."""
+    from ucnerf_amd.internal import camera_utils
+    cams = frame_cameras()
+    for _ in range(3):
+        camera_utils.generate_ray_batch(cams, 0, W_IMG, H_IMG, 0.0, 8.0, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        camera_utils.generate_ray_batch(cams, 0, W_IMG, H_IMG, 0.0, 8.0, device=device)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    n = H_IMG * W_IMG
+    return dict(ms_per_frame=ms, rays_per_s=n / (ms * 1e-3), bytes_per_ray=76, achieved_GBps=n * 76 / (ms * 1e-3) / 1e9,
+                peak_GBps=PEAK_HBM_GBS, kernel="k_generate_rays (float64 arithmetic, float32 stores; incl. output allocation)",
+                reference="numpy on DataLoader workers + 64 B/ray over PCIe (157 MB per frame)")
 
 
 class Ranks:
@@ -310,6 +325,7 @@ def main():
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             res["sky_layer"] = sky_layer_ms(flat, device)
+            res["ray_generation"] = ray_generation_ms(device)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
