@@ -440,3 +440,52 @@ def test_product_raises_without_device_tensors():
     rays = rm.synthetic_rays(8, seed=1)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         model(False, rays, 1.0, False)
+
+
+@pytest.mark.parametrize("C,log2_T", [(1, 12), (4, 12), (8, 12), (2, 16)])
+def test_features_backward_every_level_dim(C, log2_T):
+    """The compacted / plain row-block backward for every channel count the reference's grid supports (1, 2, 4, 8:
+    gridencoder.cu:376-399) and for a table with several row blocks per level, against the atomic scatter.  The sample
+    geometry comes from the tiny model; the gradient target is a bare grid of the given level_dim."""
+    from ucnerf_amd import _lib
+    from ucnerf_amd.gridencoder import GridEncoder
+    lib = _lib.load()
+    spec = rm.make_spec("tiny")
+    n = 500
+    rays = rm.synthetic_rays(n, seed=14)
+    noise = [rm.draw_level_noise(spec, n, l, False, torch.Generator().manual_seed(15 + l)) for l in range(2)]
+    model, _ = H.hip_model(spec, rm.init_state(spec, seed=13))
+    with torch.no_grad():
+        _, hist = model(False, H.pin_noise(H.to_dev(rays), noise), 1.0, True)
+    sdist = hist[-1]["sdist"].contiguous()
+    S = sdist.shape[-1] - 1
+    b = H.to_dev(rays)
+    flat = {k: b[k].reshape(n, -1).contiguous() for k in ("origins", "directions", "cam_dirs", "radii", "near", "far")}
+    basis = torch.empty(n, 6, device="cuda")
+    st = _lib.stream()
+    _lib.check(lib.ucn_cone_basis(flat["cam_dirs"].data_ptr(), noise[-1].rand_vec.cuda().contiguous().data_ptr(), n,
+                                  basis.data_ptr(), st))
+    enc = GridEncoder(num_levels=16, level_dim=C, desired_resolution=524288, log2_hashmap_size=log2_T).cuda()
+    d = _lib.UcnField()
+    d.embeddings = enc.embeddings.data_ptr()
+    d.offsets_host, d.grid_sizes_host = enc._offsets_np.ctypes.data, enc._sizes_np.ctypes.data
+    d.num_levels, d.level_dim, d.base_resolution = 16, C, 16
+    d.log2_per_level_scale = float(np.log2(enc.per_level_scale))
+    L = 16
+    g0 = torch.randn(L, n * S, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(C))
+    g0[:, ::5] = 0
+    ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(d), n, S), device="cuda")
+
+    def run(lpb, g, work=None):
+        out = torch.zeros_like(enc.embeddings)
+        _lib.check(lib.ucn_march_features_backward(
+            ctypes.byref(d), sdist.data_ptr(), flat["near"].data_ptr(), flat["far"].data_ptr(), flat["origins"].data_ptr(),
+            flat["directions"].data_ptr(), basis.data_ptr(), flat["radii"].data_ptr(), None, None, float(model.std_scale),
+            n, S, lpb, 0, g.data_ptr(), out.data_ptr(), _lib.ptr(work), st))
+        return out
+
+    want = run(1, g0)
+    tol = 2e-5 * float(want.abs().max())
+    assert float(want.abs().max()) > 0
+    assert H.maxdiff(run(0, g0, ws), want) <= tol
+    assert H.maxdiff(run(0, g0), want) <= tol
