@@ -165,7 +165,7 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
                                 anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
                                 hash_decay_mults=0.1, disable_multiscale_loss=False)
     g = torch.Generator(device=device).manual_seed(2)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+    opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)   # = create_optimizer (train_utils.py:347)
     model.train()
     times = []
     n_total = batch_flat['origins'].shape[0]

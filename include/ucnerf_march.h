@@ -195,6 +195,17 @@ int ucn_composite_backward(const float *density, const float *rgbs, const float 
                            const float *g_main, float *g_density /*[N,S]*/, float *g_rgbs /*[N,S,3]|NULL*/,
                            ucn_stream_t stream);
 
+/* ------------------------------------------------- training-side reductions + optimiser
+ * ucn_adam_step: torch.optim.Adam (amsgrad = False, weight_decay = 0; what train_utils.py:347-366 builds) on one
+ * fp32 tensor of n elements, in place, one pass; step counts from 1; sanitize_grad != 0 folds in the
+ * `param.grad.nan_to_num_()` of train_utils.py:343 (and stores the sanitised gradient like the reference).
+ * ucn_distortion_loss: stepfun.py:297-307 lossfun_distortion per ray in O(S): g_loss NULL -> out [N] = loss per
+ * ray; g_loss [N] -> out [N,S] = d(sum_n g_loss[n] loss[n]) / d w (t carries no gradient). */
+int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
+                  float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream);
+int ucn_distortion_loss(const float *t /*[N,S+1]*/, const float *w /*[N,S]*/, uint32_t N, uint32_t S,
+                        const float *g_loss, float *out, ucn_stream_t stream);
+
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
  * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the

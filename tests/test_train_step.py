@@ -197,3 +197,68 @@ def test_composite_backward_matches_oracle_autograd(S, opaque):
     assert opaque or (int((out["acc"] < 0.6).sum()) > 0 and int((out["acc"] >= 0.6).sum()) > 0)   # opaque: acc == 1
     for got, want in ((d1.grad.cpu(), d0.grad), (r1.grad.cpu(), r0.grad)):
         assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam_and_shares_its_state():
+    """FusedAdam (ucn_adam_step on the large tensors, torch's own path on the rest) vs torch.optim.Adam on the host
+    after clip_gradients' nan_to_num, three steps with a changing learning rate; gradients contain NaN / +-inf."""
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator().manual_seed(5)
+    shapes = [((1 << 20) + 3,), (600000, 2), (64, 32), (3,)]                 # two fused (one with a ragged tail), two not
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    dev = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+    o_dev = tu.FusedAdam(dev, lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+    for it in range(3):
+        for o in (o_ref, o_dev):
+            for grp in o.param_groups:
+                grp["lr"] = 0.01 * (0.5 ** it)
+        for p, q in zip(ref, dev):
+            grad = torch.randn(p.shape, generator=g) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=g))
+            flat = grad.view(-1)
+            flat[1], flat[-1] = float("nan"), float("inf")
+            flat[2] = float("-inf")
+            p.grad, q.grad = grad.clone().nan_to_num_(), grad.clone().cuda()
+            if q.numel() < tu.FusedAdam.MIN_NUMEL:
+                q.grad.nan_to_num_()                                          # clip_gradients (train_utils.py:343)
+        o_ref.step()
+        o_dev.step()
+        for p, q in zip(ref, dev):
+            assert float((q.detach().cpu() - p.detach()).abs().max()) <= 2e-6 * max(1.0, float(p.detach().abs().max())), it
+    for p, q in zip(ref, dev):
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = o_ref.state[p][key], o_dev.state[q][key].cpu()
+            fin = torch.isfinite(a)                             # (FLT_MAX)^2 overflows the second moment in both
+            assert torch.equal(fin, torch.isfinite(b)), key
+            a, b = a[fin], b[fin]
+            big = a.abs() < 1e30                                # the FLT_MAX entries of exp_avg: compare relatively
+            rel = ((a - b).abs() / a.abs().clamp_min(1e-30))[~big]
+            assert rel.numel() == 0 or float(rel.max()) <= 1e-5, key
+            assert float((a[big] - b[big]).abs().max()) <= 1e-5 * max(1e-30, float(a[big].abs().max())), key
+        assert float(o_dev.state[q]["step"]) == 3.0
+    assert torch.isfinite(dev[0].grad).all()                                  # the kernel stored the sanitised gradient
+    plain = torch.optim.Adam([p.detach().clone().cuda().requires_grad_(True) for p in ref], lr=0.01)
+    plain.load_state_dict(o_dev.state_dict())                                 # same state layout as torch.optim.Adam
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [64, 128, 37])
+def test_distortion_loss_kernel_matches_the_quadratic_reference_form(S):
+    """ucn_distortion_loss (O(S), forward and d/dw) vs stepfun.py:297-307 written out with its [N,S,S] matrix."""
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator().manual_seed(S)
+    N = 257
+    t = torch.sort(torch.rand(N, S + 1, generator=g), dim=-1).values
+    w = (torch.rand(N, S, generator=g) ** 3).requires_grad_(True)
+    c = torch.randn(N, generator=g)
+    ut = (t[..., 1:] + t[..., :-1]) / 2
+    dut = (ut[..., :, None] - ut[..., None, :]).abs()
+    want = (w * (w[..., None, :] * dut).sum(-1)).sum(-1) + (w ** 2 * (t[..., 1:] - t[..., :-1])).sum(-1) / 3
+    (want * c).sum().backward()
+    w1 = w.detach().clone().cuda().requires_grad_(True)
+    got = tu.lossfun_distortion(t.cuda(), w1)
+    (got * c.cuda()).sum().backward()
+    assert got.shape == (N,)
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
+    assert float((w1.grad.cpu() - w.grad).abs().max()) <= 1e-5 * float(w.grad.abs().max())

@@ -12,7 +12,7 @@ cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_lo
                             anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
                             hash_decay_mults=0.1, disable_multiscale_loss=False)
 g = torch.Generator(device=dev).manual_seed(2)
-opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
 model.train()
 n = 8192
 acc = {}

@@ -15,12 +15,43 @@ import collections
 import numpy as np
 import torch
 
+from .. import _lib
 from .train_graph import GradientScaler  # noqa: F401  (ref train_utils.py:101-111)
 
 
 # ------------------------------------------------------------------ step-function helpers
+class _Distortion(torch.autograd.Function):
+    """lossfun_distortion per ray as two HIP launches (`ucn_distortion_loss`): forward [N], backward d/dw [N, S]."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, t, w):
+        lib = _lib.load()
+        S = w.shape[-1]
+        t2, w2 = t.reshape(-1, S + 1).contiguous(), w.reshape(-1, S).contiguous()
+        out = torch.empty(w2.shape[0], device=w.device)
+        _lib.check(lib.ucn_distortion_loss(t2.data_ptr(), w2.data_ptr(), w2.shape[0], S, None, out.data_ptr(), _lib.stream()))
+        ctx.save_for_backward(t2, w2)
+        ctx.shape = w.shape
+        return out.reshape(w.shape[:-1])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        lib = _lib.load()
+        t2, w2 = ctx.saved_tensors
+        g = g.reshape(-1).float().contiguous()
+        gw = torch.empty_like(w2)
+        _lib.check(lib.ucn_distortion_loss(t2.data_ptr(), w2.data_ptr(), w2.shape[0], w2.shape[1], g.data_ptr(), gw.data_ptr(),
+                                           _lib.stream()))
+        return None, gw.reshape(ctx.shape)
+
+
 def lossfun_distortion(t, w):
-    """ref stepfun.py:297-307, O(S)."""
+    """ref stepfun.py:297-307, O(S).  Device tensors whose fenceposts carry no gradient (the training graph: sample
+    positions are detached, models.py:204) take the HIP kernel; the torch form below is the general one."""
+    if w.is_cuda and not t.requires_grad and w.shape[-1] <= 512:
+        return _Distortion.apply(t, w)
     u = (t[..., 1:] + t[..., :-1]) / 2
     zero = torch.zeros_like(w[..., :1])
     W = torch.cat([zero, torch.cumsum(w[..., :-1], dim=-1)], dim=-1)
@@ -126,3 +157,85 @@ def transformIdentityLoss(renderings):
     if 'affine_trans_sky' in renderings[0]:
         loss = loss + torch.abs(eye - renderings[0]['affine_trans_sky'])
     return loss.mean()
+
+
+# ------------------------------------------------------------------ optimiser (train_utils.py:335-366)
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam -- what `create_optimizer` builds (train_utils.py:347-366) -- whose large fp32 device tensors
+    (the hash tables: 7.1 M x 2 and 1.9 M x 2 parameters in config B) are stepped by ONE pass of `ucn_adam_step`
+    instead of ~12 elementwise passes, with the `grad.nan_to_num_()` of `clip_gradients` folded in.  State keys and
+    layout are torch's (`step`, `exp_avg`, `exp_avg_sq`), so state_dicts interchange with torch.optim.Adam.  Every other
+    parameter (and any group using amsgrad / weight_decay / maximize) goes through the parent class unchanged."""
+    MIN_NUMEL = 1 << 20
+
+    def _fusable(self, group, p):
+        return (p.grad is not None and p.is_cuda and p.dtype == torch.float32 and p.numel() >= self.MIN_NUMEL
+                and p.is_contiguous() and p.grad.is_contiguous() and not p.grad.is_sparse and not group.get('amsgrad', False)
+                and group.get('weight_decay', 0) == 0 and not group.get('maximize', False)
+                and not group.get('capturable', False) and not group.get('differentiable', False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        held = []
+        for group in self.param_groups:
+            for p in group['params']:
+                if self._fusable(group, p):
+                    held.append((group, p, p.grad))
+                    p.grad = None                                # the parent skips parameters without a gradient
+        try:
+            super().step()
+        finally:
+            for _, p, g in held:
+                p.grad = g
+        for group, p, g in held:
+            state = self.state[p]
+            if len(state) == 0:                                  # torch/optim/adam.py _init_group
+                state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state['step'] += 1
+            lr = group['lr']
+            beta1, beta2 = group['betas']
+            _lib.check(lib.ucn_adam_step(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                                         p.numel(), float(lr), float(beta1), float(beta2), float(group['eps']),
+                                         int(state['step'].item()), 1, _lib.stream()))
+        return loss
+
+
+def clip_gradients(model, accelerator, config):
+    """ref train_utils.py:335-344: norm / value clipping, then nan_to_num on every gradient.  (The tables stepped by
+    FusedAdam are sanitised again inside its kernel -- idempotent.)"""
+    if getattr(config, 'grad_max_norm', 0) > 0 and accelerator.sync_gradients:
+        accelerator.clip_grad_norm_(model.parameters(), config.grad_max_norm)
+    if getattr(config, 'grad_max_val', 0) > 0 and accelerator.sync_gradients:
+        accelerator.clip_grad_value_(model.parameters(), config.grad_max_val)
+    for param in model.parameters():
+        if param.grad is not None:
+            param.grad.nan_to_num_()
+
+
+def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
+    """ref math.py:53-85: log-linear interpolation with an optional sine warm-up."""
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    else:
+        delay_rate = 1.
+    if lr_init <= 0 or lr_final <= 0:                                         # math.py:44-50 log_lerp
+        raise ValueError(f'Interpolants {lr_init} and {lr_final} must be positive.')
+    lv0, lv1 = np.log(lr_init), np.log(lr_final)
+    return delay_rate * np.exp(np.clip(step / max_steps, 0, 1) * (lv1 - lv0) + lv0)
+
+
+def create_optimizer(config, model):
+    """ref train_utils.py:347-366: Adam over all parameters + the learning-rate schedule."""
+    lr_fn_main = lambda step: learning_rate_decay(step, lr_init=config.lr_init, lr_final=config.lr_final,
+                                                  max_steps=config.max_steps, lr_delay_steps=config.lr_delay_steps,
+                                                  lr_delay_mult=config.lr_delay_mult)
+    optimizer = FusedAdam(model.parameters(), lr=config.lr_init, betas=[config.adam_beta1, config.adam_beta2],
+                          eps=config.adam_eps)
+    return optimizer, lr_fn_main
