@@ -7,138 +7,207 @@
 //                   stepfun.py:329-339 (weighted percentiles)
 //
 // The reference does the dilation and the inverse-CDF lookup with O(n*m) broadcast masks
-// ([N,3n,n] and [N,n,m] temporaries in HBM).  Here a ray's step function never leaves the chip:
-// k_resample walks the three already-sorted fencepost lists with merge pointers (one thread per
-// ray, per-thread arrays live in lane-interleaved scratch = coalesced), and k_composite gives one
-// wave64 to each ray: transmittance is a wave prefix-sum (DPP-free shuffles), the percentile
+// ([N,3n,n] and [N,n,m] temporaries in HBM).  Here a ray's step function never leaves the chip: k_resample and
+// k_composite give one wave64 to each ray (step function in LDS, ranks by binary search, sums as wave scans): transmittance is a wave prefix-sum (DPP-free shuffles), the percentile
 // lookups are ballots over the CDF held in LDS.
 #include "ucn_common.h"
 
 namespace {
 
 // ------------------------------------------------------------------ resample
-template <int MAXP>
+// One wave64 per ray, 4 rays per workgroup; the ray's step function lives in LDS:
+//   t[n+1], p[n]      previous fenceposts and pdf = weight / width                      (weight_to_pdf)
+//   kn[m], wt[m-1]    the max-dilated step function, m = 3n + 1                         (max_dilate_weights)
+//   cdf[nw+1], c[S]   CDF of the annealed, trimmed weights and the S inverse-CDF samples (sample_intervals)
+// Every sequential walk of the reference (3-way merge of sorted lists, sliding-window maximum, cumulative sums,
+// monotone inverse-CDF pointer) becomes a rank computation by binary search or a wave scan:
+//   * rank of an element in the merge = own index + elements of the other two lists ordered before it, with the
+//     sequential tie rule (shifted-down copy first, then the fencepost, then the shifted-up copy); only VALUES
+//     reach the next stage, so ties cannot change the result;
+//   * window bounds jlo / jhi = counts of shifted fenceposts <= the knot (both lists are sorted);
+//   * sums accumulate in double like torch-CPU's cumsum (acc_type) -- a float sum over ~200-400 terms would drift by
+//     ~1e-5 in the CDF, i.e. whole samples in t; the wave scan adds the same addends in a different order, which
+//     is invisible after the cast back to float.
+// (The first version ran one THREAD per ray with its arrays in scratch memory: 6.4 ms per 2.46 M rays; the stores
+//  are now coalesced across the lanes of the ray's wave as well.)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_scan_d(double v, int lane) {      // inclusive
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// #{j < len : f(j) <= x} / #{j < len : f(j) < x} for a non-decreasing f
+template <bool STRICT, class F>
+__device__ __forceinline__ uint32_t count_before(F f, uint32_t len, float x) {
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const float v = f(mid);
+        if (STRICT ? (v < x) : (v <= x)) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_prev, const float *__restrict__ w_prev,
                                                   uint32_t n_prev, float dilation, float anneal, float pad,
                                                   const float *__restrict__ u_table, const float *__restrict__ jitter,
                                                   uint32_t jcols, float max_jitter, uint32_t N, uint32_t S,
                                                   float *__restrict__ sd_out) {
-    const uint32_t ray = blockIdx.x * 256u + threadIdx.x;
-    if (ray >= N) return;
-    float kn[3 * MAXP + 1];  // fenceposts of the (dilated) step function
-    float wt[3 * MAXP + 1];  // its weights, later the CDF
-    const float *sd;         // fenceposts actually resampled (after the [1:-1] trim)
-    float *w;
+    extern __shared__ float s_mem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ray_raw = blockIdx.x * 4u + wv;
+    const bool live = ray_raw < N;                       // wave-uniform; dead waves still reach the barriers
+    const uint32_t ray = live ? ray_raw : N - 1;
+    const uint32_t n = n_prev, m = 3 * n + 1;            // n >= 1: the first level is k_resample_first
+    float *t = s_mem + (size_t)wv * ((n + 1) + n + (m + 1) + m + (m + 1) + S);
+    float *p = t + (n + 1), *kn = p + n, *wt = kn + (m + 1), *cdf = wt + m, *c = cdf + (m + 1);
+    const float *sd;                                     // fenceposts actually resampled (after the [1:-1] trim)
+    const float *w;
     uint32_t nw;
-    if (n_prev == 0) {
-        kn[0] = 0.0f; kn[1] = 1.0f; wt[0] = 1.0f;
-        sd = kn; w = wt; nw = 1;
-    } else {
-        const uint32_t n = n_prev;
-        float t[MAXP + 1], p[MAXP];
-        for (uint32_t i = 0; i <= n; i++) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
-        for (uint32_t i = 0; i < n; i++)
+    {
+        for (uint32_t i = lane; i <= n; i += 64) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += 64)
             p[i] = w_prev[(size_t)ray * n + i] / fmaxf(t[i + 1] - t[i], UCN_EPS);       // weight_to_pdf
-        // sort(cat[t, t0-d, t1+d]) == 3-way merge of three sorted lists, then clip to [0,1]
-        const uint32_t m = 3 * n + 1;
-        uint32_t ia = 0, ib = 0, ic = 0;
-        for (uint32_t i = 0; i < m; i++) {
-            const float a = ia <= n ? t[ia] : INFINITY;
-            const float b = ib < n ? t[ib] - dilation : INFINITY;
-            const float c = ic < n ? t[ic + 1] + dilation : INFINITY;
+        // sort(cat[t, t0-d, t1+d]) == ranks in the 3-way merge of three sorted lists, then clip to [0,1]
+        auto A = [&](uint32_t j) { return t[j]; };
+        auto Bq = [&](uint32_t j) { return t[j] - dilation; };
+        auto Cq = [&](uint32_t j) { return t[j + 1] + dilation; };
+        for (uint32_t e = lane; e < m; e += 64) {
             float v;
-            if (b <= a && b <= c) { v = b; ib++; }
-            else if (a <= c)      { v = a; ia++; }
-            else                  { v = c; ic++; }
-            kn[i] = fminf(fmaxf(v, 0.0f), 1.0f);
+            uint32_t pos;
+            if (e <= n) {
+                v = A(e);
+                pos = e + count_before<false>(Bq, n, v) + count_before<true>(Cq, n, v);
+            } else if (e <= 2 * n) {
+                const uint32_t i = e - (n + 1);
+                v = Bq(i);
+                pos = i + count_before<true>(A, n + 1, v) + count_before<true>(Cq, n, v);
+            } else {
+                const uint32_t i = e - (2 * n + 1);
+                v = Cq(i);
+                pos = i + count_before<false>(A, n + 1, v) + count_before<false>(Bq, n, v);
+            }
+            kn[pos] = fminf(fmaxf(v, 0.0f), 1.0f);
         }
-        // max-pool the pdf over the dilated intervals covering each fencepost
-        // Sums below accumulate in double: torch-CPU (the oracle) accumulates float cumsum in double
-        // (acc_type) and its vectorised float sums are pairwise-accurate; a sequential float sum over
-        // ~200-400 terms would drift by ~1e-5 in the CDF, i.e. whole samples in t.
-        uint32_t jlo = 0, jhi = 0;
-        double total = 0.0;
-        for (uint32_t i = 0; i + 1 < m; i++) {
+        __syncthreads();
+        // max-pool the pdf over the dilated intervals covering each knot interval, times its width
+        double part = 0.0;
+        for (uint32_t i = lane; i + 1 < m; i += 64) {
             const float k = kn[i];
-            while (jhi < n && t[jhi] - dilation <= k) jhi++;
-            while (jlo < n && !(t[jlo + 1] + dilation > k)) jlo++;
+            const uint32_t jhi = count_before<false>(Bq, n, k);          // intervals with t0 - d <= k
+            const uint32_t jlo = count_before<false>(Cq, n, k);          // intervals with t1 + d <= k end before k
             float env = 0.0f;
             for (uint32_t j = jlo; j < jhi; j++) env = fmaxf(env, p[j]);
-            const float wv = env * (kn[i + 1] - kn[i]);                                  // pdf_to_weight
-            wt[i] = wv;
-            total += (double)wv;
+            const float wv_ = env * (kn[i + 1] - kn[i]);                 // pdf_to_weight
+            wt[i] = wv_;
+            part += (double)wv_;
         }
-        const float norm = fmaxf((float)total, UCN_EPS);
-        for (uint32_t i = 0; i + 1 < m; i++) wt[i] = wt[i] / norm;
-        sd = kn + 1; w = wt + 1; nw = m - 3;                                             // models.py:175-176
+        const float norm = fmaxf((float)wave_sum_d(part), UCN_EPS);
+        for (uint32_t i = lane; i + 1 < m; i += 64) wt[i] = wt[i] / norm;
+        sd = kn + 1; w = wt + 1; nw = m - 3;                             // models.py:175-176
+        __syncthreads();
     }
-    // logits -> softmax -> CDF (in place in w[], shifted by one so that cdf[i] = w[i-1])
+    // logits -> softmax -> CDF; lane owns CH consecutive intervals so that the prefix sum is a wave scan.  The logit
+    // and then the exponential of an interval are parked in the lane's own cdf[] slots (one logf / expf each).
+    const uint32_t CH = (nw + 63) / 64;
     float mx = -INFINITY;
-    for (uint32_t i = 0; i < nw; i++) {
-        const float lg = (sd[i + 1] > sd[i]) ? anneal * logf(w[i] + pad) : -INFINITY;
-        w[i] = lg;
-        mx = fmaxf(mx, lg);
+    for (uint32_t q = 0; q < CH; q++) {
+        const uint32_t i = lane * CH + q;
+        if (i < nw) {
+            const float lg = (sd[i + 1] > sd[i]) ? anneal * logf(w[i] + pad) : -INFINITY;
+            cdf[i] = lg;
+            mx = fmaxf(mx, lg);
+        }
     }
-    double zsum = 0.0;
-    for (uint32_t i = 0; i < nw; i++) {
-        const float e = expf(w[i] - mx);
-        w[i] = e;
-        zsum += (double)e;
+    mx = wave_max_f(mx);
+    double zpart = 0.0;
+    for (uint32_t q = 0; q < CH; q++) {
+        const uint32_t i = lane * CH + q;
+        if (i < nw) {
+            const float e = expf(cdf[i] - mx);
+            cdf[i] = e;
+            zpart += (double)e;
+        }
     }
-    const float z = (float)zsum;
-    // cdf[0] = 0, cdf[i] = min(1, sum_{k<i} pw_k) for i < nw, cdf[nw] = 1  (stepfun.py:123-127)
+    const float z = (float)wave_sum_d(zpart);
     double run = 0.0;
-    for (uint32_t i = 0; i < nw; i++) {
-        const float pw = w[i] / z;
-        w[i] = fminf((float)run, 1.0f);    // cdf[i]; run == 0 exactly for i == 0
-        run += (double)pw;
+    for (uint32_t q = 0; q < CH; q++) {
+        const uint32_t i = lane * CH + q;
+        if (i < nw) run += (double)(cdf[i] / z);
     }
-    // w[nw] slot: wt has 3*MAXP+1 entries, and nw <= 3*MAXP-2
-    w[nw] = 1.0f;
-    // inverse CDF at the sorted u's, then midpoints + reflected/clamped ends (stepfun.py:283-293)
+    run = wave_scan_d(run, lane) - run;                                  // sum of pw over the lanes before this one
+    // cdf[0] = 0, cdf[i] = min(1, sum_{k<i} pw_k) for i < nw, cdf[nw] = 1  (stepfun.py:123-127)
+    for (uint32_t q = 0; q < CH; q++) {
+        const uint32_t i = lane * CH + q;
+        if (i < nw) {
+            const float pw = cdf[i] / z;
+            cdf[i] = fminf((float)run, 1.0f);                            // run == 0 exactly for i == 0
+            run += (double)pw;
+        }
+    }
+    if (lane == 0) cdf[nw] = 1.0f;
+    __syncthreads();
+    // inverse CDF at the sorted u's (stepfun.py:283-293): idx = #{1 <= j <= nw : cdf[j] <= u}
     const float jit = jitter ? jitter[(size_t)ray * jcols] : 0.0f;
-    uint32_t idx = 0;
-    float prev_c = 0.0f, prev_mid = 0.0f, c0 = 0.0f;
-    float *out = sd_out + (size_t)ray * (S + 1);
-    // Outputs leave in blocks of 16 consecutive floats per thread: a thread's row is its own 516-byte strip, and
-    // dword stores trickling out one per iteration let every 64-byte sector be evicted half-written from L2
-    // (measured: 7 GB fetched + 14 GB written per call for 1.3 GB of output, 9.5 ms); sixteen back-to-back stores
-    // complete the sector while it is still resident.
-    for (uint32_t kb = 0; kb < S; kb += 16) {
-        float ob[16];
-#pragma unroll
-        for (uint32_t kk = 0; kk < 16; kk++) {
-            const uint32_t k = kb + kk;
-            ob[kk] = 0.0f;
-            if (k < S) {
-                float u = u_table[k];
-                if (jitter) u = u + (jcols > 1 ? jitter[(size_t)ray * jcols + k] : jit) * max_jitter;
-                while (idx + 1 <= nw && w[idx + 1] <= u) idx++;
-                const uint32_t i1 = idx + 1 <= nw ? idx + 1 : nw;
-                const float x0 = w[idx], x1 = w[i1];
-                float fr = (u - x0) / (x1 - x0);
-                if (fr != fr) fr = 0.0f;                               // nan_to_num(.., 0); +-inf clip below
-                fr = fminf(fmaxf(fr, 0.0f), 1.0f);
-                const float f0 = sd[idx], f1 = sd[i1];
-                const float c = f0 + fr * (f1 - f0);
-                if (k == 0) {
-                    c0 = c;
-                } else {
-                    const float mid = (c + prev_c) / 2.0f;
-                    if (k == 1) ob[0] = fmaxf(2.0f * c0 - mid, 0.0f);  // k == 1 is (kb, kk) = (0, 1): a static slot
-                    ob[kk] = mid;
-                    prev_mid = mid;
-                }
-                prev_c = c;
-            }
-        }
-#pragma unroll
-        for (uint32_t kk = 0; kk < 16; kk++) {
-            const uint32_t k = kb + kk;
-            if (k < S && !(k == 0 && S == 1)) out[k] = ob[kk];         // (S == 1 never writes out[0] upstream either)
-        }
+    auto Cdf1 = [&](uint32_t j) { return cdf[j + 1]; };
+    for (uint32_t k = lane; k < S; k += 64) {
+        float u = u_table[k];
+        if (jitter) u = u + (jcols > 1 ? jitter[(size_t)ray * jcols + k] : jit) * max_jitter;
+        const uint32_t idx = count_before<false>(Cdf1, nw, u);
+        const uint32_t i1 = idx + 1 <= nw ? idx + 1 : nw;
+        const float x0 = cdf[idx], x1 = cdf[i1];
+        float fr = (u - x0) / (x1 - x0);
+        if (fr != fr) fr = 0.0f;                                         // nan_to_num(.., 0); +-inf clip below
+        fr = fminf(fmaxf(fr, 0.0f), 1.0f);
+        const float f0 = sd[idx], f1 = sd[i1];
+        c[k] = f0 + fr * (f1 - f0);
     }
-    out[S] = fminf(2.0f * prev_c - prev_mid, 1.0f);
+    __syncthreads();
+    // midpoints + reflected / clamped ends; the S + 1 outputs of the ray leave as coalesced stores
+    if (!live) return;
+    float *out = sd_out + (size_t)ray * (S + 1);
+    for (uint32_t k = lane; k <= S; k += 64) {
+        float v;
+        if (k == 0) v = fmaxf(2.0f * c[0] - (c[1] + c[0]) / 2.0f, 0.0f);
+        else if (k == S) v = fminf(2.0f * c[S - 1] - (c[S - 1] + c[S - 2]) / 2.0f, 1.0f);
+        else v = (c[k] + c[k - 1]) / 2.0f;
+        out[k] = v;
+    }
+}
+
+// First level (n_prev == 0): the step function is the single interval [0, 1] with weight 1, so cdf = [0, 1], the
+// softmax is exactly 1 and every sample is c_k = clamp(u_k, 0, 1) (stepfun.py:283-293 with fp = xp = [0, 1]: the
+// interpolation 0 + fr * (1 - 0) is exact).  One thread per output fencepost.
+__global__ __launch_bounds__(256) void k_resample_first(const float *__restrict__ u_table, const float *__restrict__ jitter,
+                                                        uint32_t jcols, float max_jitter, uint32_t N, uint32_t S,
+                                                        float *__restrict__ sd_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)N * (S + 1)) return;
+    const uint32_t ray = (uint32_t)(i / (S + 1)), k = (uint32_t)(i - (uint64_t)ray * (S + 1));
+    auto cu = [&](uint32_t q) {
+        float u = u_table[q];
+        if (jitter) u = u + jitter[(size_t)ray * jcols + (jcols > 1 ? q : 0u)] * max_jitter;
+        return fminf(fmaxf(u, 0.0f), 1.0f);
+    };
+    float v;
+    if (k == 0) v = fmaxf(2.0f * cu(0) - (cu(1) + cu(0)) / 2.0f, 0.0f);
+    else if (k == S) v = fminf(2.0f * cu(S - 1) - (cu(S - 1) + cu(S - 2)) / 2.0f, 1.0f);
+    else v = (cu(k) + cu(k - 1)) / 2.0f;
+    sd_out[i] = v;
 }
 
 // ------------------------------------------------------------------ cone basis
@@ -414,15 +483,17 @@ extern "C" int ucn_resample(const float *sdist_prev, const float *weights_prev, 
     UCN_REQUIRE(n_prev <= 256, "resample: at most 256 intervals per level are supported, got %u", n_prev);
     UCN_REQUIRE(!jitter || jitter_cols == 1 || jitter_cols == S, "resample: jitter must be [N,1] or [N,S]");
     if (N == 0) return 0;
-    const dim3 grid(ucn_div_up(N, 256));
-    hipStream_t st = (hipStream_t)stream;
-#define UCN_RS(MAXP)                                                                                              \
-    hipLaunchKernelGGL(k_resample<MAXP>, grid, dim3(256), 0, st, sdist_prev, weights_prev, n_prev, dilation,      \
-                       anneal, resample_padding, u_table, jitter, jitter_cols, max_jitter, N, S, sdist_out)
-    if (n_prev <= 64) UCN_RS(64);
-    else if (n_prev <= 128) UCN_RS(128);
-    else UCN_RS(256);
-#undef UCN_RS
+    UCN_REQUIRE(S <= 1024, "resample: at most 1024 samples per ray are supported, got %u", S);
+    if (n_prev == 0) {
+        hipLaunchKernelGGL(k_resample_first, dim3((uint32_t)(((uint64_t)N * (S + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           u_table, jitter, jitter_cols, max_jitter, N, S, sdist_out);
+        UCN_LAUNCH_CHECK("resample (first level)");
+        return 0;
+    }
+    const uint32_t m = 3 * n_prev + 1;
+    const size_t lds = 4 * sizeof(float) * ((size_t)(n_prev + 1) + n_prev + (m + 1) + m + (m + 1) + S);
+    hipLaunchKernelGGL(k_resample, dim3(ucn_div_up(N, 4)), dim3(256), lds, (hipStream_t)stream, sdist_prev, weights_prev, n_prev,
+                       dilation, anneal, resample_padding, u_table, jitter, jitter_cols, max_jitter, N, S, sdist_out);
     UCN_LAUNCH_CHECK("resample");
     return 0;
 }
