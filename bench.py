@@ -75,6 +75,31 @@ def ray_generation_ms(device, steps=20):
                 reference="numpy on DataLoader workers + 64 B/ray over PCIe (157 MB per frame)")
 
 
+def virtual_warp_ms(device, steps=20):
+    """train_utils.img_warping on one full 1280x1920 depth map (what datasets.py:527 does on the CPU
+    every training step): 4 B read, 9 B written per pixel."""
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator(device=device).manual_seed(3)
+    depth = torch.rand(H_IMG, W_IMG, device=device, generator=g) * 10 + 2
+    depth[torch.rand(H_IMG, W_IMG, device=device, generator=g) < 0.4] = 0
+    K = np.array([[FOCAL, 0.0, W_IMG / 2], [0.0, FOCAL, H_IMG / 2], [0.0, 0.0, 1.0]])
+    ref = np.eye(4)
+    src = np.eye(4)
+    src[:3, 3] = [0.3, 0.35, 0.1]
+    for _ in range(3):
+        tu.img_warping(ref, src, depth, K)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        pts, mask = tu.img_warping(ref, src, depth, K)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    n = H_IMG * W_IMG
+    return dict(ms_per_frame=ms, pixels_per_s=n / (ms * 1e-3), achieved_GBps=n * 13 / (ms * 1e-3) / 1e9, peak_GBps=PEAK_HBM_GBS,
+                valid_fraction=float(mask.float().mean()), kernel="k_img_warp (incl. the host-side 4x4 inverse and the bool cast)")
+
+
 class Ranks:
     """The three attributes render_image reads from an `accelerate.Accelerator`."""
 
@@ -326,6 +351,7 @@ def main():
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             res["sky_layer"] = sky_layer_ms(flat, device)
             res["ray_generation"] = ray_generation_ms(device)
+            res["virtual_warp"] = virtual_warp_ms(device)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

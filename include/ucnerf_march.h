@@ -206,6 +206,18 @@ int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int ucn_distortion_loss(const float *t /*[N,S+1]*/, const float *w /*[N,S]*/, uint32_t N, uint32_t S,
                         const float *g_loss, float *out, ucn_stream_t stream);
 
+/* ------------------------------------------------- virtual-pose depth warping
+ * ref: train_utils.py:19-55 img_warping / :58-98 img_warping_for_depth, called per training step on a full depth
+ * map by datasets.py:511-529.  rel_pose_host = HOST float[12], rows of the upper 3x4 of inv(src_pose) @ ref_pose
+ * (OpenCV convention, float32 like the reference); intrinsic_host = HOST float[9].  pts_out [H,W,2] = projected
+ * (x, y) in the source frame, mask_out [H,W] uint8 = depth > 0 and inside the frame, z_src_out [H,W]|NULL = depth in
+ * the source camera.  ucn_warp_scatter_depth: depth_tgt[int(y), int(x)] = z for the masked pixels, later pixels
+ * (row-major) overwriting earlier ones; owner_ws = DEVICE uint32[H*W] scratch. */
+int ucn_img_warping(const float *depth, const float *rel_pose_host, const float *intrinsic_host, uint32_t H, uint32_t W,
+                    float *pts_out, uint8_t *mask_out, float *z_src_out, ucn_stream_t stream);
+int ucn_warp_scatter_depth(const float *pts, const uint8_t *mask, const float *z_src, uint32_t H, uint32_t W,
+                           uint32_t *owner_ws, float *depth_tgt, ucn_stream_t stream);
+
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
  * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the

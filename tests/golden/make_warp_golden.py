@@ -1,0 +1,62 @@
+"""Golden vectors for the virtual-pose depth warp from the reference's own train_utils.py.
+
+Runs ONLY in the authoring container:   python tests/golden/make_warp_golden.py  -> tests/golden/warp.npz
+Inputs follow datasets.py:511-529 / :983-1050: a Waymo-like intrinsic matrix, a reference camera pose and virtual
+source poses derived from it (shift up, rotate right, stereo shift, forward), both flipped to the OpenCV convention,
+and a synthetic depth map with holes (depth 0 = no LiDAR return).  Outputs: img_warping's (pts_in_tgt, mask) and
+img_warping_for_depth's depth_tgt.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+
+def main():
+    ref = ref_import.load()
+    tu = ref.train_utils
+    rng = np.random.default_rng(21)
+    H, W = 96, 144
+    K = np.array([[2055.556149 * W / 1920, 0.0, 939.657470 * W / 1920], [0.0, 2055.556149 * H / 1280, 641.072182 * H / 1280],
+                  [0.0, 0.0, 1.0]])
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    c2w = np.eye(4)
+    c2w[:3, :3], c2w[:3, 3] = q, rng.standard_normal(3)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = (6.0 + 4.0 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + rng.random((H, W))).astype(np.float32)
+    depth[rng.random((H, W)) < 0.3] = 0.0                                   # holes
+    depth[:5] = 0.0
+    out = dict(intrinsic=K, ref_pose=c2w, depth=depth)
+
+    def T(dx=0.0, dy=0.0, dz=0.0):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = [dx, dy, dz]
+        return m
+
+    a = np.radians(-17.0)
+    rot = c2w.copy()
+    rot[:3, :3] = rot[:3, :3] @ np.array([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]]).astype(np.float32)
+    cases = dict(up=c2w @ T(dy=0.4), stereo=c2w @ T(dx=0.45), forward=c2w @ T(dz=0.35), rot_right=rot)
+    flip = np.diag([1., -1., -1., 1.])                                      # datasets.py:523-524
+    for name, src in cases.items():
+        pts, mask = tu.img_warping(c2w @ flip, src @ flip, depth, K)
+        dt = tu.img_warping_for_depth(c2w @ flip, src @ flip, depth, K)
+        out[f"{name}.src_pose"] = src
+        out[f"{name}.pts"] = np.asarray(pts, dtype=np.float32)
+        out[f"{name}.mask"] = np.asarray(mask).astype(np.uint8)
+        out[f"{name}.depth_tgt"] = np.asarray(dt, dtype=np.float32)
+        print(name, int(np.asarray(mask).sum()), "valid pixels")
+    path = os.path.join(HERE, "warp.npz")
+    np.savez_compressed(path, **out)
+    print(f"warp.npz: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -138,3 +138,36 @@ def test_rays_oracle_vs_reference():
             assert b[k].dtype == np.float32 and np.array_equal(b[k], fx[f"{tag}.{k}"]), (tag, k)
         assert np.array_equal(b["cam_idx"][..., 0], fx[f"{tag}.cam_idx"].astype(np.float32))
         assert float(b["near"].max()) == 0.0 and float(b["far"].min()) == 8.0 and float(b["lossmult"].min()) == 1.0
+
+
+WARP_CASES = ("up", "stereo", "forward", "rot_right")
+
+
+def check_warp(fx, name, uv, mask, depth_tgt=None):
+    """Shared by the oracle (here) and the HIP kernels (tests/test_warp.py): projected coordinates to a few float32 ulp
+    of a pixel coordinate where the depth is valid; the mask up to pixels that sit ON a frame boundary (a pure shift
+    keeps one coordinate exactly integral, so `u >= 0` at column 0 flips with the rounding of a BLAS call); the
+    splatted depth on the non-degenerate poses, up to the same truncation ambiguity."""
+    import numpy as np
+    want, wm = fx[name + ".pts"], fx[name + ".mask"].astype(bool)
+    H, W = wm.shape
+    ok = fx["depth"] > 0
+    assert float(np.abs(uv - want)[ok].max()) <= 2e-3, name
+    edge = np.minimum.reduce([np.abs(want[..., 0]), np.abs(want[..., 0] - (W - 0.5)), np.abs(want[..., 1]),
+                              np.abs(want[..., 1] - (H - 0.5))]) < 1e-2
+    assert not ((np.asarray(mask).astype(bool) != wm) & ~edge).any(), name
+    if depth_tgt is not None and name in ("forward", "rot_right"):
+        wd = fx[name + ".depth_tgt"]
+        assert int((np.abs(depth_tgt - wd) > 1e-4).sum()) <= 0.01 * int((wd != 0).sum()), name
+
+
+def test_warp_oracle_vs_reference():
+    """oracle/warp.py against the reference's own img_warping / img_warping_for_depth (tests/golden/warp.npz)."""
+    import numpy as np
+    from oracle import warp
+    fx = np.load(H.GOLDEN + "/warp.npz")
+    flip = np.diag([1., -1., -1., 1.])                                   # datasets.py:523-524
+    for name in WARP_CASES:
+        ref, src = fx["ref_pose"] @ flip, fx[name + ".src_pose"] @ flip
+        uv, mask = warp.img_warping(ref, src, fx["depth"], fx["intrinsic"])
+        check_warp(fx, name, uv, mask, warp.img_warping_for_depth(ref, src, fx["depth"], fx["intrinsic"]))

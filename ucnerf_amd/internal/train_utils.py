@@ -239,3 +239,58 @@ def create_optimizer(config, model):
     optimizer = FusedAdam(model.parameters(), lr=config.lr_init, betas=[config.adam_beta1, config.adam_beta2],
                           eps=config.adam_eps)
     return optimizer, lr_fn_main
+
+
+# ------------------------------------------------------------------ virtual-pose depth warp (train_utils.py:19-98)
+def _warp_inputs(ref_pose, src_pose, depth, intrinsic):
+    import ctypes
+    as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))
+    d = as_t(depth).to(torch.float32)
+    if not d.is_cuda:
+        d = d.cuda()                                               # the depth map is the only O(H*W) input
+    d = d.contiguous()
+    ref, src = as_t(ref_pose).cpu().to(torch.float32), as_t(src_pose).cpu().to(torch.float32)
+    rel = (src.inverse() @ ref)[:3].contiguous()                   # :39, float32 on the host like the reference
+    K = as_t(intrinsic).cpu().to(torch.float32).contiguous()
+    return d, rel, K, ctypes
+
+
+def img_warping(ref_pose, src_pose, virtual_pose_ref_depth, virtual_intrinsic, return_depth=False):
+    """ref train_utils.py:19-55: where every pixel of the reference frame lands in the (virtual) source camera, and
+    which pixels are usable (valid depth, inside the source frame).  Same arguments (numpy arrays or tensors); the
+    O(H*W) work is the HIP kernel `ucn_img_warping`, results stay on the device: pts_in_tgt [H,W,2] float32, mask
+    [H,W] bool."""
+    lib = _lib.load()
+    d, rel, K, ctypes = _warp_inputs(ref_pose, src_pose, virtual_pose_ref_depth, virtual_intrinsic)
+    H, W = d.shape
+    pts = torch.empty(H, W, 2, device=d.device)
+    mask = torch.empty(H, W, dtype=torch.uint8, device=d.device)
+    z = torch.empty(H, W, device=d.device) if return_depth else None
+    _lib.check(lib.ucn_img_warping(d.data_ptr(), rel.data_ptr(), K.data_ptr(), H, W, pts.data_ptr(), mask.data_ptr(),
+                                   _lib.ptr(z), _lib.stream()))
+    return (pts, mask.bool(), z) if return_depth else (pts, mask.bool())
+
+
+def img_warping_for_depth(ref_pose, src_pose, virtual_pose_ref_depth, virtual_intrinsic):
+    """ref train_utils.py:58-98: the reference depth splatted into the source frame (later pixels win)."""
+    lib = _lib.load()
+    pts, mask, z = img_warping(ref_pose, src_pose, virtual_pose_ref_depth, virtual_intrinsic, return_depth=True)
+    H, W = z.shape
+    out = torch.empty(H, W, device=z.device)
+    owner = torch.empty(H, W, dtype=torch.int32, device=z.device)
+    m8 = mask.to(torch.uint8)
+    _lib.check(lib.ucn_warp_scatter_depth(pts.data_ptr(), m8.data_ptr(), z.data_ptr(), H, W, owner.data_ptr(), out.data_ptr(),
+                                          _lib.stream()))
+    return out
+
+
+def sample_virtual_pixels(pts_in_src, mask, num, generator=None):
+    """datasets.py:531-545: `num` random valid reference pixels and the source pixels they warp to
+    (torch.round = half-to-even, like the reference).  Returns int32 device tensors (ref_x, ref_y, src_x, src_y)."""
+    valid = torch.nonzero(mask)                                    # [n_valid, 2] = (y, x), row-major like pixel_coords[mask]
+    if valid.shape[0] == 0:
+        raise RuntimeError("sample_virtual_pixels: the warp leaves no valid pixel (datasets.py:528 retries another pose)")
+    pick = torch.randint(0, valid.shape[0], (num,), device=mask.device, generator=generator)
+    ry, rx = valid[pick, 0], valid[pick, 1]
+    src = torch.round(pts_in_src[ry, rx])
+    return rx.int(), ry.int(), src[:, 0].int(), src[:, 1].int()
