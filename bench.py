@@ -100,6 +100,30 @@ def virtual_warp_ms(device, steps=20):
                 valid_fraction=float(mask.float().mean()), kernel="k_img_warp (incl. the host-side 4x4 inverse and the bool cast)")
 
 
+def density_query_ms(model, device, side=256, chunk=1 << 21):
+    """the field as extract.py:28-64 `evaluate_density` consumes it (marching cubes / TSDF): a dense
+    side^3 lattice of points through nerf_mlp.predict_density(no_warp=True) in chunks."""
+    lin = torch.linspace(-1, 1, side, device=device)
+    pts = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    mlp = model.nerf_mlp
+
+    def sweep():
+        out = []
+        for p in torch.split(pts, chunk, dim=0):
+            raw = mlp.predict_density(p[:, None], torch.zeros_like(p[:, :1]), no_warp=True)[0]
+            out.append(torch.nn.functional.softplus(raw + mlp.density_bias))
+        return torch.cat(out)
+    with torch.no_grad():
+        sweep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z = sweep()
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    return dict(points=pts.shape[0], ms=ms, points_per_s=pts.shape[0] / (ms * 1e-3), finite=bool(torch.isfinite(z).all()),
+                call="nerf_mlp.predict_density(means[:, None], stds[:, None], no_warp=True)  (extract.py:54)")
+
+
 class Ranks:
     """The three attributes render_image reads from an `accelerate.Accelerator`."""
 
@@ -352,6 +376,7 @@ def main():
             res["sky_layer"] = sky_layer_ms(flat, device)
             res["ray_generation"] = ray_generation_ms(device)
             res["virtual_warp"] = virtual_warp_ms(device)
+            res["density_query"] = density_query_ms(model, device)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
