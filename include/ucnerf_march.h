@@ -205,6 +205,13 @@ int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
                   float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream);
 int ucn_distortion_loss(const float *t /*[N,S+1]*/, const float *w /*[N,S]*/, uint32_t N, uint32_t S,
                         const float *g_loss, float *out, ucn_stream_t stream);
+/* ref: train_utils.py:247-270 anti_interlevel_loss for ONE proposal level (stepfun.py:395-403 blur_stepfun +
+ * math.py:110-133 sorted_interp_quad): c [N,S_nerf+1], w [N,S_nerf] = the (detached) NeRF level; cp [N,S_prop+1],
+ * wp [N,S_prop] = the proposal level.  loss_ray [N] = sum_j max(w_s - wp, 0)^2 / (wp + 1e-5); dterm [N,S_prop] =
+ * d loss_ray / d wp (the caller applies the mean and the loss multiplier). */
+int ucn_interlevel_loss(const float *c, const float *w, uint32_t S_nerf, const float *cp, const float *wp,
+                        uint32_t S_prop, float pulse_width, uint32_t N, float *loss_ray, float *dterm,
+                        ucn_stream_t stream);
 
 /* ------------------------------------------------- virtual-pose depth warping
  * ref: train_utils.py:19-55 img_warping / :58-98 img_warping_for_depth, called per training step on a full depth

@@ -262,3 +262,30 @@ def test_distortion_loss_kernel_matches_the_quadratic_reference_form(S):
     assert got.shape == (N,)
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
     assert float((w1.grad.cpu() - w.grad).abs().max()) <= 1e-5 * float(w.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S1,Sp,r", [(128, 64, 0.03), (32, 128, 0.003), (37, 19, 0.01)])
+def test_interlevel_loss_kernel_matches_the_torch_form(S1, Sp, r):
+    """ucn_interlevel_loss (value and d/d wp) vs the torch formulation of train_utils.anti_interlevel_loss evaluated
+    on the host (blur_stepfun + interp_quad, themselves pinned to the reference's loss values by G10)."""
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator().manual_seed(S1 + Sp)
+    N = 301
+    c = torch.sort(torch.rand(N, S1 + 1, generator=g), dim=-1).values
+    c[:, 0], c[:, -1] = 0.0, 1.0
+    w = torch.rand(N, S1, generator=g) ** 4
+    w = w / w.sum(-1, keepdim=True)
+    cp = torch.sort(torch.rand(N, Sp + 1, generator=g), dim=-1).values
+    cp[:, 0], cp[:, -1] = 0.0, 1.0
+    wp0 = torch.rand(N, Sp, generator=g) ** 2
+    wp0 = wp0 / wp0.sum(-1, keepdim=True)
+    cfg = types.SimpleNamespace(anti_interlevel_loss_mult=1.0, pulse_width=[r])
+    wp = wp0.clone().requires_grad_(True)
+    want = tu.anti_interlevel_loss([dict(sdist=cp, weights=wp), dict(sdist=c, weights=w)], cfg)
+    want.backward()
+    wq = wp0.clone().cuda().requires_grad_(True)
+    got = tu.anti_interlevel_loss([dict(sdist=cp.cuda(), weights=wq), dict(sdist=c.cuda(), weights=w.cuda())], cfg)
+    got.backward()
+    assert abs(float(got) - float(want)) <= 2e-5 * max(abs(float(want)), 1e-6), (float(got), float(want))
+    assert float((wq.grad.cpu() - wp.grad).abs().max()) <= 2e-4 * float(wp.grad.abs().max())

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "ucn_distortion_loss": [c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp],
     "ucn_img_warping": [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_warp_scatter_depth": [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp],
+    "ucn_interlevel_loss": [c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp, c_vp],
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],

@@ -117,6 +117,129 @@ __global__ __launch_bounds__(256) void k_distortion(const float *__restrict__ t,
     }
 }
 
+// Anti-aliased interlevel loss of Zip-NeRF for one proposal level (train_utils.py:247-270): the NeRF level's
+// histogram (c, w) is blurred with a box of half-width r (stepfun.py:395-403 blur_stepfun: a piecewise-linear pdf on
+// the merged knots c -+ r), integrated (math.py:110-133 sorted_interp_quad) at the proposal fenceposts cp, and the
+// proposal weights wp are pushed up to the resampled ones: sum_j max(w_s - wp, 0)^2 / (wp + 1e-5).  The NeRF level is
+// detached, so only d/d wp exists.  One wave per ray; the reference's sort of 2(S+1) knots is a two-list merge rank,
+// its O(n m) interpolation masks a binary search, its cumulative sums wave scans (accumulated in double like
+// torch-CPU's cumsum; the reference's device cumsum is fp32 and agrees to ~3e-5).
+__device__ __forceinline__ double wscan_d(double v, int lane) {      // inclusive; torch-CPU's cumsum accumulates in double
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_interlevel(const float *__restrict__ c_, const float *__restrict__ w_, uint32_t S1,
+                                                    const float *__restrict__ cp_, const float *__restrict__ wp_, uint32_t Sp, float r,
+                                                    uint32_t N, float *__restrict__ loss_ray, float *__restrict__ dterm) {
+    extern __shared__ float s_il[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ray_raw = blockIdx.x * 4u + wv;
+    const bool live = ray_raw < N;
+    const uint32_t ray = live ? ray_raw : N - 1;
+    const uint32_t n1 = S1 + 1, m = 2 * n1;
+    float *c = s_il + (size_t)wv * (n1 + S1 + 4 * m + (Sp + 1));
+    float *pdf = c + n1, *kn = pdf + S1, *ds = kn + m, *vals = ds + m, *cdf = vals + m, *q = cdf + m;
+    for (uint32_t i = lane; i < n1; i += 64) c[i] = c_[(size_t)ray * n1 + i];
+    __syncthreads();
+    for (uint32_t i = lane; i < S1; i += 64) pdf[i] = w_[(size_t)ray * S1 + i] / (c[i + 1] - c[i]);
+    __syncthreads();
+    // merged knots of (c - r) and (c + r) with the slope jumps +-y1 attached (blur_stepfun)
+    for (uint32_t e = lane; e < m; e += 64) {
+        const bool second = e >= n1;
+        const uint32_t i = second ? e - n1 : e;
+        const float y1 = ((i < S1 ? pdf[i] : 0.0f) - (i > 0 ? pdf[i - 1] : 0.0f)) / (2.0f * r);
+        const float v = second ? c[i] + r : c[i] - r;
+        uint32_t lo = 0, hi = n1;                          // #other-list elements ordered before v
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const float o = second ? c[mid] - r : c[mid] + r;
+            if (second ? (o <= v) : (o < v)) lo = mid + 1;
+            else hi = mid;
+        }
+        kn[i + lo] = v;
+        ds[i + lo] = second ? -y1 : y1;
+    }
+    __syncthreads();
+    // vals = [0, clamp_min(cumsum(dx * cumsum(dslope[:-1])), 0)], cdf = [0, cumsum(trapezoids)]: lane owns CH knots
+    const uint32_t CH = (m + 63) / 64;
+    double part = 0.0;
+    for (uint32_t k = 0; k < CH; k++) {
+        const uint32_t i = lane * CH + k;
+        if (i + 1 < m) part += (double)ds[i];
+    }
+    double run = wscan_d(part, lane) - part;
+    double part2 = 0.0;
+    for (uint32_t k = 0; k < CH; k++) {
+        const uint32_t i = lane * CH + k;
+        if (i + 1 < m) {
+            run += (double)ds[i];
+            const float inc = (kn[i + 1] - kn[i]) * (float)run;       // cumsum(dslope) is a float tensor in the reference
+            cdf[i] = inc;                                  // parked: the increments of the second cumsum
+            part2 += (double)inc;
+        }
+    }
+    __syncthreads();
+    double run2 = wscan_d(part2, lane) - part2;
+    for (uint32_t k = 0; k < CH; k++) {
+        const uint32_t i = lane * CH + k;
+        if (i + 1 < m) {
+            run2 += (double)cdf[i];
+            vals[i + 1] = fmaxf((float)run2, 0.0f);
+        }
+    }
+    if (lane == 0) vals[0] = 0.0f;
+    __syncthreads();
+    double part3 = 0.0;
+    for (uint32_t k = 0; k < CH; k++) {
+        const uint32_t i = lane * CH + k;
+        if (i + 1 < m) part3 += (double)(0.5f * (vals[i + 1] + vals[i]) * (kn[i + 1] - kn[i]));
+    }
+    double run3 = wscan_d(part3, lane) - part3;
+    for (uint32_t k = 0; k < CH; k++) {
+        const uint32_t i = lane * CH + k;
+        if (i + 1 < m) {
+            run3 += (double)(0.5f * (vals[i + 1] + vals[i]) * (kn[i + 1] - kn[i]));
+            cdf[i + 1] = (float)run3;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) cdf[0] = 0.0f;
+    __syncthreads();
+    // integrate the blurred pdf up to every proposal fencepost (sorted_interp_quad)
+    for (uint32_t j = lane; j <= Sp; j += 64) {
+        const float x = cp_[(size_t)ray * (Sp + 1) + j];
+        uint32_t lo = 0, hi = m;                           // #(knots <= x)
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (kn[mid] <= x) lo = mid + 1;
+            else hi = mid;
+        }
+        const uint32_t i0 = lo > 0 ? lo - 1 : 0, i1 = lo < m - 1 ? lo : m - 1;
+        const float xp0 = kn[i0], xp1 = kn[i1], p0 = vals[i0], p1 = vals[i1];
+        float off = (x - xp0) / (xp1 - xp0);
+        if (off != off) off = 0.0f;                        // nan_to_num(.., 0).clamp(0, 1)
+        else if (off == INFINITY) off = 3.4028234663852886e38f;
+        else if (off == -INFINITY) off = -3.4028234663852886e38f;
+        off = fminf(fmaxf(off, 0.0f), 1.0f);
+        q[j] = cdf[i0] + (x - xp0) * (p0 + p1 * off + p0 * (1.0f - off)) / 2.0f;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    for (uint32_t j = lane; j < Sp; j += 64) {
+        const float ws = q[j + 1] - q[j], wp = wp_[(size_t)ray * Sp + j];
+        const float ex = fmaxf(ws - wp, 0.0f), den = wp + 1e-5f;
+        acc += ex * ex / den;
+        if (live) dterm[(size_t)ray * Sp + j] = -2.0f * ex / den - ex * ex / (den * den);
+    }
+    acc = wsum(acc);
+    if (lane == 0 && live) loss_ray[ray] = acc;
+}
+
 }  // namespace
 
 extern "C" int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
@@ -154,5 +277,20 @@ extern "C" int ucn_distortion_loss(const float *t, const float *w, uint32_t N, u
     else UCN_DL(8);
 #undef UCN_DL
     UCN_LAUNCH_CHECK("distortion_loss");
+    return 0;
+}
+
+extern "C" int ucn_interlevel_loss(const float *c, const float *w, uint32_t S_nerf, const float *cp, const float *wp, uint32_t S_prop,
+                                   float pulse_width, uint32_t N, float *loss_ray, float *dterm, ucn_stream_t stream) {
+    if (N == 0) return 0;
+    UCN_REQUIRE(c && w && cp && wp && loss_ray && dterm, "interlevel_loss: null pointer argument");
+    UCN_REQUIRE(S_nerf >= 1 && S_nerf <= 512 && S_prop >= 1 && S_prop <= 1024, "interlevel_loss: unsupported sample counts %u / %u",
+                S_nerf, S_prop);
+    UCN_REQUIRE(pulse_width > 0.0f, "interlevel_loss: pulse width must be positive");
+    const uint32_t n1 = S_nerf + 1, m = 2 * n1;
+    const size_t lds = 4 * sizeof(float) * ((size_t)n1 + S_nerf + 4 * m + (S_prop + 1));
+    hipLaunchKernelGGL(k_interlevel, dim3(ucn_div_up(N, 4)), dim3(256), lds, (hipStream_t)stream, c, w, S_nerf, cp, wp, S_prop, pulse_width,
+                       N, loss_ray, dterm);
+    UCN_LAUNCH_CHECK("interlevel_loss");
     return 0;
 }

@@ -85,6 +85,33 @@ def interp_quad(x, xp, fpdf, fcdf):
     return c0 + (x - xp0) * (p0 + p1 * off + p0 * (1 - off)) / 2
 
 
+class _InterLevel(torch.autograd.Function):
+    """One proposal level of anti_interlevel_loss as the HIP kernel `ucn_interlevel_loss`: mean over rays and proposal
+    intervals of max(w_s - wp, 0)^2 / (wp + 1e-5); the NeRF level (c, w) and the fenceposts cp are constants."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, c, w, cp, wp, r):
+        lib = _lib.load()
+        S1, Sp = w.shape[-1], wp.shape[-1]
+        c2, w2 = c.reshape(-1, S1 + 1).contiguous(), w.reshape(-1, S1).contiguous()
+        cp2, wp2 = cp.reshape(-1, Sp + 1).contiguous(), wp.reshape(-1, Sp).contiguous()
+        N = w2.shape[0]
+        loss_ray = torch.empty(N, device=w.device)
+        dterm = torch.empty(N, Sp, device=w.device)
+        _lib.check(lib.ucn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), S1, cp2.data_ptr(), wp2.data_ptr(), Sp, float(r), N,
+                                           loss_ray.data_ptr(), dterm.data_ptr(), _lib.stream()))
+        ctx.save_for_backward(dterm)
+        ctx.shape = wp.shape
+        return loss_ray.sum() / (N * Sp)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (dterm,) = ctx.saved_tensors
+        return None, None, None, (dterm * (g / dterm.numel())).reshape(ctx.shape), None
+
+
 # ------------------------------------------------------------------ losses (train.py:173-216)
 def compute_data_loss(batch, renderings, config):
     """ref train_utils.py:171-230 ('mse' and 'charb')."""
@@ -120,6 +147,9 @@ def anti_interlevel_loss(ray_history, config):
     widths = getattr(config, 'pulse_width', [0.03, 0.003])
     for i, level in enumerate(ray_history[:-1]):
         cp, wp = level['sdist'], level['weights']
+        if wp.is_cuda and not cp.requires_grad and w.shape[-1] <= 512:
+            total = total + _InterLevel.apply(c, w, cp, wp, widths[i])     # the same arithmetic as one HIP launch
+            continue
         knots, vals = blur_stepfun(c, pdf, widths[i])
         area = 0.5 * (vals[..., 1:] + vals[..., :-1]) * (knots[..., 1:] - knots[..., :-1])
         cdf = torch.cat([torch.zeros_like(area[..., :1]), torch.cumsum(area, dim=-1)], dim=-1)
