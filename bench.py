@@ -327,9 +327,9 @@ def main():
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         gather["frac"] = gather["achieved"] / gather["peak"]
         # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
-        # same command (profiles/r01e_final/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)
+        # same command (profiles/r01f_final/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_final", "traffic.json")))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_final", "traffic.json")))
             gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
             gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
                                       "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
