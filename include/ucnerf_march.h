@@ -143,9 +143,9 @@ int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const 
                                 const float *radii, const float *flip, const float *spin, float std_scale,
                                 uint32_t N, uint32_t S, uint32_t levels_per_block, int sample_major,
                                 const float *grad_features, float *grad_embeddings,
-                                float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(f,N,S) floats (24 planes of
-                                                   sample geometry + per-level row-block masks + a level-major copy
-                                                   of a layout-1/3 gradient), or NULL: the row-block
+                                float *workspace /*DEVICE, ucn_march_features_backward_ws_floats(f,N,S) floats (the
+                                                   samples' geometry cache + per-level row-block masks + a
+                                                   level-major copy of a layout-1/3 gradient), or NULL: the row-block
                                                    algorithm then re-derives the geometry in every workgroup and
                                                    cannot compact its work (several times slower)*/,
                                 ucn_stream_t stream);

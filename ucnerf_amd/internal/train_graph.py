@@ -1,4 +1,4 @@
-"""Differentiable (training) form of Model.forward -- SURVEY.md 8(a15/a16), round-1 state.
+"""Differentiable (training) form of Model.forward -- SURVEY.md 8(a15/a16).
 
 What carries gradients in the reference's training step (train.py:165-221): the hash tables (through
 _grid_encode.backward, grid.py:68-89), the MLP weights, and -- when enabled -- the sky / colour-correction
@@ -6,12 +6,14 @@ parameters.  Sample positions do not (`stop_level_grad`, models.py:204-205; `tra
 @torch.no_grad, coord.py:75).  Here:
 
 * resampling, cone basis and the fused cast/contract/hash-grid/erf featurisation are the same HIP kernels as
-  in rendering; their backward (`ucn_march_features_backward`, fp32 atomics into the table gradient) is
-  hand-written HIP and replaces kernel_grid_backward + the autograd of the erf/mean glue;
-* the dense layers and the O(S) per-ray compositing run as library GEMMs / elementwise ops under torch
-  autograd (hipBLASLt via F.linear; bf16 under autocast like the reference's `accelerator.autocast()`).
-  A fused MFMA backward on the register-chained engine is the next step; until then this
-  is a GPU path through vendor GEMMs, not a fallback to the CPU: host tensors still raise.
+  in rendering; the featurisation's backward (`ucn_march_features_backward`: LDS row blocks + compaction, no
+  global atomics) is hand-written HIP and replaces kernel_grid_backward + the autograd of the erf/mean glue;
+* alpha compositing (weights, rgb, depth, acc) is `ucn_composite` forward and `ucn_composite_backward`;
+* the dense layers run as library GEMMs under torch autograd (hipBLASLt; bf16 under autocast like the reference's
+  `accelerator.autocast()`), arranged so that nothing of size [N*S, 283] / [N*S, 539] is ever concatenated and the
+  weight / bias gradients are split-K batched GEMMs.  A fused MFMA backward on the register-chained engine is the
+  next step; until then this is a GPU path through vendor GEMMs, not a fallback to the CPU:
+  host tensors still raise.
 """
 import ctypes
 
