@@ -225,6 +225,14 @@ int ucn_img_warping(const float *depth, const float *rel_pose_host, const float 
 int ucn_warp_scatter_depth(const float *pts, const uint8_t *mask, const float *z_src, uint32_t H, uint32_t W,
                            uint32_t *owner_ws, float *depth_tgt, ucn_stream_t stream);
 
+/* Elementwise halves of the colour MLP's hidden layers in the training graph (models.py:615-640 under autograd):
+ * ucn_bias_relu: pre_inout [N*S, W] <- relu(pre + per_ray[ray]) with per_ray [N, W] (the direction block of the
+ * layer times the ray's encoding, plus the bias); ucn_relu_backward_reduce: d_pre = gy * [h > 0] and
+ * d_per_ray [N, W] = sum over the ray's S samples of d_pre.  dtype 0 = float32, 2 = bfloat16 (autocast); W % 8 == 0. */
+int ucn_bias_relu(void *pre_inout, const void *per_ray, uint32_t N, uint32_t S, uint32_t W, int dtype, ucn_stream_t stream);
+int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d_per_ray, uint32_t N, uint32_t S,
+                             uint32_t W, int dtype, ucn_stream_t stream);
+
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
  * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the

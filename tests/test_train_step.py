@@ -289,3 +289,42 @@ def test_interlevel_loss_kernel_matches_the_torch_form(S1, Sp, r):
     got.backward()
     assert abs(float(got) - float(want)) <= 2e-5 * max(abs(float(want)), 1e-6), (float(got), float(want))
     assert float((wq.grad.cpu() - wp.grad).abs().max()) <= 2e-4 * float(wp.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_colour_mlp_node_matches_the_concatenated_reference_form():
+    """_ColourMLP (block-wise GEMMs + ucn_bias_relu / ucn_relu_backward_reduce, one autograd node) against the
+    reference's formulation written out with its concatenations (models.py:615-640) and torch autograd.  fp32: equal
+    to GEMM re-association.  bf16 autocast: a rounding that flips a ReLU mask changes a gradient element by O(1), so the
+    reference's own autocast run is ~0.2 away from its fp32 run in d x; the node has to be as close to the fp32 run as
+    the reference's autocast run is."""
+    import torch.nn.functional as F
+    from ucnerf_amd.internal import train_graph as tg
+    torch.manual_seed(3)
+    N, S, NB, NW, ND = 64, 128, 256, 256, 27
+    l0, l1 = torch.nn.Linear(NB + ND, NW).cuda(), torch.nn.Linear(NW + NB + ND, NW).cuda()
+    x = torch.randn(N * S, NB, device="cuda")
+    enc = torch.randn(N, ND, device="cuda")
+    gout = torch.randn(N * S, NW, device="cuda")
+    params = (l0.weight, l0.bias, l1.weight, l1.bias)
+
+    def reference(x):
+        e = enc[:, None, :].expand(N, S, ND).reshape(N * S, ND)
+        h0 = torch.cat([x, e], dim=-1)
+        h1 = F.relu(F.linear(h0, l0.weight, l0.bias))
+        return F.relu(F.linear(torch.cat([h1, h0], dim=-1), l1.weight, l1.bias))
+
+    def run(node, bf16):
+        for p in params:
+            p.grad = None
+        xin = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            out = tg._ColourMLP.apply(xin, enc, *params, N, S) if node else reference(xin)
+        (out.float() * gout).sum().backward()
+        return [out.detach().float(), xin.grad.float()] + [p.grad.float().clone() for p in params]
+
+    truth, node32, ref16, node16 = run(False, False), run(True, False), run(False, True), run(True, True)
+    for a, b, c, t, what in zip(node32, ref16, node16, truth, ("h2", "dx", "dW0", "db0", "dW1", "db1")):
+        scale = max(1.0, float(t.abs().max()))
+        assert float((a - t).abs().max()) <= 2e-5 * scale, ("fp32", what)
+        assert float((c - t).abs().max()) <= 1.5 * float((b - t).abs().max()) + 2e-3 * scale, ("bf16", what)

@@ -240,6 +240,108 @@ __global__ __launch_bounds__(256) void k_interlevel(const float *__restrict__ c_
     if (lane == 0 && live) loss_ray[ray] = acc;
 }
 
+// ---- elementwise halves of the colour MLP's hidden layers in training (models.py:615-640 under autograd).
+// The reference concatenates the per-ray direction encoding to every sample; here it enters as a per-RAY row
+// (direction block of the weight times the encoding, plus the bias) that is broadcast over the ray's S samples:
+//   forward   h = relu(pre + per_ray[ray])                      (in place over the GEMM output)
+//   backward  d_pre = gy * [h > 0],  d_per_ray[ray] = sum_s d_pre   (the second feeds the direction-weight and bias
+//             gradients: a reduction over rays instead of samples)
+// T = float (no autocast) or bf16 (the reference's accelerator.autocast()): arithmetic in fp32, one rounding per store,
+// which is what torch's bf16 elementwise kernels do.
+struct Bf16 { uint16_t v; };
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(Bf16 x) { return __uint_as_float((uint32_t)x.v << 16); }
+__device__ __forceinline__ void from_f32(float f, float &o) { o = f; }
+__device__ __forceinline__ void from_f32(float f, Bf16 &o) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);                       // round to nearest even (finite inputs)
+    o.v = (uint16_t)(u >> 16);
+}
+
+// 8 consecutive elements as fp32 (16-byte vector accesses; the pointers are 16-byte aligned: W % 8 == 0)
+__device__ __forceinline__ void load8(const float *p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const Bf16 *p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[2 * k] = __uint_as_float(w[k] << 16);
+        v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ void store8(float *p, const float (&v)[8]) {
+    reinterpret_cast<float4 *>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4 *>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(Bf16 *p, const float (&v)[8]) {       // v already rounded to bf16 values
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = (__float_as_uint(v[2 * k]) >> 16) | (__float_as_uint(v[2 * k + 1]) & 0xFFFF0000u);
+    *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// x rounded to the storage type, as fp32
+__device__ __forceinline__ float rounded(float x, const float *) { return x; }
+__device__ __forceinline__ float rounded(float x, const Bf16 *) {
+    Bf16 o;
+    from_f32(x, o);
+    return to_f32(o);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias_relu(T *__restrict__ pre, const T *__restrict__ per_ray, uint64_t total, uint32_t W,
+                                                   uint32_t S) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 8u;          // 8 consecutive columns of one row
+    if (i0 >= total) return;
+    const uint64_t row = i0 / W;
+    const uint32_t col = (uint32_t)(i0 - row * W);
+    float a[8], b[8];
+    load8(pre + i0, a);
+    load8(per_ray + (row / S) * W + col, b);
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = rounded(fmaxf(a[k] + b[k], 0.0f), pre);
+    store8(pre + i0, a);
+}
+
+// One workgroup per ray: thread = (column group of 8, one of SL sample lanes); partial column sums meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void k_relu_bwd_reduce(const T *__restrict__ gy, const T *__restrict__ h, T *__restrict__ d_pre,
+                                                         T *__restrict__ d_per_ray, uint32_t S, uint32_t W) {
+    __shared__ float s_part[256 * 8];
+    const uint32_t ray = blockIdx.x, groups = W / 8u, lanes = 256u / groups;   // W = 256 -> 32 groups x 8 sample lanes
+    const uint32_t cg = threadIdx.x % groups, sl = threadIdx.x / groups;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (sl < lanes) {
+        for (uint32_t s = sl; s < S; s += lanes) {
+            const uint64_t i0 = ((uint64_t)ray * S + s) * W + cg * 8u;
+            float g[8], a[8];
+            load8(gy + i0, g);
+            load8(h + i0, a);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                g[k] = a[k] > 0.0f ? rounded(g[k], d_pre) : 0.0f;
+                acc[k] += g[k];                             // the sum torch forms reads the ROUNDED d_pre
+            }
+            store8(d_pre + i0, g);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_part[threadIdx.x * 8 + k] = acc[k];
+    __syncthreads();
+    if (sl == 0) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            t[k] = 0.0f;
+            for (uint32_t q = 0; q < lanes; q++) t[k] += s_part[(q * groups + cg) * 8 + k];
+            t[k] = rounded(t[k], d_per_ray);
+        }
+        store8(d_per_ray + (uint64_t)ray * W + cg * 8u, t);
+    }
+}
+
 }  // namespace
 
 extern "C" int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
@@ -292,5 +394,34 @@ extern "C" int ucn_interlevel_loss(const float *c, const float *w, uint32_t S_ne
     hipLaunchKernelGGL(k_interlevel, dim3(ucn_div_up(N, 4)), dim3(256), lds, (hipStream_t)stream, c, w, S_nerf, cp, wp, S_prop, pulse_width,
                        N, loss_ray, dterm);
     UCN_LAUNCH_CHECK("interlevel_loss");
+    return 0;
+}
+
+extern "C" int ucn_bias_relu(void *pre_inout, const void *per_ray, uint32_t N, uint32_t S, uint32_t W, int dtype, ucn_stream_t stream) {
+    if ((uint64_t)N * S * W == 0) return 0;
+    UCN_REQUIRE(pre_inout && per_ray, "bias_relu: null pointer argument");
+    UCN_REQUIRE(W % 8 == 0, "bias_relu: width must be a multiple of 8, got %u", W);
+    UCN_REQUIRE(dtype == 0 || dtype == 2, "bias_relu: dtype must be 0 (float32) or 2 (bfloat16)");
+    const uint64_t total = (uint64_t)N * S * W;
+    const dim3 grid((uint32_t)((total / 8 + 255) / 256));
+    if (dtype == 0) hipLaunchKernelGGL(k_bias_relu<float>, grid, dim3(256), 0, (hipStream_t)stream, (float *)pre_inout, (const float *)per_ray, total, W, S);
+    else hipLaunchKernelGGL(k_bias_relu<Bf16>, grid, dim3(256), 0, (hipStream_t)stream, (Bf16 *)pre_inout, (const Bf16 *)per_ray, total, W, S);
+    UCN_LAUNCH_CHECK("bias_relu");
+    return 0;
+}
+
+extern "C" int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d_per_ray, uint32_t N, uint32_t S, uint32_t W,
+                                        int dtype, ucn_stream_t stream) {
+    if ((uint64_t)N * S * W == 0) return 0;
+    UCN_REQUIRE(gy && h && d_pre && d_per_ray, "relu_backward_reduce: null pointer argument");
+    UCN_REQUIRE(W % 8 == 0 && W / 8 <= 256 && 256 % (W / 8) == 0, "relu_backward_reduce: unsupported width %u", W);
+    UCN_REQUIRE(dtype == 0 || dtype == 2, "relu_backward_reduce: dtype must be 0 (float32) or 2 (bfloat16)");
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_relu_bwd_reduce<float>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float *)gy, (const float *)h,
+                           (float *)d_pre, (float *)d_per_ray, S, W);
+    else
+        hipLaunchKernelGGL(k_relu_bwd_reduce<Bf16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const Bf16 *)gy, (const Bf16 *)h,
+                           (Bf16 *)d_pre, (Bf16 *)d_per_ray, S, W);
+    UCN_LAUNCH_CHECK("relu_backward_reduce");
     return 0;
 }

@@ -162,6 +162,72 @@ def view_encoding(d, deg):
     return torch.cat([d, torch.sin(torch.cat([scaled, scaled + 0.5 * torch.pi], dim=-1))], dim=-1)
 
 
+def _wgrad(gy, x):
+    """gy^T @ x for tall operands [M, a], [M, b] -> [a, b] float32, the reduction over M cut into batched chunks
+    (see _TallLinear)."""
+    m, c = x.shape[0], _TallLinear.CHUNK
+    if m >= 4 * c and m % c == 0:
+        return torch.bmm(gy.reshape(m // c, c, -1).transpose(1, 2), x.reshape(m // c, c, -1)).float().sum(0)
+    return (gy.t() @ x).float()
+
+
+class _ColourMLP(torch.autograd.Function):
+    """The two hidden layers of the colour MLP in the reference's topology (models.py:615-640: net_depth_viewdirs = 2,
+    skip connection after layer 0) as ONE autograd node:
+
+        h1 = relu(x W0x^T + [enc W0e^T + b0]_ray),   h2 = relu(h1 W1h^T + x W1x^T + [enc W1e^T + b1]_ray)
+
+    with W0 = [W0x | W0e], W1 = [W1h | W1x | W1e] the reference's weights over its concatenated inputs
+    [bottleneck, dir_enc] and [h1, bottleneck, dir_enc].  The GEMMs are library GEMMs (bf16 under autocast); the
+    broadcast-add + ReLU and its backward (mask + per-ray reduction) are the HIP kernels ucn_bias_relu /
+    ucn_relu_backward_reduce, in place; the two contributions to d x accumulate inside the second GEMM (addmm), so
+    no activation-sized tensor is added, concatenated or re-read by an elementwise kernel."""
+
+    @staticmethod
+    def forward(ctx, x, enc, W0, b0, W1, b1, N, S):
+        lib = _lib.load()
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
+        code = {torch.float32: 0, torch.bfloat16: 2}[dt]
+        NB, NW = x.shape[1], W0.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            xb, eb = x.to(dt).contiguous(), enc.to(dt)
+            W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
+            W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
+            pr0 = torch.addmm(b0.to(dt), eb, W0e.t()).contiguous()                       # [N, NW] per ray
+            h1 = xb @ W0x.t()
+            _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
+            pr1 = torch.addmm(b1.to(dt), eb, W1e.t()).contiguous()
+            h2 = torch.addmm(h1 @ W1h.t(), xb, W1x.t())
+            _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
+        ctx.save_for_backward(xb, eb, h1, h2, W0x, W1h, W1x)
+        ctx.meta = (N, S, NB, NW, code, x.dtype, W0.dtype, b0.dtype)
+        ctx.mark_non_differentiable()
+        return h2
+
+    @staticmethod
+    def backward(ctx, g_h2):
+        lib = _lib.load()
+        xb, eb, h1, h2, W0x, W1h, W1x = ctx.saved_tensors
+        N, S, NB, NW, code, x_dt, w_dt, b_dt = ctx.meta
+        dt = xb.dtype
+        with torch.autocast("cuda", enabled=False):
+            g = g_h2.to(dt).contiguous()
+            d1 = torch.empty_like(g)
+            r1 = torch.empty(N, NW, device=g.device, dtype=dt)
+            _lib.check(lib.ucn_relu_backward_reduce(g.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, code,
+                                                    _lib.stream()))
+            d_h1 = d1 @ W1h
+            d0 = d_h1                                                                     # masked in place
+            r0 = torch.empty(N, NW, device=g.device, dtype=dt)
+            _lib.check(lib.ucn_relu_backward_reduce(d_h1.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, code,
+                                                    _lib.stream()))
+            gW0 = torch.cat([_wgrad(d0, xb), (r0.t() @ eb).float()], dim=1)
+            gW1 = torch.cat([_wgrad(d1, h1), _wgrad(d1, xb), (r1.t() @ eb).float()], dim=1)
+            gb0, gb1 = r0.float().sum(0), r1.float().sum(0)
+            gx = torch.addmm(d1 @ W1x, d0, W0x)                                           # both paths into x in one output
+        return gx.to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
+
+
 def field_heads(mlp, feat, viewdirs, N, S):
     """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs).
 
@@ -175,6 +241,11 @@ def field_heads(mlp, feat, viewdirs, N, S):
     if mlp.disable_rgb:
         return density, torch.zeros(N, S, 3, device=feat.device)
     enc = view_encoding(viewdirs, mlp.deg_view)                                                  # [N, 27], per ray
+    if mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and mlp.net_width_viewdirs % 8 == 0:
+        l0, l1 = mlp.lin_second_stage_0, mlp.lin_second_stage_1                                  # the reference's topology
+        h = _ColourMLP.apply(x, enc, l0.weight, l0.bias, l1.weight, l1.bias, N, S)
+        rgb = torch.sigmoid(mlp.rgb_premultiplier * tall_linear(mlp.rgb_layer, h).reshape(N, S, -1) + mlp.rgb_bias)
+        return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
     per_sample, skip, with_enc = [x], [x], True            # column blocks of the next layer's input, in cat order
     for i in range(mlp.net_depth_viewdirs):
         lin = mlp.get_submodule(f"lin_second_stage_{i}")
