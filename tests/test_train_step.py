@@ -319,7 +319,7 @@ def test_colour_mlp_node_matches_the_concatenated_reference_form():
             p.grad = None
         xin = x.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
-            out = tg._ColourMLP.apply(xin, enc, *params, N, S) if node else reference(xin)
+            out = tg._ColourMLP.apply(xin, enc, *params, N, S)[0] if node else reference(xin)
         (out.float() * gout).sum().backward()
         return [out.detach().float(), xin.grad.float()] + [p.grad.float().clone() for p in params]
 

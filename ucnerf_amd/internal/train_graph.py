@@ -177,6 +177,9 @@ class _ColourMLP(torch.autograd.Function):
 
         h1 = relu(x W0x^T + [enc W0e^T + b0]_ray),   h2 = relu(h1 W1h^T + x W1x^T + [enc W1e^T + b1]_ray)
 
+    (second output: column 0 of x, the raw density, so that its gradient joins d x inside the node instead of through
+    a zero-filled [N*S, 256] tensor and an add)
+
     with W0 = [W0x | W0e], W1 = [W1h | W1x | W1e] the reference's weights over its concatenated inputs
     [bottleneck, dir_enc] and [h1, bottleneck, dir_enc].  The GEMMs are library GEMMs (bf16 under autocast); the
     broadcast-add + ReLU and its backward (mask + per-ray reduction) are the HIP kernels ucn_bias_relu /
@@ -197,15 +200,14 @@ class _ColourMLP(torch.autograd.Function):
             h1 = xb @ W0x.t()
             _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
             pr1 = torch.addmm(b1.to(dt), eb, W1e.t()).contiguous()
-            h2 = torch.addmm(h1 @ W1h.t(), xb, W1x.t())
+            h2 = (h1 @ W1h.t()).addmm_(xb, W1x.t())                                      # accumulate in place: no copy
             _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
         ctx.save_for_backward(xb, eb, h1, h2, W0x, W1h, W1x)
         ctx.meta = (N, S, NB, NW, code, x.dtype, W0.dtype, b0.dtype)
-        ctx.mark_non_differentiable()
-        return h2
+        return h2, xb[:, 0].clone()                       # raw density = column 0 of the bottleneck (models.py:508)
 
     @staticmethod
-    def backward(ctx, g_h2):
+    def backward(ctx, g_h2, g_raw):
         lib = _lib.load()
         xb, eb, h1, h2, W0x, W1h, W1x = ctx.saved_tensors
         N, S, NB, NW, code, x_dt, w_dt, b_dt = ctx.meta
@@ -224,7 +226,9 @@ class _ColourMLP(torch.autograd.Function):
             gW0 = torch.cat([_wgrad(d0, xb), (r0.t() @ eb).float()], dim=1)
             gW1 = torch.cat([_wgrad(d1, h1), _wgrad(d1, xb), (r1.t() @ eb).float()], dim=1)
             gb0, gb1 = r0.float().sum(0), r1.float().sum(0)
-            gx = torch.addmm(d1 @ W1x, d0, W0x)                                           # both paths into x in one output
+            gx = (d1 @ W1x).addmm_(d0, W0x)                                               # both paths into x in one output
+            if g_raw is not None:
+                gx[:, 0] += g_raw.reshape(-1).to(dt)                                      # the density head's column
         return gx.to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
 
 
@@ -237,15 +241,16 @@ def field_heads(mlp, feat, viewdirs, N, S):
     [N, 27] GEMM broadcast over the samples -- no [N*S, 283] / [N*S, 539] concatenations, 7 % fewer flops, and the
     bias / direction-weight gradients reduce over rays instead of samples."""
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
-    density = F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias)
     if mlp.disable_rgb:
-        return density, torch.zeros(N, S, 3, device=feat.device)
+        return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)
     enc = view_encoding(viewdirs, mlp.deg_view)                                                  # [N, 27], per ray
     if mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and mlp.net_width_viewdirs % 8 == 0:
         l0, l1 = mlp.lin_second_stage_0, mlp.lin_second_stage_1                                  # the reference's topology
-        h = _ColourMLP.apply(x, enc, l0.weight, l0.bias, l1.weight, l1.bias, N, S)
+        h, raw = _ColourMLP.apply(x, enc, l0.weight, l0.bias, l1.weight, l1.bias, N, S)
+        density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
         rgb = torch.sigmoid(mlp.rgb_premultiplier * tall_linear(mlp.rgb_layer, h).reshape(N, S, -1) + mlp.rgb_bias)
         return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
+    density = F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias)
     per_sample, skip, with_enc = [x], [x], True            # column blocks of the next layer's input, in cat order
     for i in range(mlp.net_depth_viewdirs):
         lin = mlp.get_submodule(f"lin_second_stage_{i}")
