@@ -125,6 +125,11 @@ class _TallLinear(torch.autograd.Function):
             chunked = m >= 4 * c and m % c == 0
             if chunked:
                 gyc = gy2.reshape(m // c, c, -1)
+            if gy2.shape[1] == 1:
+                # a single output row (PropMLP's density head): every library route for it (bmm with one row, mv)
+                # takes an 11 ms HOST-side path in bf16 on this stack, which made the whole step CPU-bound
+                gw = (gy2 * x2).float().sum(0, keepdim=True)
+            elif chunked:
                 gw = torch.bmm(gyc.transpose(1, 2), x2.reshape(m // c, c, -1)).float().sum(0)
             else:
                 gw = (gy2.t() @ x2).float()
