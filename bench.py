@@ -124,6 +124,26 @@ def density_query_ms(model, device, side=256, chunk=1 << 21):
                 call="nerf_mlp.predict_density(means[:, None], stds[:, None], no_warp=True)  (extract.py:54)")
 
 
+def hbm_probe(device, n_floats=1 << 28, steps=10):
+    """What a plain device-to-device copy kernel (`ucn_probe_copy`, float4 per lane) reaches on this part: the
+    practical ceiling behind the 8 TB/s spec figure that `roofline.peak` uses."""
+    import ctypes  # noqa: F401
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    src = torch.empty(n_floats, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        _lib.check(lib.ucn_probe_copy(src.data_ptr(), dst.data_ptr(), n_floats, _lib.stream()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        _lib.check(lib.ucn_probe_copy(src.data_ptr(), dst.data_ptr(), n_floats, _lib.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return dict(bytes_read_plus_written=8 * n_floats, ms=ms, GBps=8 * n_floats / (ms * 1e-3) / 1e9, spec_peak_GBps=PEAK_HBM_GBS)
+
+
 class Ranks:
     """The three attributes render_image reads from an `accelerate.Accelerator`."""
 
@@ -377,6 +397,7 @@ def main():
             res["ray_generation"] = ray_generation_ms(device)
             res["virtual_warp"] = virtual_warp_ms(device)
             res["density_query"] = density_query_ms(model, device)
+            res["hbm_probe"] = hbm_probe(device)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
