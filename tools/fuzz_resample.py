@@ -1,0 +1,33 @@
+"""Fuzz: k_resample vs the oracle chain (accepted when as close to the float64 evaluation as the float32 oracle) over 150 (n_prev, S, dilation) combinations (run on the GPU box)."""
+import sys, itertools
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import torch
+import helpers as H
+from oracle import raymarch as rm
+from ucnerf_amd import _lib
+from test_gpu_parity import _resample, dev
+lib = _lib.load()
+bad = 0
+for n_prev, S, dil, seed in itertools.product((1, 2, 3, 5, 63, 64, 65, 129, 255, 256), (2, 3, 64, 127, 511), (0.0, 0.0103, 0.2), (0,)):
+    g = torch.Generator().manual_seed(seed * 1000 + n_prev * 7 + S)
+    N = 37
+    t = torch.sort(torch.rand(N, n_prev + 1, generator=g), dim=-1).values
+    t[:, 0], t[:, -1] = 0.0, 1.0
+    w = torch.rand(N, n_prev, generator=g) ** 3 + 1e-4
+    w = w / w.sum(-1, keepdim=True)
+    anneal = 1.0
+    jit = torch.rand(N, 1, generator=g)
+    def chain(t, w, jit):
+        td, wd = rm.dilate_weights(t, w, dil, 0.0, 1.0)
+        td, wd = td[..., 1:-1], wd[..., 1:-1]
+        logits = torch.where(td[..., 1:] > td[..., :-1], anneal * torch.log(wd), torch.full_like(wd, -torch.inf))
+        return rm.sample_fenceposts(td, logits, S, 0.0, 1.0, jit)
+    want = chain(t, w, jit); truth = chain(t.double(), w.double(), jit.double())
+    got = _resample(lib, dev(t), dev(w), dil, anneal, S, jitter=dev(jit))
+    e_ref = (want.double() - truth).abs().amax(-1, keepdim=True); e_hip = (got.double() - truth).abs()
+    ok = ((got - want).abs() <= 2e-6) | (e_hip <= 4 * e_ref + 1e-5)
+    mono = bool((got[:, 1:] >= got[:, :-1]).all())
+    if not (ok.all() and mono and float(got.min()) >= 0 and float(got.max()) <= 1):
+        bad += 1
+        print("MISMATCH", n_prev, S, dil, float((got - want).abs().max()), float(e_hip.max()), float(e_ref.max()), mono)
+print("resample fuzz done, mismatches:", bad)
