@@ -233,6 +233,19 @@ int ucn_bias_relu(void *pre_inout, const void *per_ray, uint32_t N, uint32_t S, 
 int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d_per_ray, uint32_t N, uint32_t S,
                              uint32_t W, int dtype, ucn_stream_t stream);
 
+/* Training-time forward of the NeRF field's dense layers in one kernel (models.py:507-674 under
+ * accelerator.autocast(): bf16 operands, fp32 accumulation), writing every activation the backward needs once:
+ * h0 [M,64], x [M,256] (bottleneck), h1, h2 [M,256] as bf16, raw [M] = x[:,0], y [M,3] = pre-sigmoid colour, M = N*S.
+ * packed = ucn_train_fwd_fragments() fragments of 64 lanes x 8 bf16 (1 KiB): the five weight matrices in MFMA
+ * A-operand order [out tile][in tile][k-step], k permuted to the accumulator layout of the producing layer
+ * (ucnerf_amd/internal/train_graph.py::_pack_fragments); biases / per-ray terms in accumulator order
+ * [tile][wave half][16] (pr0, pr1: [N, 8, 2, 16] = direction block of the colour layer times the ray's encoding
+ * plus its bias).  Widths are the reference's (64, 256, 256, 256, 3); feat [M,F] fp32 with F <= 32. */
+uint64_t ucn_train_fwd_fragments(void);
+int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
+                  const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
+                  void *h1, void *h2, float *raw, float *y, ucn_stream_t stream);
+
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
  * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the

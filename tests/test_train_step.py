@@ -328,3 +328,40 @@ def test_colour_mlp_node_matches_the_concatenated_reference_form():
         scale = max(1.0, float(t.abs().max()))
         assert float((a - t).abs().max()) <= 2e-5 * scale, ("fp32", what)
         assert float((c - t).abs().max()) <= 1.5 * float((b - t).abs().max()) + 2e-3 * scale, ("bf16", what)
+
+
+@pytest.mark.gpu
+def test_fused_heads_forward_kernel_matches_the_per_layer_path(monkeypatch):
+    """ucn_train_fwd (the whole dense part of the NeRF field forward as one bf16 MFMA kernel, activations saved for the
+    backward) vs the per-layer autocast path and the fp32 evaluation of the same module: outputs within bf16 rounding
+    of the per-layer path, gradients as close to the fp32 run as the per-layer autocast run is."""
+    import bench
+    from ucnerf_amd.internal import train_graph as tg
+    model, _, _ = bench.build_model(torch.device("cuda", 0))
+    mlp = model.nerf_mlp
+    N, S = 96, 128
+    g = torch.Generator(device="cuda").manual_seed(8)
+    feat0 = torch.randn(N * S, 32, device="cuda", generator=g) * 0.5
+    vd = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    cd, cr = torch.randn(N, S, device="cuda", generator=g), torch.randn(N, S, 3, device="cuda", generator=g)
+    names = [n for n, _ in mlp.named_parameters() if "encoder" not in n]
+
+    def run(fused, bf16):
+        monkeypatch.setenv("UCN_FUSED_HEADS", "1" if fused else "0")
+        mlp.zero_grad(set_to_none=True)
+        feat = feat0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            density, rgb = tg.field_heads(mlp, feat, vd, N, S)
+        ((density.float() * cd).sum() + (rgb.float() * cr).sum()).backward()
+        grads = {n: p.grad.float().clone() for n, p in mlp.named_parameters() if n in names and p.grad is not None}
+        return density.detach().float(), rgb.detach().float(), feat.grad.float(), grads
+
+    t_d, t_rgb, t_gf, t_g = run(False, False)
+    l_d, l_rgb, l_gf, l_g = run(False, True)
+    f_d, f_rgb, f_gf, f_g = run(True, True)
+    assert float((f_d - l_d).abs().max()) <= 3e-2 * max(1.0, float(l_d.abs().max()))
+    assert float((f_rgb - l_rgb).abs().max()) <= 2e-2
+    assert set(f_g) == set(l_g) == set(t_g) and len(f_g) >= 10
+    for what, f, l, t in [("dfeat", f_gf, l_gf, t_gf)] + [(n, f_g[n], l_g[n], t_g[n]) for n in sorted(t_g)]:
+        scale = max(1e-6, float(t.abs().max()))
+        assert float((f - t).abs().max()) <= 1.5 * float((l - t).abs().max()) + 5e-3 * scale, what

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -76,6 +76,8 @@ SIGNATURES = {
     "ucn_interlevel_loss": [c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp, c_vp],
     "ucn_bias_relu": [c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_relu_backward_reduce": [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
+    "ucn_train_fwd_fragments": [],
+    "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],
@@ -85,7 +87,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
-             "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64}
+             "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64}
 
 _lib = None
 

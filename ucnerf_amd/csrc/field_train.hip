@@ -1,0 +1,210 @@
+// Training-time FORWARD of the NeRF field's dense layers as one kernel: the five layers
+// of models.py:507-674 in the reference's own (uncomposed) topology, bf16 operands with fp32 accumulation -- what the
+// reference's `accelerator.autocast()` makes of them -- with every hidden activation the backward needs written once:
+//
+//   h0 = relu(W_d0 feat + b_d0)            [64]      density layer 0
+//   x  = W_d1 h0 + b_d1                    [256]     bottleneck; x[0] = raw density
+//   h1 = relu(W0x x  + pr0[ray])           [256]     pr0 = W0e enc + b0, per RAY (computed by the caller, [N, 256])
+//   h2 = relu(W1h h1 + W1x x + pr1[ray])   [256]     the skip connection as a second block of the same GEMM
+//   y  = W_rgb h2 + b_rgb                  [3]       pre-sigmoid colour
+//
+// As library GEMMs these layers are HBM-bound on their activations (1 GB in + out per 256x256 product, plus the
+// elementwise passes between them); here a wave keeps its 32 samples' activations in registers from the 128-byte
+// feature row to the three colour logits and HBM sees each activation exactly once, as a store.
+//
+// One wave = 32 samples (the N of v_mfma_f32_32x32x16_bf16), 4 waves per workgroup.  Weights are packed by the host
+// into MFMA A-fragments in consumption order (frag = 64 lanes x 8 bf16 = 1 KiB; k-order permuted to the accumulator
+// layout of the producing layer, exactly like the rendering engine's packers): 436 fragments per tile, staged through
+// LDS in 64 KiB chunks shared by the workgroup's four waves (reading them per wave straight from L2 was 5x slower).
+#include <utility>
+
+#include "mfma_chain.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+struct TrainFwdArgs {
+    const float *feat;        // [M, F] fp32, F <= 32 (sample-major, what k_march_features writes for the GEMMs)
+    const uint4 *w;           // packed fragments: L0 (2x1x2), L1 (8x2x2), L2 (8x8x2), L3 (8x16x2), L4 (1x8x2)
+    const float *bias_d0, *bias_d1, *bias_rgb;   // accumulator order: [tile][h][16]
+    const float *pr0, *pr1;   // [N, 8][2][16] fp32, accumulator order per ray
+    uint16_t *h0, *x, *h1, *h2;                  // bf16 [M, 64] / [M, 256] row-major
+    float *raw, *y;           // [M], [M, 3]
+    uint32_t M, S, F;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf(bf8 a, bf8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// fp32 -> bf16, round to nearest even: the C cast is v_cvt_pk_bf16_f32 on gfx950 (two values per instruction)
+__device__ __forceinline__ bf8 pack8(const float (&v)[8]) {
+    bf8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
+    return o;
+}
+// 8 accumulator registers (k-step s of a tile) -> the B operand of the next layer
+__device__ __forceinline__ bf8 to_b(const f32x16 &a, int s, bool relu) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = relu ? fmaxf(a[8 * s + e], 0.0f) : a[8 * s + e];
+    return pack8(v);
+}
+// store a tile of activations: lane (j, h) holds rows 32t + (r&3) + 8(r>>2) + 4h -> four 8-byte pieces per tile.
+// (Transposing through LDS to write whole 512-byte rows was measured: 1.13 -> 1.06 ms, not worth 66 KiB of LDS.)
+__device__ __forceinline__ void store_tile(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int t, int h, const bf8 (&b)[2],
+                                           bool live) {
+    if (!live) return;
+    const uint4 lo = __builtin_bit_cast(uint4, b[0]), hi = __builtin_bit_cast(uint4, b[1]);
+    uint2 *p = reinterpret_cast<uint2 *>(dst + (size_t)sample * width + 32 * t + 4 * h);
+    p[0] = make_uint2(lo.x, lo.y);      // r = 0..3   -> features +0
+    p[2] = make_uint2(lo.z, lo.w);      // r = 4..7   -> features +8
+    p[4] = make_uint2(hi.x, hi.y);      // r = 8..11  -> features +16
+    p[6] = make_uint2(hi.z, hi.w);      // r = 12..15 -> features +24
+}
+__device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &acc) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 v = reinterpret_cast<const float4 *>(p)[q];
+        acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+    }
+}
+
+// Weight staging = the rendering engine's WeightStream (mfma_chain.h): two 64 KiB LDS buffers, the next chunk's 64
+// fragments arrive by global_load_lds DMA issued one piece per four MFMAs of the current chunk, one barrier per chunk.
+// (A first version staged 32 KiB chunks through registers one chunk ahead: the L2 latency of a chunk, ~1.5 us, is longer
+// than its 0.4 us of MFMAs, so every boundary waited -- 1.1 ms per call.)
+constexpr int kFrags = 2 * 1 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;      // 436
+constexpr int kChunks = (kFrags + kChunkGroups - 1) / kChunkGroups;                        // 7 (stream zero-padded)
+
+template <int... Is, class F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// acc[ot] += sum over NT_IN input tiles of A(frag) . in[it][s].  Output tiles go in PAIRS, the pair innermost
+// (fragment order [ot pair][it][s][o2], a single tile: [it][s]): two MFMAs that accumulate into the same registers do
+// not issue back to back (+43 cycles), alternating between two accumulators they do -- the first version, with all
+// of a tile's MFMAs in a row, ran at 40 % of this one's speed.
+template <int NT_OUT, int NT_IN, int G0>
+__device__ __forceinline__ void layer(WeightStream &ws, f32x16 (&acc)[NT_OUT], const bf8 (&in)[NT_IN][2]) {
+    static_assert(NT_OUT == 1 || NT_OUT % 2 == 0, "output tiles come in pairs");
+    sfor<NT_OUT * NT_IN * 2>([&](auto i) {
+        constexpr int I = i.value, G = G0 + I;
+        constexpr int P = NT_OUT == 1 ? 1 : 2;                               // tiles per group
+        constexpr int o2 = I % P, s = (I / P) % 2, it = (I / (2 * P)) % NT_IN, ot = P * (I / (2 * P * NT_IN)) + o2;
+        if constexpr (G % kChunkGroups == 0 && G > 0) ws.sync();
+        if constexpr (G % 4 == 0 && G / kChunkGroups + 1 < kChunks) ws.piece_unchecked(G / kChunkGroups + 1, (G % kChunkGroups) / 4);
+        acc[ot] = mfma_bf(__builtin_bit_cast(bf8, ws.group(G)), in[it][s], acc[ot]);
+    });
+}
+
+__global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
+    const bool live = s0 < a.M;
+    const uint32_t sample = live ? s0 : a.M - 1;
+    const uint32_t ray = sample / a.S;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // 2 x 64 KiB weight chunks
+    WeightStream ws{reinterpret_cast<const float *>(a.w), s_w, lane, wave, (uint32_t)kChunks};
+    ws.issue(0);
+
+    // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
+    bf8 fin[1][2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t k = 16u * s + 8u * h + e;
+            v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
+        }
+        fin[0][s] = pack8(v);
+    }
+    ws.sync();                              // chunk 0 and the feature loads above land together
+    // ---- density layer 0
+    f32x16 a0[2];
+    load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
+    load_acc(a.bias_d0 + (1 * 2 + h) * 16, a0[1]);
+    layer<2, 1, 0>(ws, a0, fin);
+    bf8 h0[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        h0[t][0] = to_b(a0[t], 0, true);
+        h0[t][1] = to_b(a0[t], 1, true);
+        store_tile(a.h0, 64, sample, t, h, h0[t], live);
+    }
+    // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) load_acc(a.bias_d1 + (t * 2 + h) * 16, acc[t]);
+    layer<8, 2, 4>(ws, acc, h0);
+    bf8 xin[16][2];                         // tiles 0..7: h1 (filled below), 8..15: x  -- the order of W1 = [W1h | W1x]
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        xin[8 + t][0] = to_b(acc[t], 0, false);
+        xin[8 + t][1] = to_b(acc[t], 1, false);
+        store_tile(a.x, 256, sample, t, h, xin[8 + t], live);
+    }
+    if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
+        const uint4 q = __builtin_bit_cast(uint4, xin[8][0]);
+        a.raw[sample] = __uint_as_float(q.x << 16);
+    }
+    // ---- colour layer 0: x -> h1
+#pragma unroll
+    for (int t = 0; t < 8; t++) load_acc(a.pr0 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
+    {
+        bf8 xonly[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; t++) { xonly[t][0] = xin[8 + t][0]; xonly[t][1] = xin[8 + t][1]; }
+        layer<8, 8, 36>(ws, acc, xonly);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        xin[t][0] = to_b(acc[t], 0, true);
+        xin[t][1] = to_b(acc[t], 1, true);
+        store_tile(a.h1, 256, sample, t, h, xin[t], live);
+    }
+    // ---- colour layer 1: [h1, x] -> h2
+#pragma unroll
+    for (int t = 0; t < 8; t++) load_acc(a.pr1 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
+    layer<8, 16, 164>(ws, acc, xin);
+    bf8 h2[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        h2[t][0] = to_b(acc[t], 0, true);
+        h2[t][1] = to_b(acc[t], 1, true);
+        store_tile(a.h2, 256, sample, t, h, h2[t], live);
+    }
+    // ---- rgb layer (3 rows of one padded output tile)
+    f32x16 yo[1];
+    load_acc(a.bias_rgb + h * 16, yo[0]);
+    layer<1, 8, 420>(ws, yo, h2);
+    if (live && h == 0) {
+        a.y[(size_t)sample * 3 + 0] = yo[0][0];
+        a.y[(size_t)sample * 3 + 1] = yo[0][1];
+        a.y[(size_t)sample * 3 + 2] = yo[0][2];
+    }
+}
+
+}  // namespace
+
+extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kChunks * kChunkGroups; }     // 436 used + zero padding
+
+extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
+                             const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
+                             void *h1, void *h2, float *raw, float *y, ucn_stream_t stream) {
+    const uint64_t M = (uint64_t)N * S;
+    if (M == 0) return 0;
+    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y,
+                "train_fwd: null pointer argument");
+    UCN_REQUIRE(F >= 1 && F <= 32, "train_fwd: 1..32 input features, got %u", F);
+    UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
+    TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
+                   (uint16_t *)h2, raw, y, (uint32_t)M, S, F};
+    hipLaunchKernelGGL(k_train_fwd, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    UCN_LAUNCH_CHECK("train_fwd");
+    return 0;
+}

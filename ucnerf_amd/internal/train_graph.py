@@ -16,6 +16,7 @@ parameters.  Sample positions do not (`stop_level_grad`, models.py:204-205; `tra
   host tensors still raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -176,6 +177,15 @@ def _wgrad(gy, x):
     return (gy.t() @ x).float()
 
 
+def _colsum(g):
+    """Column sums of a tall [M, a] matrix as float32 [a]: a batched ones-row GEMM over 8192-row chunks (an fp32 copy +
+    reduce_kernel over [1M, 3] costs 0.35 ms; this is 0.06 ms)."""
+    m, c = g.shape[0], _TallLinear.CHUNK
+    if m >= 4 * c and m % c == 0:
+        return torch.bmm(g.new_ones(m // c, 1, c), g.reshape(m // c, c, -1)).float().sum(dim=(0, 1))
+    return g.float().sum(0)
+
+
 class _ColourMLP(torch.autograd.Function):
     """The two hidden layers of the colour MLP in the reference's topology (models.py:615-640: net_depth_viewdirs = 2,
     skip connection after layer 0) as ONE autograd node:
@@ -237,6 +247,138 @@ class _ColourMLP(torch.autograd.Function):
         return gx.to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
 
 
+# ------------------------------------------------------------------ fused bf16 forward of the NeRF field's dense layers
+_FRAG_CACHE = {}
+
+
+def _perm(r, g):
+    """Feature (within a 32-wide tile) held by accumulator register r of wave half g (csrc/mfma_chain.h acc_row)."""
+    return (r & 3) + 8 * (r >> 2) + 4 * g
+
+
+def _fragment_index(rows, cols, natural, device):
+    """Gather index into a zero-padded [32*NT_OUT, 32*NT_IN] weight for its MFMA A-fragments in consumption order
+    [out tile pair][in tile][k-step][tile of the pair][lane][8]: lane (row = lane & 31, g = lane >> 5) element e is
+    W[32 ot + row][32 it + k], k = 16 s + 8 g + e for the first layer (features arrive in natural order) and
+    perm(8 s + e, g) for the others (the producing layer's accumulator order)."""
+    key = (rows, cols, natural, str(device))
+    hit = _FRAG_CACHE.get(key)
+    if hit is None:
+        nto, nti = (rows + 31) // 32, (cols + 31) // 32
+        p = 1 if nto == 1 else 2                              # output tiles in pairs, the pair innermost (csrc/field_train.hip)
+        assert nto % p == 0
+        otp, it, s_, o2, lane, e = torch.meshgrid(torch.arange(nto // p), torch.arange(nti), torch.arange(2), torch.arange(p),
+                                                  torch.arange(64), torch.arange(8), indexing="ij")
+        ot = p * otp + o2
+        row, g = lane & 31, lane >> 5
+        k = 16 * s_ + 8 * g + e if natural else _perm(8 * s_ + e, g)
+        hit = (((32 * ot + row) * (32 * nti) + 32 * it + k).reshape(-1).to(device), nto, nti)
+        _FRAG_CACHE[key] = hit
+    return hit
+
+
+def _acc_order(width, device):
+    """Column permutation that puts a [.., width] vector into accumulator order [tile][wave half][16]."""
+    key = ("acc", width, str(device))
+    hit = _FRAG_CACHE.get(key)
+    if hit is None:
+        t, g, r = torch.meshgrid(torch.arange((width + 31) // 32), torch.arange(2), torch.arange(16), indexing="ij")
+        hit = (32 * t + _perm(r, g)).reshape(-1).to(device)
+        _FRAG_CACHE[key] = hit
+    return hit
+
+
+def _pack_fragments(weights, device, total=0):
+    """bf16 fragments of [(W, natural_k_order), ...] concatenated: one gather per matrix (index cached)."""
+    out = []
+    for W, natural in weights:
+        idx, nto, nti = _fragment_index(W.shape[0], W.shape[1], natural, device)
+        pad = torch.zeros(32 * nto, 32 * nti, device=device, dtype=torch.bfloat16)
+        pad[:W.shape[0], :W.shape[1]] = W
+        out.append(pad.reshape(-1)[idx])
+    flat = torch.cat(out)
+    return torch.cat([flat, flat.new_zeros(total * 512 - flat.numel())]) if total * 512 > flat.numel() else flat
+
+
+def _acc_vec(v, width, device):
+    pad = torch.zeros(v.shape[:-1] + (32 * ((width + 31) // 32),), device=device, dtype=torch.float32)
+    pad[..., :v.shape[-1]] = v
+    return pad[..., _acc_order(width, device)].contiguous()
+
+
+class _FusedHeads(torch.autograd.Function):
+    """Density MLP + colour MLP + rgb layer of the NeRF field (models.py:507-674, the reference's topology and widths)
+    under bf16 autocast: the forward is ONE HIP kernel (`ucn_train_fwd`: activations stay in registers from the
+    feature row to the colour logits, each hidden activation is stored once for the backward); the backward runs the
+    same arithmetic as the per-layer path on those saved activations (library GEMMs for dgrad / wgrad,
+    `ucn_relu_backward_reduce` for the masks and per-ray reductions)."""
+
+    @staticmethod
+    def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S):
+        lib = _lib.load()
+        dev, dt = feat.device, torch.bfloat16
+        NB, NW = Wd1.shape[0], W0.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
+            W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
+            Wd0b, Wd1b, Wrb, eb = Wd0.to(dt), Wd1.to(dt), Wr.to(dt), enc.to(dt)
+            packed = _pack_fragments([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], dim=1), False), (Wrb, False)], dev,
+                                     total=lib.ucn_train_fwd_fragments())
+            assert packed.numel() == lib.ucn_train_fwd_fragments() * 512
+            pr0 = _acc_vec(torch.addmm(b0.to(dt), eb, W0e.t()).float(), NW, dev)         # what the bf16 GEMM + bias would hold
+            pr1 = _acc_vec(torch.addmm(b1.to(dt), eb, W1e.t()).float(), NW, dev)
+            bias0, bias1, biasr = (_acc_vec(b.to(dt).float(), w, dev) for b, w in ((bd0, 64), (bd1, NB), (br, 32)))
+            M = N * S
+            f = feat.float().contiguous()
+            h0 = torch.empty(M, 64, device=dev, dtype=dt)
+            x, h1, h2 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
+            raw, y = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+            _lib.check(lib.ucn_train_fwd(f.data_ptr(), f.shape[1], packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
+                                         biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, h0.data_ptr(), x.data_ptr(),
+                                         h1.data_ptr(), h2.data_ptr(), raw.data_ptr(), y.data_ptr(), _lib.stream()))
+        ctx.save_for_backward(f.to(dt), eb, h0, x, h1, h2, Wd0b, Wd1b, W0x, W1h, W1x, Wrb)
+        ctx.meta = (N, S, NB, NW, feat.dtype, Wd0.dtype, bd0.dtype)
+        return raw.to(dt), y.to(dt)
+
+    @staticmethod
+    def backward(ctx, g_raw, g_y):
+        lib = _lib.load()
+        fb, eb, h0, x, h1, h2, Wd0, Wd1, W0x, W1h, W1x, Wr = ctx.saved_tensors
+        N, S, NB, NW, f_dt, w_dt, b_dt = ctx.meta
+        dt = torch.bfloat16
+        st = _lib.stream()
+        with torch.autocast("cuda", enabled=False):
+            gy = g_y.to(dt).contiguous()
+            gWr, gbr = _wgrad(gy, h2), _colsum(gy)
+            g2 = gy @ Wr                                                                  # [M, NW]
+            d1, r1 = torch.empty_like(g2), torch.empty(N, NW, device=g2.device, dtype=dt)
+            _lib.check(lib.ucn_relu_backward_reduce(g2.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, 2, st))
+            d0 = d1 @ W1h
+            r0 = torch.empty(N, NW, device=g2.device, dtype=dt)
+            _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, 2, st))
+            gW0 = torch.cat([_wgrad(d0, x), (r0.t() @ eb).float()], dim=1)
+            gW1 = torch.cat([_wgrad(d1, h1), _wgrad(d1, x), (r1.t() @ eb).float()], dim=1)
+            gb0, gb1 = r0.float().sum(0), r1.float().sum(0)
+            gx = (d1 @ W1x).addmm_(d0, W0x)
+            if g_raw is not None:
+                gx[:, 0] += g_raw.reshape(-1).to(dt)
+            gWd1 = _wgrad(gx, h0)
+            gbd1 = _colsum(gx)
+            gh0 = gx @ Wd1                                                                # [M, 64]
+            gh0 = torch.where(h0 > 0, gh0, torch.zeros_like(gh0))
+            gWd0, gbd0 = _wgrad(gh0, fb), _colsum(gh0)
+            gfeat = (gh0 @ Wd0).to(f_dt)
+        return (gfeat, None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
+                gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None)
+
+
+def _fusable_heads(mlp, feat):
+    return (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not mlp.disable_rgb
+            and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and feat.shape[1] <= 32
+            and mlp.density_layer[0].out_features == 64 and mlp.density_layer[2].out_features == 256
+            and mlp.net_width_viewdirs == 256 and mlp.rgb_layer.out_features == 3)
+
+
 def field_heads(mlp, feat, viewdirs, N, S):
     """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs).
 
@@ -245,6 +387,13 @@ def field_heads(mlp, feat, viewdirs, N, S):
     as GEMMs that accumulate into one output, the per-RAY direction block (and the layer bias) as one small
     [N, 27] GEMM broadcast over the samples -- no [N*S, 283] / [N*S, 539] concatenations, 7 % fewer flops, and the
     bias / direction-weight gradients reduce over rays instead of samples."""
+    if _fusable_heads(mlp, feat) and os.environ.get("UCN_FUSED_HEADS", "1") == "1":
+        d0, d1, l0, l1, lr = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1, mlp.rgb_layer
+        raw, y = _FusedHeads.apply(feat, view_encoding(viewdirs, mlp.deg_view), d0.weight, d0.bias, d1.weight, d1.bias, l0.weight,
+                                   l0.bias, l1.weight, l1.bias, lr.weight, lr.bias, N, S)
+        density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
+        rgb = torch.sigmoid(mlp.rgb_premultiplier * y.reshape(N, S, 3) + mlp.rgb_bias)
+        return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
     if mlp.disable_rgb:
         return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)
