@@ -235,7 +235,8 @@ int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d
 
 /* Training-time forward of the NeRF field's dense layers in one kernel (models.py:507-674 under
  * accelerator.autocast(): bf16 operands, fp32 accumulation), writing every activation the backward needs once:
- * h0 [M,64], x [M,256] (bottleneck), h1, h2 [M,256] as bf16, raw [M] = x[:,0], y [M,3] = pre-sigmoid colour, M = N*S.
+ * h0 [M,64], x [M,256] (bottleneck), h1, h2 [M,256] as bf16, raw [M] = x[:,0], y [M,3] = pre-sigmoid colour, M = N*S,
+ * and the ReLU masks m0 / m1 / m2 (16 bits per 32-feature tile and wave half) for ucn_train_bwd.
  * packed = ucn_train_fwd_fragments() fragments of 64 lanes x 8 bf16 (1 KiB): the five weight matrices in MFMA
  * A-operand order [out tile][in tile][k-step], k permuted to the accumulator layout of the producing layer
  * (ucnerf_amd/internal/train_graph.py::_pack_fragments); biases / per-ray terms in accumulator order
@@ -244,7 +245,15 @@ int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d
 uint64_t ucn_train_fwd_fragments(void);
 int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
-                  void *h1, void *h2, float *raw, float *y, ucn_stream_t stream);
+                  void *h1, void *h2, float *raw, float *y, uint32_t *m0 /*[M,2]*/, void *m1 /*[M,2] x 16 B*/,
+                  void *m2, ucn_stream_t stream);
+/* The same chain backwards (dgrad): gy [M,3] bf16 (gradient of y), graw [M] bf16|NULL (gradient of raw), packed_t =
+ * the TRANSPOSED weights in the same fragment format (Wr^T, W1h^T, [W1x^T | W0x^T], Wd1^T, Wd0^T), m0/m1/m2 = the ReLU
+ * masks ucn_train_fwd wrote.  Outputs: the pre-activation gradients the weight-gradient GEMMs need, d1, d0, gx
+ * [M,256] and gh0 [M,64] as bf16, and the feature gradient gfeat [M,F] fp32. */
+int ucn_train_bwd(const void *gy, const void *graw, const void *packed_t, const uint32_t *m0, const void *m1,
+                  const void *m2, uint32_t N, uint32_t S, uint32_t F, void *d1, void *d0, void *gx, void *gh0,
+                  float *gfeat, ucn_stream_t stream);
 
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608

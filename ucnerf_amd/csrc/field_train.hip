@@ -31,6 +31,8 @@ struct TrainFwdArgs {
     const float *pr0, *pr1;   // [N, 8][2][16] fp32, accumulator order per ray
     uint16_t *h0, *x, *h1, *h2;                  // bf16 [M, 64] / [M, 256] row-major
     float *raw, *y;           // [M], [M, 3]
+    uint32_t *m0;             // [M][2] : ReLU masks of h0, bit 16 t + r of wave half h  (2 tiles)
+    uint4 *m1, *m2;           // [M][2] : ReLU masks of h1 / h2, 16 bits per tile, 8 tiles
     uint32_t M, S, F;
 };
 
@@ -48,6 +50,20 @@ __device__ __forceinline__ bf8 to_b(const f32x16 &a, int s, bool relu) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = relu ? fmaxf(a[8 * s + e], 0.0f) : a[8 * s + e];
+    return pack8(v);
+}
+// bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile)
+__device__ __forceinline__ uint32_t mask16(const f32x16 &a) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) m |= (a[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+// the masked (ReLU') half tile as a B operand
+__device__ __forceinline__ bf8 to_b_masked(const f32x16 &a, int s, uint32_t bits) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = ((bits >> (8 * s + e)) & 1u) ? a[8 * s + e] : 0.0f;
     return pack8(v);
 }
 // store a tile of activations: lane (j, h) holds rows 32t + (r&3) + 8(r>>2) + 4h -> four 8-byte pieces per tile.
@@ -136,6 +152,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         h0[t][1] = to_b(a0[t], 1, true);
         store_tile(a.h0, 64, sample, t, h, h0[t], live);
     }
+    if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
     f32x16 acc[8];
 #pragma unroll
@@ -167,6 +184,12 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         xin[t][1] = to_b(acc[t], 1, true);
         store_tile(a.h1, 256, sample, t, h, xin[t], live);
     }
+    if (live) {
+        uint32_t mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) mk[q] = mask16(acc[2 * q]) | (mask16(acc[2 * q + 1]) << 16);
+        a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+    }
     // ---- colour layer 1: [h1, x] -> h2
 #pragma unroll
     for (int t = 0; t < 8; t++) load_acc(a.pr1 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
@@ -177,6 +200,12 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         h2[t][0] = to_b(acc[t], 0, true);
         h2[t][1] = to_b(acc[t], 1, true);
         store_tile(a.h2, 256, sample, t, h, h2[t], live);
+    }
+    if (live) {
+        uint32_t mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) mk[q] = mask16(acc[2 * q]) | (mask16(acc[2 * q + 1]) << 16);
+        a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
     // ---- rgb layer (3 rows of one padded output tile)
     f32x16 yo[1];
@@ -189,22 +218,156 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     }
 }
 
+// The same chain backwards (dgrad): transposed weights in the same fragment stream format, the forward's ReLU masks
+// instead of the activations, every pre-activation gradient the weight-gradient GEMMs need stored once:
+//   d1 = (Wr^T gy) * m2          [256]      gx  = W1x^T d1 + W0x^T d0 (+ g_raw on feature 0)   [256]
+//   d0 = (W1h^T d1) * m1         [256]      gh0 = (Wd1^T gx) * m0 [64],   gfeat = Wd0^T gh0    [F] fp32
+struct TrainBwdArgs {
+    const uint16_t *gy;       // [M, 3] bf16
+    const uint16_t *graw;     // [M] bf16 or NULL
+    const uint4 *w;           // fragments: Wr^T (8x1x2), W1h^T (8x8x2), [W1x^T | W0x^T] (8x16x2), Wd1^T (2x8x2), Wd0^T (1x2x2)
+    const uint32_t *m0;
+    const uint4 *m1, *m2;
+    uint16_t *d1, *d0, *gx, *gh0;     // bf16 [M,256] x3, [M,64]
+    float *gfeat;                     // [M, F]
+    uint32_t M, F;
+};
+
+__device__ __forceinline__ void zero_acc(f32x16 &a) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
+    const bool live = s0 < a.M;
+    const uint32_t sample = live ? s0 : a.M - 1;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    WeightStream ws{reinterpret_cast<const float *>(a.w), s_w, lane, wave, (uint32_t)kChunks};
+    ws.issue(0);
+    // ---- colour logit gradients: k = 0..2 of k-step 0, wave half 0
+    bf8 gin[1][2];
+    {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) v[e] = __uint_as_float((uint32_t)a.gy[(size_t)sample * 3 + e] << 16);
+        }
+        gin[0][0] = pack8(v);
+        const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        gin[0][1] = pack8(z);
+    }
+    const uint4 mk2 = a.m2[(size_t)sample * 2 + h], mk1 = a.m1[(size_t)sample * 2 + h];
+    const uint32_t mk0 = a.m0[(size_t)sample * 2 + h];
+    const uint32_t m2w[4] = {mk2.x, mk2.y, mk2.z, mk2.w}, m1w[4] = {mk1.x, mk1.y, mk1.z, mk1.w};
+    ws.sync();
+    f32x16 acc[8];
+    bf8 din[16][2];                          // tiles 0..7: d1, 8..15: d0  (the order of [W1x^T | W0x^T])
+    // ---- through the rgb layer and the second hidden layer's ReLU
+#pragma unroll
+    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
+    layer<8, 1, 0>(ws, acc, gin);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint32_t bits = (m2w[t / 2] >> (16 * (t % 2))) & 0xFFFFu;
+        din[t][0] = to_b_masked(acc[t], 0, bits);
+        din[t][1] = to_b_masked(acc[t], 1, bits);
+        store_tile(a.d1, 256, sample, t, h, din[t], live);
+    }
+    // ---- through W1h and the first hidden layer's ReLU
+#pragma unroll
+    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
+    {
+        bf8 d1only[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; t++) { d1only[t][0] = din[t][0]; d1only[t][1] = din[t][1]; }
+        layer<8, 8, 16>(ws, acc, d1only);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint32_t bits = (m1w[t / 2] >> (16 * (t % 2))) & 0xFFFFu;
+        din[8 + t][0] = to_b_masked(acc[t], 0, bits);
+        din[8 + t][1] = to_b_masked(acc[t], 1, bits);
+        store_tile(a.d0, 256, sample, t, h, din[8 + t], live);
+    }
+    // ---- both paths into the bottleneck, plus the density head's column
+#pragma unroll
+    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
+    layer<8, 16, 144>(ws, acc, din);
+    if (a.graw && h == 0) acc[0][0] += __uint_as_float((uint32_t)a.graw[sample] << 16);
+    bf8 gxb[8][2];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        gxb[t][0] = to_b(acc[t], 0, false);
+        gxb[t][1] = to_b(acc[t], 1, false);
+        store_tile(a.gx, 256, sample, t, h, gxb[t], live);
+    }
+    // ---- density layer 1 backwards, ReLU of h0
+    f32x16 a0[2];
+    zero_acc(a0[0]);
+    zero_acc(a0[1]);
+    layer<2, 8, 400>(ws, a0, gxb);
+    bf8 gh0[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t bits = (mk0 >> (16 * t)) & 0xFFFFu;
+        gh0[t][0] = to_b_masked(a0[t], 0, bits);
+        gh0[t][1] = to_b_masked(a0[t], 1, bits);
+        store_tile(a.gh0, 64, sample, t, h, gh0[t], live);
+    }
+    // ---- density layer 0 backwards: the feature gradient, fp32, natural feature order
+    f32x16 gf[1];
+    zero_acc(gf[0]);
+    layer<1, 2, 432>(ws, gf, gh0);
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t f0 = 8u * q + 4u * h;                       // features f0 .. f0 + 3 = registers 4q .. 4q + 3
+            if (f0 + 3 < a.F) {
+                *reinterpret_cast<float4 *>(a.gfeat + (size_t)sample * a.F + f0) = make_float4(gf[0][4 * q], gf[0][4 * q + 1], gf[0][4 * q + 2], gf[0][4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (f0 + e < a.F) a.gfeat[(size_t)sample * a.F + f0 + e] = gf[0][4 * q + e];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kChunks * kChunkGroups; }     // 436 used + zero padding
 
 extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                              const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
-                             void *h1, void *h2, float *raw, float *y, ucn_stream_t stream) {
+                             void *h1, void *h2, float *raw, float *y, uint32_t *m0, void *m1, void *m2, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
-    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y,
+    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y && m0 && m1 && m2,
                 "train_fwd: null pointer argument");
     UCN_REQUIRE(F >= 1 && F <= 32, "train_fwd: 1..32 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
-                   (uint16_t *)h2, raw, y, (uint32_t)M, S, F};
+                   (uint16_t *)h2, raw, y, m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
     hipLaunchKernelGGL(k_train_fwd, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_fwd");
+    return 0;
+}
+
+extern "C" int ucn_train_bwd(const void *gy, const void *graw, const void *packed_t, const uint32_t *m0, const void *m1, const void *m2,
+                             uint32_t N, uint32_t S, uint32_t F, void *d1, void *d0, void *gx, void *gh0, float *gfeat,
+                             ucn_stream_t stream) {
+    const uint64_t M = (uint64_t)N * S;
+    if (M == 0) return 0;
+    UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gx && gh0 && gfeat, "train_bwd: null pointer argument");
+    UCN_REQUIRE(F >= 1 && F <= 32, "train_bwd: 1..32 input features, got %u", F);
+    UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");
+    TrainBwdArgs a{(const uint16_t *)gy, (const uint16_t *)graw, (const uint4 *)packed_t, m0, (const uint4 *)m1, (const uint4 *)m2,
+                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, gfeat, (uint32_t)M, F};
+    hipLaunchKernelGGL(k_train_bwd, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }

@@ -309,9 +309,9 @@ def _acc_vec(v, width, device):
 class _FusedHeads(torch.autograd.Function):
     """Density MLP + colour MLP + rgb layer of the NeRF field (models.py:507-674, the reference's topology and widths)
     under bf16 autocast: the forward is ONE HIP kernel (`ucn_train_fwd`: activations stay in registers from the
-    feature row to the colour logits, each hidden activation is stored once for the backward); the backward runs the
-    same arithmetic as the per-layer path on those saved activations (library GEMMs for dgrad / wgrad,
-    `ucn_relu_backward_reduce` for the masks and per-ray reductions)."""
+    feature row to the colour logits, each hidden activation and its ReLU mask is stored once); the backward's dgrad
+    chain is ONE HIP kernel too (`ucn_train_bwd`: transposed weight fragments, the forward's masks), and the weight
+    gradients are split-K library GEMMs on the pre-activation gradients it stores."""
 
     @staticmethod
     def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S):
@@ -333,42 +333,45 @@ class _FusedHeads(torch.autograd.Function):
             h0 = torch.empty(M, 64, device=dev, dtype=dt)
             x, h1, h2 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
             raw, y = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+            m0 = torch.empty(M, 2, device=dev, dtype=torch.int32)
+            m1, m2 = (torch.empty(M, 2, 4, device=dev, dtype=torch.int32) for _ in range(2))
             _lib.check(lib.ucn_train_fwd(f.data_ptr(), f.shape[1], packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
                                          biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, h0.data_ptr(), x.data_ptr(),
-                                         h1.data_ptr(), h2.data_ptr(), raw.data_ptr(), y.data_ptr(), _lib.stream()))
-        ctx.save_for_backward(f.to(dt), eb, h0, x, h1, h2, Wd0b, Wd1b, W0x, W1h, W1x, Wrb)
+                                         h1.data_ptr(), h2.data_ptr(), raw.data_ptr(), y.data_ptr(), m0.data_ptr(), m1.data_ptr(),
+                                         m2.data_ptr(), _lib.stream()))
+            # the dgrad chain's weights: the transposes, same fragment format (first matrix: gy arrives in natural order)
+            packed_t = _pack_fragments([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], dim=1), False),
+                                        (Wd1b.t(), False), (Wd0b.t(), False)], dev, total=lib.ucn_train_fwd_fragments())
+        ctx.save_for_backward(f.to(dt), eb, h0, x, h1, h2, m0, m1, m2, packed_t)
         ctx.meta = (N, S, NB, NW, feat.dtype, Wd0.dtype, bd0.dtype)
         return raw.to(dt), y.to(dt)
 
     @staticmethod
     def backward(ctx, g_raw, g_y):
         lib = _lib.load()
-        fb, eb, h0, x, h1, h2, Wd0, Wd1, W0x, W1h, W1x, Wr = ctx.saved_tensors
+        fb, eb, h0, x, h1, h2, m0, m1, m2, packed_t = ctx.saved_tensors
         N, S, NB, NW, f_dt, w_dt, b_dt = ctx.meta
-        dt = torch.bfloat16
-        st = _lib.stream()
+        dt, dev, M = torch.bfloat16, fb.device, fb.shape[0]
         with torch.autocast("cuda", enabled=False):
             gy = g_y.to(dt).contiguous()
+            gr = None if g_raw is None else g_raw.reshape(-1).to(dt).contiguous()
+            d1, d0, gx = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
+            gh0 = torch.empty(M, 64, device=dev, dtype=dt)
+            gfeat = torch.empty(M, fb.shape[1], device=dev)
+            _lib.check(lib.ucn_train_bwd(gy.data_ptr(), _lib.ptr(gr), packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                         N, S, fb.shape[1], d1.data_ptr(), d0.data_ptr(), gx.data_ptr(), gh0.data_ptr(),
+                                         gfeat.data_ptr(), _lib.stream()))
+            # weight gradients: split-K GEMMs on the stored pre-activation gradients; the direction blocks and biases
+            # reduce over rays first
+            r1 = d1.reshape(N, S, NW).sum(1)
+            r0 = d0.reshape(N, S, NW).sum(1)
             gWr, gbr = _wgrad(gy, h2), _colsum(gy)
-            g2 = gy @ Wr                                                                  # [M, NW]
-            d1, r1 = torch.empty_like(g2), torch.empty(N, NW, device=g2.device, dtype=dt)
-            _lib.check(lib.ucn_relu_backward_reduce(g2.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, 2, st))
-            d0 = d1 @ W1h
-            r0 = torch.empty(N, NW, device=g2.device, dtype=dt)
-            _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, 2, st))
             gW0 = torch.cat([_wgrad(d0, x), (r0.t() @ eb).float()], dim=1)
             gW1 = torch.cat([_wgrad(d1, h1), _wgrad(d1, x), (r1.t() @ eb).float()], dim=1)
             gb0, gb1 = r0.float().sum(0), r1.float().sum(0)
-            gx = (d1 @ W1x).addmm_(d0, W0x)
-            if g_raw is not None:
-                gx[:, 0] += g_raw.reshape(-1).to(dt)
-            gWd1 = _wgrad(gx, h0)
-            gbd1 = _colsum(gx)
-            gh0 = gx @ Wd1                                                                # [M, 64]
-            gh0 = torch.where(h0 > 0, gh0, torch.zeros_like(gh0))
+            gWd1, gbd1 = _wgrad(gx, h0), _colsum(gx)
             gWd0, gbd0 = _wgrad(gh0, fb), _colsum(gh0)
-            gfeat = (gh0 @ Wd0).to(f_dt)
-        return (gfeat, None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
+        return (gfeat.to(f_dt), None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
                 gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None)
 
 
