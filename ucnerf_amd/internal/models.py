@@ -186,6 +186,23 @@ class MLP(nn.Module):
         self._desc, self._desc_key = d, key
         return d
 
+    def grid_field(self):
+        """ucn_field_t with only the hash-grid part filled in: all the featurisation kernels read.  The training graph
+        uses it so that an optimiser step does not trigger a re-pack of the RENDERING engine's weight stream."""
+        emb = self.encoder.embeddings
+        _lib.require_device(emb, f"{type(self).__name__}.encoder.embeddings")
+        key = (emb.data_ptr(),)
+        if getattr(self, "_grid_desc_key", None) != key:
+            enc = self.encoder
+            d = _lib.UcnField()
+            d.embeddings = emb.data_ptr()
+            d.offsets_host = enc._offsets_np.ctypes.data
+            d.grid_sizes_host = enc._sizes_np.ctypes.data
+            d.num_levels, d.level_dim, d.base_resolution = enc.num_levels, enc.level_dim, enc.base_resolution
+            d.log2_per_level_scale = float(np.log2(enc.per_level_scale))
+            self._grid_desc, self._grid_desc_key = d, key
+        return self._grid_desc
+
     # ---- reference API on explicit Gaussians (extract.py:56-57,96) ---------------------------
     @torch.no_grad()
     def predict_density(self, means, stds, rand=False, no_warp=False):

@@ -34,7 +34,7 @@ class _FieldFeatures(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb):
         lib = _lib.load()
-        desc = mlp.field()
+        desc = mlp.grid_field()
         L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
         feat = torch.empty(N * S, L * C, device=embeddings.device)
         coord = torch.empty(N, S, 3, device=embeddings.device)
@@ -62,8 +62,8 @@ class _FieldFeatures(torch.autograd.Function):
             layout = 3
         else:
             g, layout = g.contiguous(), 1
-        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.field()), N, S), device=g.device)
-        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
+        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.grid_field()), N, S), device=g.device)
+        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.grid_field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
                                                    N, S, 0, layout, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
         return grad, None, None, None, None, None, None
 
