@@ -260,8 +260,9 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
     model.eval()
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
                 autocast="bf16 GEMMs, fp32 tables/compositing",
-                graph="HIP resample + fused featurisation fwd / bwd (LDS row blocks, no global atomics); dense layers as split "
-                      "library GEMMs without materialised concatenations")
+                graph="HIP resample, fused featurisation fwd / bwd (LDS row blocks, no global atomics), NeRF-field dense forward and "
+                      "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd), compositing fwd / bwd, distortion + interlevel "
+                      "losses, table Adam; weight gradients and PropMLP as library GEMMs")
 
 
 def main():
