@@ -241,7 +241,8 @@ int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d
  * A-operand order [out tile][in tile][k-step], k permuted to the accumulator layout of the producing layer
  * (ucnerf_amd/internal/train_graph.py::_pack_fragments); biases / per-ray terms in accumulator order
  * [tile][wave half][16] (pr0, pr1: [N, 8, 2, 16] = direction block of the colour layer times the ray's encoding
- * plus its bias).  Widths are the reference's (64, 256, 256, 256, 3); feat [M,F] fp32 with F <= 32. */
+ * plus its bias).  Widths are the reference's (64, 256, 256, 256, 3); feat [M,F] fp32 with F <= 64 (one feature tile up to 32, two above:
+ * the first and last matrices then have 4 more fragments). */
 uint64_t ucn_train_fwd_fragments(void);
 int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,

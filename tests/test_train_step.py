@@ -331,17 +331,25 @@ def test_colour_mlp_node_matches_the_concatenated_reference_form():
 
 
 @pytest.mark.gpu
-def test_fused_heads_forward_kernel_matches_the_per_layer_path(monkeypatch):
+@pytest.mark.parametrize("field", ["B", "R"])
+def test_fused_heads_forward_kernel_matches_the_per_layer_path(monkeypatch, field):
     """ucn_train_fwd (the whole dense part of the NeRF field forward as one bf16 MFMA kernel, activations saved for the
     backward) vs the per-layer autocast path and the fp32 evaluation of the same module: outputs within bf16 rounding
     of the per-layer path, gradients as close to the fp32 run as the per-layer autocast run is."""
     import bench
-    from ucnerf_amd.internal import train_graph as tg
-    model, _, _ = bench.build_model(torch.device("cuda", 0))
+    from ucnerf_amd.internal import configs, models, train_graph as tg
+    if field == "B":                                     # BASELINE config B: 16 levels x 2 channels = one feature tile
+        model, _, _ = bench.build_model(torch.device("cuda", 0))
+    else:                                                # the reference's waymo.gin field: 10 levels x 4 channels = 40 features
+        torch.manual_seed(1)
+        with models.bindings(NerfMLP=dict(grid_level_dim=4, grid_log2_hashmap_size=12), PropMLP=dict(grid_log2_hashmap_size=12)):
+            model = models.Model(config=configs.Config(), num_levels=2, num_prop_samples=64, num_nerf_samples=128).cuda()
     mlp = model.nerf_mlp
+    F_in = mlp.encoder.num_levels * mlp.encoder.level_dim
+    assert F_in == (32 if field == "B" else 40)
     N, S = 96, 128
     g = torch.Generator(device="cuda").manual_seed(8)
-    feat0 = torch.randn(N * S, 32, device="cuda", generator=g) * 0.5
+    feat0 = torch.randn(N * S, F_in, device="cuda", generator=g) * 0.5
     vd = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
     cd, cr = torch.randn(N, S, device="cuda", generator=g), torch.randn(N, S, 3, device="cuda", generator=g)
     names = [n for n, _ in mlp.named_parameters() if "encoder" not in n]

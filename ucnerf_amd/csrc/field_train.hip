@@ -25,7 +25,7 @@ namespace {
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 struct TrainFwdArgs {
-    const float *feat;        // [M, F] fp32, F <= 32 (sample-major, what k_march_features writes for the GEMMs)
+    const float *feat;        // [M, F] fp32, F <= 64 (sample-major, what k_march_features writes for the GEMMs)
     const uint4 *w;           // packed fragments: L0 (2x1x2), L1 (8x2x2), L2 (8x8x2), L3 (8x16x2), L4 (1x8x2)
     const float *bias_d0, *bias_d1, *bias_rgb;   // accumulator order: [tile][h][16]
     const float *pr0, *pr1;   // [N, 8][2][16] fp32, accumulator order per ray
@@ -90,8 +90,8 @@ __device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &ac
 // fragments arrive by global_load_lds DMA issued one piece per four MFMAs of the current chunk, one barrier per chunk.
 // (A first version staged 32 KiB chunks through registers one chunk ahead: the L2 latency of a chunk, ~1.5 us, is longer
 // than its 0.4 us of MFMAs, so every boundary waited -- 1.1 ms per call.)
-constexpr int kFrags = 2 * 1 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;      // 436
-constexpr int kChunks = (kFrags + kChunkGroups - 1) / kChunkGroups;                        // 7 (stream zero-padded)
+constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
+constexpr int kChunks = (kFragsMax + kChunkGroups - 1) / kChunkGroups;                     // 7 either way (stream zero-padded)
 
 template <int... Is, class F>
 __device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -115,6 +115,7 @@ __device__ __forceinline__ void layer(WeightStream &ws, f32x16 (&acc)[NT_OUT], c
     });
 }
 
+template <int NTF>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
@@ -128,23 +129,26 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     ws.issue(0);
 
     // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
-    bf8 fin[1][2];
+    bf8 fin[NTF][2];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        float v[8];
+    for (int ft = 0; ft < NTF; ft++)
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t k = 16u * s + 8u * h + e;
-            v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
+        for (int s = 0; s < 2; s++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t k = 32u * ft + 16u * s + 8u * h + e;
+                v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
+            }
+            fin[ft][s] = pack8(v);
         }
-        fin[0][s] = pack8(v);
-    }
     ws.sync();                              // chunk 0 and the feature loads above land together
     // ---- density layer 0
     f32x16 a0[2];
     load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
     load_acc(a.bias_d0 + (1 * 2 + h) * 16, a0[1]);
-    layer<2, 1, 0>(ws, a0, fin);
+    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 128, G4 = G3 + 256;
+    layer<2, NTF, 0>(ws, a0, fin);
     bf8 h0[2][2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     f32x16 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) load_acc(a.bias_d1 + (t * 2 + h) * 16, acc[t]);
-    layer<8, 2, 4>(ws, acc, h0);
+    layer<8, 2, G1>(ws, acc, h0);
     bf8 xin[16][2];                         // tiles 0..7: h1 (filled below), 8..15: x  -- the order of W1 = [W1h | W1x]
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         bf8 xonly[8][2];
 #pragma unroll
         for (int t = 0; t < 8; t++) { xonly[t][0] = xin[8 + t][0]; xonly[t][1] = xin[8 + t][1]; }
-        layer<8, 8, 36>(ws, acc, xonly);
+        layer<8, 8, G2>(ws, acc, xonly);
     }
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     // ---- colour layer 1: [h1, x] -> h2
 #pragma unroll
     for (int t = 0; t < 8; t++) load_acc(a.pr1 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
-    layer<8, 16, 164>(ws, acc, xin);
+    layer<8, 16, G3>(ws, acc, xin);
     bf8 h2[8][2];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     // ---- rgb layer (3 rows of one padded output tile)
     f32x16 yo[1];
     load_acc(a.bias_rgb + h * 16, yo[0]);
-    layer<1, 8, 420>(ws, yo, h2);
+    layer<1, 8, G4>(ws, yo, h2);
     if (live && h == 0) {
         a.y[(size_t)sample * 3 + 0] = yo[0][0];
         a.y[(size_t)sample * 3 + 1] = yo[0][1];
@@ -238,6 +242,7 @@ __device__ __forceinline__ void zero_acc(f32x16 &a) {
     for (int r = 0; r < 16; r++) a[r] = 0.0f;
 }
 
+template <int NTF>
 __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,21 +324,25 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
         store_tile(a.gh0, 64, sample, t, h, gh0[t], live);
     }
     // ---- density layer 0 backwards: the feature gradient, fp32, natural feature order
-    f32x16 gf[1];
-    zero_acc(gf[0]);
-    layer<1, 2, 432>(ws, gf, gh0);
+    f32x16 gf[NTF];
+#pragma unroll
+    for (int ft = 0; ft < NTF; ft++) zero_acc(gf[ft]);
+    layer<NTF, 2, 432>(ws, gf, gh0);
     if (live) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t f0 = 8u * q + 4u * h;                       // features f0 .. f0 + 3 = registers 4q .. 4q + 3
-            if (f0 + 3 < a.F) {
-                *reinterpret_cast<float4 *>(a.gfeat + (size_t)sample * a.F + f0) = make_float4(gf[0][4 * q], gf[0][4 * q + 1], gf[0][4 * q + 2], gf[0][4 * q + 3]);
-            } else {
+        for (int ft = 0; ft < NTF; ft++)
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (f0 + e < a.F) a.gfeat[(size_t)sample * a.F + f0 + e] = gf[0][4 * q + e];
+            for (int q = 0; q < 4; q++) {
+                const uint32_t f0 = 32u * ft + 8u * q + 4u * h;            // features f0 .. f0 + 3 = registers 4q .. 4q + 3
+                if (f0 + 3 < a.F && a.F % 4 == 0) {
+                    *reinterpret_cast<float4 *>(a.gfeat + (size_t)sample * a.F + f0) =
+                        make_float4(gf[ft][4 * q], gf[ft][4 * q + 1], gf[ft][4 * q + 2], gf[ft][4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (f0 + e < a.F) a.gfeat[(size_t)sample * a.F + f0 + e] = gf[ft][4 * q + e];
+                }
             }
-        }
     }
 }
 
@@ -348,11 +357,12 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     if (M == 0) return 0;
     UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y && m0 && m1 && m2,
                 "train_fwd: null pointer argument");
-    UCN_REQUIRE(F >= 1 && F <= 32, "train_fwd: 1..32 input features, got %u", F);
+    UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
                    (uint16_t *)h2, raw, y, m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
-    hipLaunchKernelGGL(k_train_fwd, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_fwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
 }
@@ -363,11 +373,12 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const void *packe
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gx && gh0 && gfeat, "train_bwd: null pointer argument");
-    UCN_REQUIRE(F >= 1 && F <= 32, "train_bwd: 1..32 input features, got %u", F);
+    UCN_REQUIRE(F >= 1 && F <= 64, "train_bwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");
     TrainBwdArgs a{(const uint16_t *)gy, (const uint16_t *)graw, (const uint4 *)packed_t, m0, (const uint4 *)m1, (const uint4 *)m2,
                    (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, gfeat, (uint32_t)M, F};
-    hipLaunchKernelGGL(k_train_bwd, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }

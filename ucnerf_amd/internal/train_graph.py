@@ -377,7 +377,7 @@ class _FusedHeads(torch.autograd.Function):
 
 def _fusable_heads(mlp, feat):
     return (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not mlp.disable_rgb
-            and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and feat.shape[1] <= 32
+            and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and feat.shape[1] <= 64
             and mlp.density_layer[0].out_features == 64 and mlp.density_layer[2].out_features == 256
             and mlp.net_width_viewdirs == 256 and mlp.rgb_layer.out_features == 3)
 
