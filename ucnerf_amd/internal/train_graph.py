@@ -256,25 +256,41 @@ def _perm(r, g):
     return (r & 3) + 8 * (r >> 2) + 4 * g
 
 
-def _fragment_index(rows, cols, natural, device):
-    """Gather index into a zero-padded [32*NT_OUT, 32*NT_IN] weight for its MFMA A-fragments in consumption order
-    [out tile pair][in tile][k-step][tile of the pair][lane][8]: lane (row = lane & 31, g = lane >> 5) element e is
-    W[32 ot + row][32 it + k], k = 16 s + 8 g + e for the first layer (features arrive in natural order) and
-    perm(8 s + e, g) for the others (the producing layer's accumulator order)."""
-    key = (rows, cols, natural, str(device))
-    hit = _FRAG_CACHE.get(key)
-    if hit is None:
-        nto, nti = (rows + 31) // 32, (cols + 31) // 32
-        p = 1 if nto == 1 else 2                              # output tiles in pairs, the pair innermost (csrc/field_train.hip)
-        assert nto % p == 0
-        otp, it, s_, o2, lane, e = torch.meshgrid(torch.arange(nto // p), torch.arange(nti), torch.arange(2), torch.arange(p),
-                                                  torch.arange(64), torch.arange(8), indexing="ij")
-        ot = p * otp + o2
-        row, g = lane & 31, lane >> 5
-        k = 16 * s_ + 8 * g + e if natural else _perm(8 * s_ + e, g)
-        hit = (((32 * ot + row) * (32 * nti) + 32 * it + k).reshape(-1).to(device), nto, nti)
-        _FRAG_CACHE[key] = hit
-    return hit
+def _fragment_index(rows, cols, natural):
+    """(row, col) of every element of a [rows, cols] weight's MFMA A-fragments in consumption order
+    [out tile pair][in tile][k-step][tile of the pair][lane][8] (a single output tile: [in tile][k-step][lane][8]):
+    lane (row = lane & 31, g = lane >> 5) element e is W[32 ot + row][32 it + k], k = 16 s + 8 g + e for the first
+    layer (features arrive in natural order) and perm(8 s + e, g) for the others (the producing layer's accumulator
+    order).  Positions beyond the matrix (tile padding) come back as row = -1."""
+    nto, nti = (rows + 31) // 32, (cols + 31) // 32
+    p = 1 if nto == 1 else 2                                  # output tiles in pairs, the pair innermost (csrc/field_train.hip)
+    assert nto % p == 0
+    otp, it, s_, o2, lane, e = torch.meshgrid(torch.arange(nto // p), torch.arange(nti), torch.arange(2), torch.arange(p),
+                                              torch.arange(64), torch.arange(8), indexing="ij")
+    row, g = 32 * (p * otp + o2) + (lane & 31), lane >> 5
+    col = 32 * it + (16 * s_ + 8 * g + e if natural else _perm(8 * s_ + e, g))
+    valid = (row < rows) & (col < cols)
+    return torch.where(valid, row, torch.full_like(row, -1)).reshape(-1), col.reshape(-1)
+
+
+def _pack_fragments(weights, device, total=0):
+    """bf16 fragment stream of [(W, natural_k_order), ...]: ONE gather from the concatenated matrices (+ a zero slot
+    for the tile padding and the stream's tail); the gather index depends only on the shapes and is cached."""
+    key = ("pack", tuple((tuple(W.shape), tuple(W.stride()), nat) for W, nat in weights), total, str(device))
+    idx = _FRAG_CACHE.get(key)
+    if idx is None:
+        parts, off = [], 0
+        for W, nat in weights:
+            r, c = _fragment_index(W.shape[0], W.shape[1], nat)
+            parts.append(torch.where(r >= 0, off + r * W.shape[1] + c, torch.full_like(r, -1)))
+            off += W.numel()
+        flat = torch.cat(parts)
+        if total * 512 > flat.numel():
+            flat = torch.cat([flat, flat.new_full((total * 512 - flat.numel(),), -1)])
+        idx = torch.where(flat >= 0, flat, torch.full_like(flat, off)).to(device)      # `off` = the zero slot
+        _FRAG_CACHE[key] = idx
+    src = torch.cat([W.reshape(-1) for W, _ in weights] + [weights[0][0].new_zeros(1)])
+    return src[idx]
 
 
 def _acc_order(width, device):
@@ -286,18 +302,6 @@ def _acc_order(width, device):
         hit = (32 * t + _perm(r, g)).reshape(-1).to(device)
         _FRAG_CACHE[key] = hit
     return hit
-
-
-def _pack_fragments(weights, device, total=0):
-    """bf16 fragments of [(W, natural_k_order), ...] concatenated: one gather per matrix (index cached)."""
-    out = []
-    for W, natural in weights:
-        idx, nto, nti = _fragment_index(W.shape[0], W.shape[1], natural, device)
-        pad = torch.zeros(32 * nto, 32 * nti, device=device, dtype=torch.bfloat16)
-        pad[:W.shape[0], :W.shape[1]] = W
-        out.append(pad.reshape(-1)[idx])
-    flat = torch.cat(out)
-    return torch.cat([flat, flat.new_zeros(total * 512 - flat.numel())]) if total * 512 > flat.numel() else flat
 
 
 def _acc_vec(v, width, device):
