@@ -348,12 +348,14 @@ def main():
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         gather["frac"] = gather["achieved"] / gather["peak"]
         # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
-        # same command (profiles/r01f_final/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes)
+        # same command (profiles/r01j_chunk/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
+        # when this run's launches have the size those passes measured
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_final", "traffic.json")))
-            gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
-            gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
-                                      "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_chunk", "traffic.json")))
+            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5:
+                gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+                gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
+                                          "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
         except (OSError, KeyError, ValueError):
             pass
         split = model.nerf_mlp.mlp_mode == 1

@@ -309,7 +309,9 @@ class Model(nn.Module):
     std_scale: float = 0.5
     prop_desired_grid_size = [512, 2048]
     # ---- knobs of this implementation (not in the reference) ----
-    max_chunk_rays: int = 1 << 16        # rays per internal pass (bounds the feature workspace)
+    max_chunk_rays: int = 10240          # rays per internal pass.  At S=128, F=32 the feature workspace is 168 MB: with
+    #                                      the tables (64 + 24 MB) it stays inside the 256 MB Infinity Cache between the
+    #                                      featurisation that writes it and the MLP that reads it (65 536: 5 % slower)
     levels_per_block: int = 0            # hash-grid levels per thread: 0 = auto (coarse levels together, fine alone)
     overlap_streams: bool = False        # featurisation of pass i+1 beside the MLP of pass i on a second HIP stream:
     #                                      measured +1 % only (both kernels want every CU), so off by default
