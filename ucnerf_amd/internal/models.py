@@ -384,13 +384,19 @@ class Model(nn.Module):
         sdist_prev = weights_prev = None
         n_prev = 0
         prod_num_samples = 1
-        chunk = max(1, int(self.max_chunk_rays))
+        nerf_chunk = max(1, int(self.max_chunk_rays))
+        nerf_row = self.num_nerf_samples * self.nerf_mlp.encoder.num_levels * self.nerf_mlp.encoder.level_dim
         for i_level in range(self.num_levels):
             is_prop = i_level < self.num_levels - 1
             S = self.num_prop_samples if is_prop else self.num_nerf_samples
             mlp = self.get_submodule(f'prop_mlp_{i_level}') if is_prop else self.nerf_mlp
             desc = mlp.field()
             L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
+            # max_chunk_rays is quoted for the NeRF level; a proposal level (fewer samples, narrower features) takes
+            # proportionally more rays per pass -- the same workspace bytes, fewer and longer launches
+            chunk = nerf_chunk
+            if is_prop and S * L * C < nerf_row:
+                chunk = max(nerf_chunk, min(nerf_chunk * nerf_row // (S * L * C) // 256 * 256, 1 << 16))
             dilation = self.dilation_bias + self.dilation_multiplier * 1.0 / prod_num_samples
             prod_num_samples *= S
             # ---- random draws, in the reference's order (stepfun.py:216, render.py:123,124,140)
