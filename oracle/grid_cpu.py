@@ -82,6 +82,43 @@ def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, 
                                       ctypes.c_uint32(gridtype), ctypes.c_int(bool(align_corners)))
 
 
+# ---------------------------------------------------------------- fp16 tables (grid.py:43-44 autocast policy)
+def grid_encode_forward_half(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+                             interp):
+    """kernel_grid with scalar_t = at::Half: embeddings / outputs / dy_dx are torch.float16 CPU tensors."""
+    _chk(inputs, "inputs"); _chk(embeddings, "embeddings", torch.float16); _chk(outputs, "outputs", torch.float16)
+    _chk(offsets, "offsets", torch.int32)
+    if dy_dx is not None:
+        _chk(dy_dx, "dy_dx", torch.float16)
+    lib().grid_oracle_forward_h(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), ctypes.c_uint32(B),
+                                ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(float(S)),
+                                ctypes.c_uint32(H), _p(dy_dx), ctypes.c_uint32(gridtype),
+                                ctypes.c_int(bool(align_corners)), ctypes.c_uint32(interp))
+
+
+def grid_encode_backward_half(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                              align_corners, interp):
+    _chk(grad, "grad", torch.float16); _chk(inputs, "inputs"); _chk(grad_embeddings, "grad_embeddings", torch.float16)
+    _chk(offsets, "offsets", torch.int32)
+    lib().grid_oracle_backward_h(_p(grad), _p(inputs), _p(offsets), _p(grad_embeddings), ctypes.c_uint32(B),
+                                 ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(float(S)),
+                                 ctypes.c_uint32(H), _p(dy_dx), _p(grad_inputs), ctypes.c_uint32(gridtype),
+                                 ctypes.c_int(bool(align_corners)), ctypes.c_uint32(interp))
+
+
+def half_bits_to_float(bits):
+    """numpy uint16 array -> float32 through the oracle's software conversion (checked against numpy in the tests)."""
+    f = lib().grid_oracle_h2f
+    f.restype, f.argtypes = ctypes.c_float, [ctypes.c_uint16]
+    return np.array([f(int(b)) for b in np.asarray(bits).reshape(-1)], dtype=np.float32)
+
+
+def float_to_half_bits(vals):
+    f = lib().grid_oracle_f2h
+    f.restype, f.argtypes = ctypes.c_uint16, [ctypes.c_float]
+    return np.array([f(float(v)) for v in np.asarray(vals, dtype=np.float32).reshape(-1)], dtype=np.uint16)
+
+
 def level_constants(offsets, S, H):
     L = offsets.numel() - 1
     scale = np.zeros(L, np.float32)

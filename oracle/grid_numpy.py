@@ -113,3 +113,47 @@ def backward_table(grad, x, offsets, S, H, n_rows, gridtype=0, align_corners=Fal
                 contrib = (w[:, None] * grad[l]).astype(np.float32).astype(np.float64)
                 np.add.at(g, r[ok], contrib[ok])
     return g
+
+
+def _h(a):
+    """round float32 -> binary16 -> float32 (numpy's conversion is IEEE round-to-nearest-even)"""
+    with np.errstate(over='ignore'):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def forward_half(x, table16, offsets, S, H, gridtype=0, align_corners=False, interp=0):
+    """kernel_grid with scalar_t = at::Half (grid.py:43-44 under autocast): table16 float16 [rows_total,C] ->
+    float16 [L,B,C].  c10::Half has no fused or mixed accumulate: `results += w * grid[i]` (gridencoder.cu:187)
+    rounds the float product to half, adds in float, rounds again (torch/headeronly/util/Half.h)."""
+    x = np.asarray(x, np.float32)
+    B, D = x.shape
+    C = table16.shape[1]
+    scale, res, rows = level_geometry(offsets, S, H)
+    L = len(scale)
+    out = np.zeros((L, B, C), np.float16)
+    oob = ((x < 0) | (x > 1)).any(axis=1)
+    with np.errstate(over='ignore'):
+        for l in range(L):
+            half = np.float32(0.0 if align_corners else 0.5)
+            p = _fma(x, np.broadcast_to(scale[l], x.shape), np.broadcast_to(half, x.shape))
+            cell = np.floor(p).astype(np.uint32)
+            f = (p - cell.astype(np.float32)).astype(np.float32)
+            if interp == 1:
+                f = (f * f * (np.float32(3.0) - np.float32(2.0) * f)).astype(np.float32)
+            acc = np.zeros((B, C), np.float32)                       # always holds a half-representable value
+            tab = table16[offsets[l]:offsets[l + 1]].astype(np.float32)
+            for k in range(1 << D):
+                w = np.ones(B, np.float32)
+                corner = cell.copy()
+                for d in range(D):
+                    if k & (1 << d):
+                        w = (w * f[:, d]).astype(np.float32)
+                        corner[:, d] += np.uint32(1)
+                    else:
+                        w = (w * (np.float32(1.0) - f[:, d])).astype(np.float32)
+                r = rows_of(corner, rows[l], res[l], gridtype, align_corners)
+                prod = _h((w[:, None] * tab[r]).astype(np.float32))
+                acc = _h((acc + prod).astype(np.float32))
+            acc[oob] = 0
+            out[l] = acc.astype(np.float16)
+    return out

@@ -268,6 +268,170 @@ void grid_oracle_total_variation(const float *inputs, const float *emb, float *g
     }
 }
 
+/* ------------------------------------------------------- fp16 tables (autocast) */
+/* grid.py:43-44 casts the table to torch.half under autocast (C even), so kernel_grid runs with
+ * scalar_t = at::Half.  What the reference's expressions then compute follows from c10::Half's operator
+ * set (torch/headeronly/util/Half.h; tests/test_oracle_grid.py compiles the expressions against that very
+ * header and checks this file's spelling of them):
+ *   float * Half -> float;  Half - Half -> Half (float subtract, rounded);  Half * Half -> Half;
+ *   Half += <float>  converts the float to Half FIRST (round to nearest even), then adds in float and rounds:
+ *       results[ch] += w * grid[i]         (gridencoder.cu:187)  acc = h(f(acc) + f(h(w * f(g))))
+ *       results_grad[ch] += w*(r-l)*pd     (gridencoder.cu:235)  acc = h(f(acc) + f(h((w * f(h(f(r)-f(l)))) * pd)))
+ *       result += grad * dy_dx             (gridencoder.cu:364)  acc = h(f(acc) + f(h(f(g) * f(d))))
+ *   (__half)(w * grad_cur[c]) + atomicAdd(__half2)  (gridencoder.cu:325-331)  row = h(f(row) + f(h(w * f(g))))
+ * None of these contains a float multiply feeding a float add directly, so nvcc's fmad contraction has
+ * nothing to fuse.  gcc 11 has no _Float16 on x86-64: binary16 <-> binary32 is done in software below
+ * (round to nearest even, subnormals and infinities included) and checked against numpy in the tests. */
+typedef uint16_t go_half;
+
+float grid_oracle_h2f(go_half h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {                                           /* subnormal: normalise */
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+go_half grid_oracle_f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (go_half)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));   /* NaN / inf */
+    if (x >= 0x477FF000u) return (go_half)(sign | 0x7C00u);                /* >= 65520 rounds to inf */
+    if (x < 0x33000001u) return sign;                                      /* <= 2^-25: rounds to zero */
+    const int e = (int)(x >> 23) - 127;
+    uint32_t man = (x & 0x7FFFFFu) | 0x800000u;                            /* 24-bit significand */
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                            /* bits dropped */
+    uint32_t q = man >> shift, rem = man & ((1u << shift) - 1u), half_ulp = 1u << (shift - 1);
+    if (rem > half_ulp || (rem == half_ulp && (q & 1u))) q++;
+    /* q carries the hidden bit for normals (bit 10); the exponent field absorbs a mantissa carry */
+    const uint32_t out = e >= -14 ? (((uint32_t)(e + 15 - 1) << 10) + q) : q;
+    return (go_half)(sign | out);
+}
+
+#define H2F grid_oracle_h2f
+#define F2H grid_oracle_f2h
+
+void grid_oracle_forward_h(const float *inputs, const go_half *emb, const int32_t *offsets,
+                           go_half *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                           uint32_t H, go_half *dy_dx, uint32_t gridtype, int align_corners,
+                           uint32_t interp) {
+    for (uint32_t level = 0; level < L; level++) {
+        const go_level_t lv = go_level(offsets, level, S, H);
+        const go_half *tab = emb + (size_t)lv.first_row * C;
+#pragma omp parallel for schedule(static)
+        for (int64_t bb = 0; bb < (int64_t)B; bb++) {
+            const uint32_t b = (uint32_t)bb;
+            const float *x = inputs + (size_t)b * D;
+            go_half *out = outputs + ((size_t)level * B + b) * C;
+            go_half *jac = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : 0;
+            if (go_outside(x, D)) {
+                for (uint32_t c = 0; c < C; c++) out[c] = 0;
+                if (jac) memset(jac, 0, sizeof(go_half) * D * C);
+                continue;
+            }
+            uint32_t cell[GO_MAX_D], corner[GO_MAX_D];
+            float frac[GO_MAX_D], dfrac[GO_MAX_D];
+            go_half acc[GO_MAX_C];
+            go_locate(x, D, lv.scale, align_corners, interp, cell, frac, dfrac);
+            for (uint32_t c = 0; c < C; c++) acc[c] = 0;
+            for (uint32_t k = 0; k < (1u << D); k++) {
+                float w = 1.0f;
+                for (uint32_t d = 0; d < D; d++) {
+                    if (k & (1u << d)) { w *= frac[d];          corner[d] = cell[d] + 1u; }
+                    else               { w *= 1.0f - frac[d];   corner[d] = cell[d]; }
+                }
+                const go_half *row = tab + (size_t)go_row(D, gridtype, align_corners, lv.rows,
+                                                          lv.resolution, corner) * C;
+                for (uint32_t c = 0; c < C; c++)
+                    acc[c] = F2H(H2F(acc[c]) + H2F(F2H(w * H2F(row[c]))));
+            }
+            for (uint32_t c = 0; c < C; c++) out[c] = acc[c];
+            if (jac) {
+                for (uint32_t gd = 0; gd < D; gd++) {
+                    go_half g[GO_MAX_C];
+                    for (uint32_t c = 0; c < C; c++) g[c] = 0;
+                    for (uint32_t k = 0; k < (1u << (D - 1)); k++) {
+                        float w = lv.scale;
+                        for (uint32_t nd = 0; nd < D - 1; nd++) {
+                            const uint32_t d = (nd >= gd) ? nd + 1 : nd;
+                            if (k & (1u << nd)) { w *= frac[d];        corner[d] = cell[d] + 1u; }
+                            else                { w *= 1.0f - frac[d]; corner[d] = cell[d]; }
+                        }
+                        corner[gd] = cell[gd];
+                        const go_half *lo = tab + (size_t)go_row(D, gridtype, align_corners, lv.rows,
+                                                                 lv.resolution, corner) * C;
+                        corner[gd] = cell[gd] + 1u;
+                        const go_half *hi = tab + (size_t)go_row(D, gridtype, align_corners, lv.rows,
+                                                                 lv.resolution, corner) * C;
+                        for (uint32_t c = 0; c < C; c++) {
+                            const float diff = H2F(F2H(H2F(hi[c]) - H2F(lo[c])));
+                            g[c] = F2H(H2F(g[c]) + H2F(F2H((w * diff) * dfrac[gd])));
+                        }
+                    }
+                    for (uint32_t c = 0; c < C; c++) jac[gd * C + c] = g[c];
+                }
+            }
+        }
+    }
+}
+
+/* grad [L,B,C] half, grad_emb [rows,C] half (pre-zeroed), dy_dx / grad_inputs half or NULL.  Adds in
+ * increasing b then corner order: one of the orders the half atomics can produce. */
+void grid_oracle_backward_h(const go_half *grad, const float *inputs, const int32_t *offsets,
+                            go_half *grad_emb, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                            uint32_t H, const go_half *dy_dx, go_half *grad_inputs, uint32_t gridtype,
+                            int align_corners, uint32_t interp) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ll = 0; ll < (int64_t)L; ll++) {
+        const uint32_t level = (uint32_t)ll;
+        const go_level_t lv = go_level(offsets, level, S, H);
+        go_half *gtab = grad_emb + (size_t)lv.first_row * C;
+        for (uint32_t b = 0; b < B; b++) {
+            const float *x = inputs + (size_t)b * D;
+            if (go_outside(x, D)) continue;
+            const go_half *g = grad + ((size_t)level * B + b) * C;
+            uint32_t cell[GO_MAX_D], corner[GO_MAX_D];
+            float frac[GO_MAX_D], dfrac[GO_MAX_D];
+            go_locate(x, D, lv.scale, align_corners, interp, cell, frac, dfrac);
+            for (uint32_t k = 0; k < (1u << D); k++) {
+                float w = 1.0f;
+                for (uint32_t d = 0; d < D; d++) {
+                    if (k & (1u << d)) { w *= frac[d];        corner[d] = cell[d] + 1u; }
+                    else               { w *= 1.0f - frac[d]; corner[d] = cell[d]; }
+                }
+                go_half *row = gtab + (size_t)go_row(D, gridtype, align_corners, lv.rows,
+                                                     lv.resolution, corner) * C;
+                for (uint32_t c = 0; c < C; c++)
+                    row[c] = F2H(H2F(row[c]) + H2F(F2H(w * H2F(g[c]))));
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)B * D; t++) {
+            const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t % D);
+            const go_half *jac = dy_dx + (size_t)b * L * D * C;
+            go_half r = 0;
+            for (uint32_t l = 0; l < L; l++)
+                for (uint32_t c = 0; c < C; c++)
+                    r = F2H(H2F(r) + H2F(F2H(H2F(grad[((size_t)l * B + b) * C + c]) *
+                                             H2F(jac[(size_t)l * D * C + d * C + c]))));
+            grad_inputs[t] = r;
+        }
+    }
+}
+
 /* exported for tests: the per-level constants the kernels must agree on */
 void grid_oracle_level_constants(const int32_t *offsets, uint32_t L, float S, uint32_t H,
                                  float *scale_out, uint32_t *resolution_out) {

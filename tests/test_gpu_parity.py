@@ -91,6 +91,105 @@ def test_grid_backward_and_tv():
     assert H.maxdiff(gt.cpu(), wt) <= 1e-5 * float(wt.abs().max())
 
 
+@pytest.mark.parametrize("D,C,gridtype,align,interp", [(3, 2, 1, False, 0), (3, 2, 0, True, 0), (3, 4, 1, True, 1),
+                                                       (5, 2, 0, False, 0), (5, 1, 1, False, 1), (5, 8, 0, True, 0),
+                                                       (2, 8, 1, True, 0), (4, 4, 0, True, 1)])
+def test_grid_forward_tiled_aligned_5d_bitexact(D, C, gridtype, align, interp):
+    """The dispatch axes the model itself never uses: gridtype 'tiled' (gridencoder.cu:78-82), align_corners
+    (:70,:148), D = 5 (:381-385) -- forward, dy_dx and the sequential input gradient bit-exact, table gradient to
+    atomic-order noise."""
+    from ucnerf_amd.gridencoder import _backend
+    rng = np.random.default_rng(500 + D * 10 + C + gridtype)
+    L, T = 6, 11
+    pls, offsets, sizes, _ = grid_cpu.table_layout(L, C, 16, 512, T, input_dim=D, align_corners=align)
+    table = torch.from_numpy(rng.random((int(offsets[-1]), C), dtype=np.float32) * 2 - 1)
+    B = 3000
+    x = rng.random((B, D), dtype=np.float32)
+    x[:4] = [[0.0] * D, [1.0] * D, [np.nextafter(np.float32(1), np.float32(2))] * D, [-1e-7] * D]
+    k = rng.integers(1, 500, size=(64, D)).astype(np.float32)
+    x[4:68] = (k - np.float32(0.0 if align else 0.5)) / np.float32(511.0)
+    x[68:100] = rng.random((32, D), dtype=np.float32) * 3 - 1
+    x = torch.from_numpy(x)
+    S = np.log2(pls)
+    want = torch.empty(L, B, C)
+    wjac = torch.empty(B, L * D * C)
+    grid_cpu.grid_encode_forward(x, table, offsets, want, B, D, C, L, S, 16, wjac, gridtype, align, interp)
+    got = torch.empty(L, B, C, device="cuda")
+    gjac = torch.empty(B, L * D * C, device="cuda")
+    _backend.grid_encode_forward(dev(x), dev(table), dev(offsets), got, B, D, C, L, S, 16, gjac, gridtype, align, interp)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(gjac.cpu(), wjac)
+    grad = torch.from_numpy(rng.standard_normal((L, B, C)).astype(np.float32))
+    want_g, want_gi = torch.zeros_like(table), torch.zeros(B, D)
+    grid_cpu.grid_encode_backward(grad, x, table, offsets, want_g, B, D, C, L, S, 16, wjac, want_gi, gridtype, align, interp)
+    got_g, got_gi = torch.zeros_like(table, device="cuda"), torch.zeros(B, D, device="cuda")
+    _backend.grid_encode_backward(dev(grad), dev(x), dev(table), dev(offsets), got_g, B, D, C, L, S, 16, gjac, got_gi,
+                                  gridtype, align, interp)
+    assert H.maxdiff(got_g.cpu(), want_g) <= 2e-5 * float(want_g.abs().max())
+    assert torch.equal(got_gi.cpu(), want_gi)
+    wt, gt = torch.zeros_like(table), torch.zeros_like(table, device="cuda")
+    grid_cpu.grad_total_variation(x, table, wt, offsets, 1e-2, B, D, C, L, S, 16, gridtype, align)
+    _backend.grad_total_variation(dev(x), dev(table), gt, dev(offsets), 1e-2, B, D, C, L, S, 16, gridtype, align)
+    assert H.maxdiff(gt.cpu(), wt) <= 1e-5 * float(wt.abs().max())
+
+
+@pytest.mark.parametrize("D,C,gridtype,align,interp", [(3, 2, 0, False, 0), (3, 4, 0, False, 1), (3, 8, 1, True, 0),
+                                                       (2, 2, 0, False, 0), (5, 2, 0, False, 0), (3, 1, 0, False, 0)])
+def test_grid_half_tables_vs_oracle(D, C, gridtype, align, interp):
+    """scalar_t = at::Half (what grid.py:43-44 selects under autocast when C is even; C = 1 through the raw op):
+    forward, dy_dx and the input gradient bit-exact against oracle/grid_oracle.c's half path (whose roundings are
+    pinned to the c10::Half header), table gradient to the order noise of half atomics."""
+    from ucnerf_amd.gridencoder import _backend
+    rng = np.random.default_rng(600 + D * 10 + C)
+    L, T = 7, 11
+    pls, offsets, sizes, _ = grid_cpu.table_layout(L, C, 16, 1024, T, input_dim=D, align_corners=align)
+    table = torch.from_numpy((rng.random((int(offsets[-1]), C), dtype=np.float32) * 2 - 1).astype(np.float16))
+    B = 2000
+    x = rng.random((B, D), dtype=np.float32)
+    x[:4] = [[0.0] * D, [1.0] * D, [np.nextafter(np.float32(1), np.float32(2))] * D, [-1e-7] * D]
+    x[4:36] = rng.random((32, D), dtype=np.float32) * 3 - 1
+    x = torch.from_numpy(x)
+    S = np.log2(pls)
+    want = torch.empty(L, B, C, dtype=torch.float16)
+    wjac = torch.empty(B, L * D * C, dtype=torch.float16)
+    grid_cpu.grid_encode_forward_half(x, table, offsets, want, B, D, C, L, S, 16, wjac, gridtype, align, interp)
+    got = torch.empty(L, B, C, device="cuda", dtype=torch.float16)
+    gjac = torch.empty(B, L * D * C, device="cuda", dtype=torch.float16)
+    _backend.grid_encode_forward(dev(x), dev(table), dev(offsets), got, B, D, C, L, S, 16, gjac, gridtype, align, interp)
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+    assert torch.equal(gjac.cpu().view(torch.int16), wjac.view(torch.int16))
+    grad = torch.from_numpy((rng.standard_normal((L, B, C)) * 0.05).astype(np.float16))
+    want_g = torch.zeros(int(offsets[-1]), C, dtype=torch.float16)
+    want_gi = torch.zeros(B, D, dtype=torch.float16)
+    grid_cpu.grid_encode_backward_half(grad, x, offsets, want_g, B, D, C, L, S, 16, wjac, want_gi, gridtype, align, interp)
+    got_g = torch.zeros(int(offsets[-1]), C, device="cuda", dtype=torch.float16)
+    got_gi = torch.zeros(B, D, device="cuda", dtype=torch.float16)
+    _backend.grid_encode_backward(dev(grad), dev(x), dev(table), dev(offsets), got_g, B, D, C, L, S, 16, gjac, got_gi,
+                                  gridtype, align, interp)
+    assert torch.equal(got_gi.cpu().view(torch.int16), want_gi.view(torch.int16))
+    # half atomics: every partial sum is rounded to half, the order differs -> a few half ulps of the row sums
+    scale = float(want_g.float().abs().max())
+    assert scale > 0 and H.maxdiff(got_g.cpu().float(), want_g.float()) <= 8 * 2 ** -10 * scale
+
+
+def test_grid_module_under_autocast_reads_half_tables():
+    """grid.py:43-44: under autocast the module's fp32 parameter is cast to half per call; output dtype half."""
+    from ucnerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=8, level_dim=2, desired_resolution=2048, log2_hashmap_size=11).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = (torch.rand(500, 3, device="cuda") * 2 - 1)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = enc(x)
+    assert out.dtype == torch.float16
+    pls, offsets, _, _ = grid_cpu.table_layout(8, 2, 16, 2048, 11)
+    want = torch.empty(8, 500, 2, dtype=torch.float16)
+    grid_cpu.grid_encode_forward_half(((x.cpu() + 1) / 2).contiguous(), enc.embeddings.detach().cpu().half(), offsets, want,
+                                      500, 3, 2, 8, np.log2(pls), 16, None, 0, False, 0)
+    assert torch.equal(out.cpu().view(torch.int16), want.permute(1, 0, 2).reshape(500, 16).contiguous().view(torch.int16))
+    out.float().sum().backward()
+    assert enc.embeddings.grad is not None and enc.embeddings.grad.dtype == torch.float32
+
+
 def test_grid_module_autograd_and_errors():
     from ucnerf_amd.gridencoder import GridEncoder, _backend
     enc = GridEncoder(num_levels=8, level_dim=2, desired_resolution=2048, log2_hashmap_size=11).cuda()

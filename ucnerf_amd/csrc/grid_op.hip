@@ -83,6 +83,23 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
 
+// acc += a * b in the reference's scalar_t arithmetic.  float: nvcc contracts to one fmaf.  at::Half: c10::Half has
+// no mixed accumulate -- the float product is rounded to half, the sum is formed in float and rounded again
+// (oracle/grid_oracle.c, "fp16 tables"; pinned against torch/headeronly/util/Half.h by tests/test_oracle_grid.py).
+// The product must be ROUNDED TO float before it is converted: the backend otherwise selects v_fma_mixlo_f16 for
+// half(a * float(half)), which rounds the exact product once (1 half ulp off the reference's float multiply +
+// conversion in ~2e-4 of the cases; seen with C = 1).  An empty asm on the value keeps the two roundings apart.
+__device__ __forceinline__ float f32_product(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+template <typename T>
+__device__ __forceinline__ T acc_mul(float a, float b, T acc) {
+    if constexpr (sizeof(T) == 4) return fmaf(a, b, acc);
+    else return from_f<T>(to_f<T>(acc) + to_f<T>(from_f<T>(f32_product(a, b))));
+}
+
 template <uint32_t D>
 __device__ __forceinline__ bool outside(const float *x) {
     bool o = false;
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256) void k_grid_forward(const float *__restrict__ 
         }
         const T *row = tab + (size_t)row_of<D>(lv, corner) * C;
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) acc[c] = from_f<T>(fmaf(w, to_f<T>(row[c]), to_f<T>(acc[c])));
+        for (uint32_t c = 0; c < C; c++) acc[c] = acc_mul<T>(w, to_f<T>(row[c]), acc[c]);
     }
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) out[c] = acc[c];
@@ -183,8 +200,8 @@ __global__ __launch_bounds__(256) void k_grid_forward(const float *__restrict__ 
                 corner[gd] = cell[gd] + 1u;
                 const T *hi = tab + (size_t)row_of<D>(lv, corner) * C;
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++)
-                    g[c] = from_f<T>(fmaf(w * (to_f<T>(hi[c]) - to_f<T>(lo[c])), dfrac[gd], to_f<T>(g[c])));
+                for (uint32_t c = 0; c < C; c++)   // (Half - Half) is itself rounded to half (gridencoder.cu:235)
+                    g[c] = acc_mul<T>(w * to_f<T>(from_f<T>(to_f<T>(hi[c]) - to_f<T>(lo[c]))), dfrac[gd], g[c]);
             }
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) jac[gd * C + c] = g[c];
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void k_grid_backward_f16(const __half *__restr
 #pragma unroll
             for (uint32_t c = 0; c < C; c += 2)
                 unsafeAtomicAdd(reinterpret_cast<__half2 *>(row + c),
-                                __halves2half2(__float2half(w * g[c]), __float2half(w * g[c + 1])));
+                                __halves2half2(__float2half(f32_product(w, g[c])), __float2half(f32_product(w, g[c + 1]))));
         } else {
             // C == 1: CAS loop on the containing 32-bit word
             uint32_t *word = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(row) & ~uintptr_t(3));
@@ -275,7 +292,8 @@ __global__ __launch_bounds__(256) void k_grid_backward_f16(const __half *__restr
             do {
                 assumed = old;
                 __half2 cur = *reinterpret_cast<__half2 *>(&assumed);
-                float v = __half2float(hi ? __high2half(cur) : __low2half(cur)) + w * g[0];
+                // gpuAtomicAdd(at::Half*, at::Half(w * grad)): the addend is rounded to half first
+                float v = __half2float(hi ? __high2half(cur) : __low2half(cur)) + __half2float(__float2half(f32_product(w, g[0])));
                 __half2 nw = hi ? __halves2half2(__low2half(cur), __float2half(v))
                                 : __halves2half2(__float2half(v), __high2half(cur));
                 old = atomicCAS(word, assumed, *reinterpret_cast<uint32_t *>(&nw));
@@ -296,8 +314,7 @@ __global__ __launch_bounds__(256) void k_input_backward(const T *__restrict__ gr
     T r = from_f<T>(0.0f);
     for (uint32_t l = 0; l < L; l++)
         for (uint32_t c = 0; c < C; c++)
-            r = from_f<T>(fmaf(to_f<T>(grad[((size_t)l * B + b) * C + c]),
-                               to_f<T>(jac[(size_t)l * D * C + d * C + c]), to_f<T>(r)));
+            r = acc_mul<T>(to_f<T>(grad[((size_t)l * B + b) * C + c]), to_f<T>(jac[(size_t)l * D * C + d * C + c]), r);
     grad_inputs[t] = r;
 }
 

@@ -1071,8 +1071,10 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     hipStream_t st = (hipStream_t)stream;
+    // experiment knob (tools/feat_occupancy.py): unused dynamic LDS per workgroup caps the workgroups per CU
+    static const size_t dummy_lds = getenv("UCN_FEAT_DUMMY_LDS") ? (size_t)atol(getenv("UCN_FEAT_DUMMY_LDS")) : 0;
 #define UCN_MF(CC)                                                                                              \
-    hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), 0, st, lv, f->embeddings, in, hx, std_scale, N, S, \
+    hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), dummy_lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
                        grp, layout, features_out, coord_out, tmean_out)
     switch (lv.C) {
         case 1: UCN_MF(1); break;

@@ -11,7 +11,6 @@ import torch
 from .. import _lib
 
 _F = (torch.float32, torch.float16, torch.float64)
-_host_offsets = {}
 
 
 def _checks(**tensors):
@@ -30,15 +29,19 @@ def _checks(**tensors):
 
 
 def host_offsets(offsets):
-    """One cached host copy per offsets tensor (the C ABI takes level offsets as HOST metadata)."""
-    key = (offsets.data_ptr(), offsets._version, offsets.numel())
-    hit = _host_offsets.get(key)
-    if hit is None:
-        hit = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
-        if len(_host_offsets) > 64:
-            _host_offsets.clear()
-        _host_offsets[key] = hit
-    return hit
+    """Host copy of a level-offsets tensor (the C ABI takes level offsets as HOST metadata).
+
+    Cached ON the tensor object together with the tensor's version counter: the copy dies with the tensor and
+    an in-place update (load_state_dict) invalidates it.  (A cache keyed on data_ptr would hand a freed
+    encoder's offsets to the next tensor the caching allocator places at that address.)"""
+    hit = getattr(offsets, "_ucn_host_offsets", None)
+    if hit is None or hit[0] != offsets._version:
+        hit = (offsets._version, np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32)))
+        try:
+            offsets._ucn_host_offsets = hit
+        except AttributeError:          # a tensor subclass without __dict__: fetch every time
+            pass
+    return hit[1]
 
 
 def _dtype_code(t):

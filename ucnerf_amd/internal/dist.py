@@ -39,14 +39,19 @@ def all_gather_rows(local, num_rays, world, rank):
     widths = [local[k].shape[1] for k in keys]
     rp = rows_per_rank(num_rays, world)
     any_t = local[keys[0]]
-    packed = torch.zeros(rp, sum(widths), device=any_t.device, dtype=torch.float32)
     n_loc = any_t.shape[0]
+    # one receive buffer per frame; this rank's rows are packed straight into its own slot of it (RCCL's in-place
+    # all-gather: send buffer = receive buffer + rank * count), so nothing frame-sized is allocated or zeroed twice
+    out = torch.empty(world * rp, sum(widths), device=any_t.device, dtype=torch.float32)
+    mine = out[rank * rp:(rank + 1) * rp]
     col = 0
     for k, w in zip(keys, widths):
-        packed[:n_loc, col:col + w] = local[k]
+        mine[:n_loc, col:col + w] = local[k]
         col += w
-    out = torch.empty(world * rp, sum(widths), device=any_t.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(out, packed)          # one collective per frame
+    if n_loc < rp:
+        mine[n_loc:].zero_()                          # padding rows of the last shard(s), stripped below
+    send = mine if dist.get_backend() == "nccl" else mine.clone()   # gloo (CPU tests) wants a separate send buffer
+    dist.all_gather_into_tensor(out, send)            # one collective per frame
     out = out[:num_rays]
     res, col = {}, 0
     for k, w in zip(keys, widths):

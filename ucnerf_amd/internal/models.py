@@ -135,9 +135,18 @@ class MLP(nn.Module):
                 if i == self.skip_layer_dir:
                     last_dim_rgb += input_dim_rgb
             self.rgb_layer = nn.Linear(last_dim_rgb, self.num_rgb_channels)
-        self._desc = None
-        self._desc_key = None
-        self._packed = None
+        self._fields = {}          # mlp_mode -> (key, ucn_field_t, packed weight stream): one packed buffer per mode
+
+    _UNPICKLED = ('_fields', '_grid_desc', '_grid_desc_key')
+
+    def __getstate__(self):
+        """copy.deepcopy / torch.save(model): the cached C descriptors hold raw device pointers (ctypes objects with
+        pointers cannot be pickled, and would dangle in a copy anyway) -- they are rebuilt on first use."""
+        state = self.__dict__.copy()
+        for k in self._UNPICKLED:
+            state.pop(k, None)
+        state['_fields'] = {}
+        return state
 
     # ---- C-ABI descriptor -------------------------------------------------------------------
     def _weights(self):
@@ -148,17 +157,20 @@ class MLP(nn.Module):
                    self.lin_second_stage_1.bias, self.rgb_layer.weight, self.rgb_layer.bias]
         return ws
 
-    def field(self):
-        """ucn_field_t for the current parameters; MFMA-ordered weight copy refreshed when any
-        parameter was updated in place or moved (render: once; train: once per optimiser step)."""
+    def field(self, mode=None):
+        """ucn_field_t for the current parameters and the given arithmetic mode (default: self.mlp_mode); the
+        MFMA-ordered weight copy of that mode is refreshed when any parameter was updated in place or moved
+        (render: once; train: once per optimiser step)."""
+        mode = int(self.mlp_mode if mode is None else mode)
         ws = self._weights()
         for w in ws:
             _lib.require_device(w, f"{type(self).__name__} parameter")
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise RuntimeError("field parameters must be contiguous float32")
-        key = tuple((w.data_ptr(), w._version) for w in ws) + (int(self.mlp_mode),)
-        if key == self._desc_key:
-            return self._desc
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        hit = self._fields.get(mode)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         lib = _lib.load()
         enc = self.encoder
         d = _lib.UcnField()
@@ -175,15 +187,16 @@ class MLP(nn.Module):
         d.n_dir = self.dim_dir_enc
         d.density_bias, d.rgb_premultiplier = float(self.density_bias), float(self.rgb_premultiplier)
         d.rgb_bias, d.rgb_padding = float(self.rgb_bias), float(self.rgb_padding)
-        d.mlp_mode = int(self.mlp_mode)
+        d.mlp_mode = mode
         n = lib.ucn_field_packed_floats(ctypes.byref(d))
         if n == 0:
             raise RuntimeError(lib.ucn_last_error().decode())
-        if self._packed is None or self._packed.numel() != n or self._packed.device != ws[0].device:
-            self._packed = torch.empty(n, dtype=torch.float32, device=ws[0].device)
-        d.packed = self._packed.data_ptr()
+        packed = hit[2] if hit is not None else None
+        if packed is None or packed.numel() != n or packed.device != ws[0].device:
+            packed = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+        d.packed = packed.data_ptr()
         _lib.check(lib.ucn_field_pack(ctypes.byref(d), _lib.stream()))
-        self._desc, self._desc_key = d, key
+        self._fields[mode] = (key, d, packed)
         return d
 
     def grid_field(self):
@@ -222,13 +235,8 @@ class MLP(nn.Module):
                     normals_pred=None, roughness=None)
 
     def _evaluate(self, means, stds, viewdirs, no_warp, want_x):
-        if want_x and self.mlp_mode != 0 and not self.disable_rgb:
-            # the split-f16 kernel composes the bottleneck away; the API that returns it uses the fp32 kernel
-            mode, self.mlp_mode = self.mlp_mode, 0
-            try:
-                return self._evaluate(means, stds, viewdirs, no_warp, want_x)
-            finally:
-                self.mlp_mode = mode
+        # the split-f16 kernel composes the bottleneck away; the API that returns it uses the fp32 kernel's packed copy
+        mode = 0 if (want_x and not self.disable_rgb) else int(self.mlp_mode)
         lib = _lib.load()
         _lib.require_device(means, "means")
         prefix = means.shape[:-2]
@@ -236,7 +244,7 @@ class MLP(nn.Module):
         if not 1 <= G <= 6:
             raise RuntimeError(f"predict_density: 1..6 Gaussians per feature supported, got {G}")
         B = int(np.prod(prefix)) if len(prefix) else 1
-        d = self.field()
+        d = self.field(mode)
         dev = means.device
         m = _f32(means, B * G, 3)
         s = _f32(stds, B * G, 1)
@@ -569,6 +577,18 @@ def bindings(**per_class):
 _MISSING = object()
 
 
+def unwrap_model(model):
+    """The bare Model behind DistributedDataParallel / DataParallel / accelerate wrappers (anything whose `.module`
+    is the wrapped nn.Module), as `accelerator.unwrap_model` would return it."""
+    seen = 0
+    while not hasattr(model, '_march') and isinstance(getattr(model, 'module', None), nn.Module) and seen < 8:
+        model = model.module
+        seen += 1
+    if not hasattr(model, '_march'):
+        raise TypeError(f"render_image: expected a ucnerf_amd Model (possibly DDP-wrapped), got {type(model).__name__}")
+    return model
+
+
 def render_image(model, accelerator, batch, rand, train_frac, config, verbose=True, return_weights=False,
                  eval_camidx=0):
     """ref models.py:907-1007: render every pixel of an [H, W, .] ray batch.
@@ -582,6 +602,9 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     replicated, so no other communication exists on the path."""
     from . import dist as udist
     model.eval()
+    # the reference hands over the `accelerator.prepare`d model (train.py:95,330, render.py:119,146, eval.py:103,140):
+    # a DistributedDataParallel wrapper when num_processes > 1.  The march itself is a method of the bare Model.
+    core = unwrap_model(model)
     height, width = batch['origins'].shape[:2]
     num_rays = height * width
     flat = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None and torch.is_tensor(v)}
@@ -590,9 +613,14 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     lo, hi = udist.shard_bounds(num_rays, world, rank)
     shard = {k: v[lo:hi] for k, v in flat.items()}
     with torch.no_grad():
-        renderings, history = model._march(rand, shard, train_frac, True, eval_camidx, want_history=return_weights)
+        renderings, history = core._march(rand, shard, train_frac, True, eval_camidx, want_history=return_weights)
     last = renderings[-1]
     keys = [k for k in last if not k.startswith('ray_')]
+    # rendering['weights'] ([H, W, S] of the last level) is 27x the pixels' payload.  The reference gathers it with
+    # everything else (models.py:965-968) but none of its callers reads it unless return_weights=True (where
+    # models.py:977 overwrites it with the history's copy): at num_processes > 1 it is exchanged only on request.
+    if world > 1 and not return_weights and not getattr(config, 'render_gather_weights', False):
+        keys = [k for k in keys if k != 'weights']
     local = {k: last[k].reshape(hi - lo, -1) for k in keys}
     if return_weights:
         local['weights'] = history[-1]['weights'].reshape(hi - lo, -1)

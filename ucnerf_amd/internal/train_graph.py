@@ -590,6 +590,18 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         rendering = {k: v.reshape(prefix + v.shape[1:]) for k, v in rendering.items()}
         rendering['weights'] = weights.reshape(prefix + (S,))
         if compute_extras:
+            # render.py:218-242: depth percentiles and the mean distance -- not differentiated by any loss of the path
+            # (train_utils.py reads them for metrics only), so they come from the rendering kernel on detached inputs
+            with torch.no_grad():
+                dn, rg = density.detach().float().contiguous(), rgbs.detach().float().contiguous()
+                w_x, main_x, extras = torch.empty(N, S, device=dev), torch.empty(N, 5, device=dev), torch.empty(N, 4, device=dev)
+                _lib.check(lib.ucn_composite(dn.data_ptr(), rg.data_ptr(), sdist.data_ptr(), near.data_ptr(), far.data_ptr(),
+                                             d.data_ptr(), float(model.bg_intensity_range[0]), int(bool(model.opaque_background)),
+                                             N, S, w_x.data_ptr(), main_x.data_ptr(), extras.data_ptr(), st))
+            rendering['distance_mean'] = extras[:, 0].reshape(prefix)
+            rendering['distance_percentile_5'] = extras[:, 1].reshape(prefix)
+            rendering['distance_median'] = extras[:, 2].reshape(prefix)
+            rendering['distance_percentile_95'] = extras[:, 3].reshape(prefix)
             n_vis = getattr(cfg, 'vis_num_rays', 16)
             rendering['ray_sdist'] = sdist[:n_vis]
             rendering['ray_weights'] = weights[:n_vis]
