@@ -114,6 +114,13 @@ int ucn_resample(const float *sdist_prev /*[N,n_prev+1]*/, const float *weights_
 int ucn_cone_basis(const float *cam_dirs /*[N,3]*/, const float *rand_vec /*[N,3]*/, uint32_t N,
                    float *basis_out /*[N,6] = e1,e2*/, ucn_stream_t stream);
 
+/* Launch-shape flag, OR-ed into ucn_march_features' `sample_major` and ucn_field_mlp's `rays_fastest` argument:
+ * the two kernels are meant to run SIMULTANEOUSLY on two HIP streams and share every CU -- the featurisation as
+ * 512-thread workgroups (two waves per SIMD) that reserve 88 KiB of LDS, the MLP with its 64 KiB weight ring
+ * (72 KiB in all), so that exactly one workgroup of each fits a CU (registers: 2 x 104 + 296 of 512 per SIMD lane).
+ * Results do not depend on it. */
+#define UCN_LAUNCH_CORESIDENT 0x100
+
 /* ref: render.py:94-152 cast_rays + coord.py:60-116 contraction + grid.py:158-174 /
  * gridencoder.cu:87-199 + models.py:494-496 (erf damping, mean over the 6 multisamples).
  * features_out layout [num_levels][N*S][level_dim]  (level-major like gridencoder.cu:108).

@@ -519,6 +519,15 @@ def make_spec(kind='B', **over):
         prop = FieldSpec('prop_mlp_0', grid_desired_resolution=512, grid_level_dim=2,
                          grid_log2_hashmap_size=12, disable_rgb=True)
         spec = PathSpec(num_levels=2, num_prop_samples=64, num_nerf_samples=128, nerf=nerf, props=[prop])
+    elif kind in ('cfg1', 'tiny64'):
+        # BASELINE.json configs[0]: 64 + 64 samples, "2x64" colour MLP = bottleneck_width 64,
+        # net_width_viewdirs 64, L = 16 / C = 2 / T = 2^19 tables ('tiny64': T = 2^12 for small fixtures)
+        T = 19 if kind == 'cfg1' else 12
+        nerf = FieldSpec('nerf_mlp', grid_desired_resolution=524288, grid_level_dim=2, grid_log2_hashmap_size=T,
+                         bottleneck_width=64, net_width_viewdirs=64)
+        prop = FieldSpec('prop_mlp_0', grid_desired_resolution=512, grid_level_dim=2, grid_log2_hashmap_size=T,
+                         disable_rgb=True)
+        spec = PathSpec(num_levels=2, num_prop_samples=64, num_nerf_samples=64, nerf=nerf, props=[prop])
     elif kind == 'tinyR':
         nerf = FieldSpec('nerf_mlp', grid_log2_hashmap_size=12)
         prop = FieldSpec('prop_mlp_0', grid_desired_resolution=512, grid_log2_hashmap_size=12, disable_rgb=True)

@@ -17,6 +17,7 @@ Fixture index:
   model_tinyR.npz   G7 Model.forward eval, waymo.gin-like (128+32, L10 C4) small tables
   model_sky.npz     G8 + sky NeRF + brightness correction (eval_camidx)
   model_train.npz   G7' Model.forward with rand=True (all draws captured), train_frac<1
+  model_tiny64.npz  G7 Model.forward eval, BASELINE configs[0] architecture (64+64, 64-wide colour MLP)  [`cfg1` mode]
   render_image.npz  G9 render_image on a 16x24 frame incl. a ragged last chunk
 """
 import os
@@ -313,6 +314,10 @@ def gen_train_step(ref, name, spec, seed):
 if __name__ == '__main__':
     ref = ref_import.load()
     torch.set_num_threads(1)              # fixed reduction order for the generating run
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg1':
+        # G7 for BASELINE configs[0]'s architecture (64 + 64 samples, 64-wide colour MLP), small tables
+        save('model_tiny64.npz', **npify(run_model(ref, rm.make_spec('tiny64'), 61, 48, 62, False)))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         gen_train_step(ref, 'train_step.npz', rm.make_spec('tiny'), 71)
         gen_train_step(ref, 'train_step_sky.npz', rm.make_spec('tiny', model_sky=True, brightness_correction=True), 81)

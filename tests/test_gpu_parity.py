@@ -320,6 +320,7 @@ def test_field_vs_golden():
 @pytest.mark.parametrize("name,kind,over", [
     ("model_tiny.npz", "tiny", {}),
     ("model_tinyR.npz", "tinyR", {}),
+    ("model_tiny64.npz", "tiny64", {}),                       # BASELINE configs[0] architecture: 64-wide colour MLP
     ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
     ("model_train.npz", "tiny", {}),
 ])
@@ -340,7 +341,7 @@ def test_model_forward_vs_golden(name, kind, over):
     # The last level of the L=16 configs is not (per-sample noise from 1-ulp coordinate changes, see
     # test_field_vs_golden / DESIGN.md); there the per-SAMPLE bars are loose and the per-PIXEL bars
     # (what north_star specifies) carry the parity claim.  tinyR (res <= 8192) sits in between.
-    fine = kind == "tiny"
+    fine = kind in ("tiny", "tiny64")
     for lvl in range(spec.num_levels):
         g = lambda k: fx[f"L{lvl}_{k}"]
         r = rend[lvl]
@@ -419,6 +420,103 @@ def test_mlp_modes_agree():
     assert H.maxdiff(out[0][0], out[1][0]) <= 2e-6                      # pixels
     rel = (out[0][1] - out[1][1]).abs() / (out[0][1].abs() + 1e-3)
     assert float(rel.max()) <= 2e-5                                     # per-sample densities
+
+
+@pytest.mark.parametrize("case", ["fresh_init", "big_table", "big_first_layer", "big_everything"])
+def test_split_f16_range(case):
+    """mlp_mode 1 carries every layer at a power-of-two scale chosen at pack time (field_mlp_h.hip, comment 5): f16
+    operands must neither overflow (|v| > 65504 -> inf) nor lose their low halves to the subnormal range, whatever the
+    magnitudes of the table and the weights.  Reference = mlp_mode 0 (exact fp32 products, itself pinned to the CPU
+    oracle by the tests above) on the same points.  Without the scales `big_first_layer` overflows h0 (|h0| ~ 1e6) and
+    `fresh_init` (|features| ~ 1e-4: the reference's own initialisation, grid.py:151-153) loses ~3e-4 relative."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=41)
+    g = torch.Generator().manual_seed(42)
+    if case == "fresh_init":
+        sd["nerf_mlp.encoder.embeddings"] = sd["nerf_mlp.encoder.embeddings"] * 1e-4
+    elif case == "big_table":
+        sd["nerf_mlp.encoder.embeddings"] = sd["nerf_mlp.encoder.embeddings"] * 1e3
+    elif case == "big_first_layer":
+        sd["nerf_mlp.density_layer.0.weight"] = sd["nerf_mlp.density_layer.0.weight"] * 1e6
+        sd["nerf_mlp.density_layer.2.weight"] = sd["nerf_mlp.density_layer.2.weight"] * 1e-6
+    elif case == "big_everything":
+        for k in list(sd):
+            if k.startswith("nerf_mlp.") and k.endswith("weight") and "rgb_layer" not in k:
+                sd[k] = sd[k] * 30.0
+        sd["nerf_mlp.encoder.embeddings"] = sd["nerf_mlp.encoder.embeddings"] * 1e2
+    model, _ = H.hip_model(spec, sd)
+    mlp = model.nerf_mlp
+    n, S = 64, 32
+    means = (torch.rand(n, S, 6, 3, generator=g) * 2 - 1) * 1.5
+    stds = torch.rand(n, S, 6, generator=g) * 1e-3
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    out = {}
+    with torch.no_grad():
+        for mode in (0, 1):
+            mlp.mlp_mode = mode
+            r = mlp(False, means.cuda(), stds.cuda(), viewdirs=vd.cuda()[:, None, :])
+            out[mode] = (r["density"].cpu().double(), r["rgb"].cpu().double())
+    d0, d1 = out[0][0], out[1][0]
+    assert torch.isfinite(d1).all() and torch.isfinite(out[1][1]).all(), "f16 operand overflow"
+    assert float(d0.abs().max()) > 0
+    # Truth: the dense layers in float64 on the oracle's (fp32) features.  At these magnitudes fp32 itself is
+    # ill-conditioned (logits of 1e5 carry 1e-2 of rounding), so "fp32-class" is stated as: the split-f16 kernel is as
+    # close to the float64 evaluation as the exact-fp32-product kernel is, up to a factor and a floor of fp32 ulps.
+    fs = spec.nerf
+    with torch.no_grad():
+        _, _, _, feat = rm.field_density_features(fs, sd, means, stds)
+        W = lambda k: sd["nerf_mlp." + k].double()
+        h0 = torch.relu(feat.double() @ W("density_layer.0.weight").T + W("density_layer.0.bias"))
+        x = h0 @ W("density_layer.2.weight").T + W("density_layer.2.bias")
+        t_d = torch.nn.functional.softplus(x[..., 0] + fs.density_bias)
+        enc = rm.view_encoding(vd, fs.deg_view).double()[:, None, :].expand(n, S, 27)
+        skip = torch.cat([x, enc], dim=-1)
+        h1 = torch.relu(skip @ W("lin_second_stage_0.weight").T + W("lin_second_stage_0.bias"))
+        h2 = torch.relu(torch.cat([h1, skip], dim=-1) @ W("lin_second_stage_1.weight").T + W("lin_second_stage_1.bias"))
+        t_rgb = torch.sigmoid(h2 @ W("rgb_layer.weight").T + W("rgb_layer.bias")) * (1 + 2 * fs.rgb_padding) - fs.rgb_padding
+    e0_d = float(((d0 - t_d).abs() / (t_d.abs() + 1e-3 * float(t_d.abs().max()) + 1e-9)).max())
+    e1_d = float(((d1 - t_d).abs() / (t_d.abs() + 1e-3 * float(t_d.abs().max()) + 1e-9)).max())
+    e0_c, e1_c = H.maxdiff(out[0][1], t_rgb), H.maxdiff(out[1][1], t_rgb)
+    assert e1_d <= 3 * e0_d + 2e-6, (case, e1_d, e0_d)
+    assert e1_c <= 3 * e0_c + 2e-6, (case, e1_c, e0_c)
+    if case == "fresh_init":                     # well conditioned: absolute bars too
+        assert e1_d <= 5e-6 and e1_c <= 5e-6, (e1_d, e1_c)
+
+
+def test_config0_workload_400x400_frame():
+    """BASELINE.json configs[0]: one 400 x 400 frame, random-init L16 / C2 / T = 2^19 hash grid + "2 x 64" colour MLP
+    (bottleneck_width = net_width_viewdirs = 64), 64 samples per level -- the reference's CPU-runnable case, here
+    through render_image.  The whole frame is rendered on the GPU; 2048 of its rays (what the CPU oracle finishes in
+    seconds) are compared with the oracle given the same random cone bases, both kernel arithmetic modes."""
+    from ucnerf_amd.internal import camera_utils, models
+    spec = rm.make_spec("cfg1")
+    sd = rm.init_state(spec, seed=91)
+    model, cfg = H.hip_model(spec, sd)
+    Hh = Ww = 400
+    K = np.array([[500.0, 0.0, Ww / 2], [0.0, 500.0, Hh / 2], [0.0, 0.0, 1.0]])
+    c2w = np.concatenate([np.eye(3), np.array([[0.05], [0.02], [0.1]])], axis=1)
+    batch = camera_utils.generate_ray_batch((np.linalg.inv(K)[None], c2w[None], None, None), 0, Ww, Hh, 0.0, 8.0, device="cuda")
+    batch = {k: batch[k] for k in ("origins", "directions", "viewdirs", "cam_dirs", "radii", "near", "far")}
+    n = Hh * Ww
+    g = torch.Generator().manual_seed(92)
+    rand_vec = torch.randn(n, 6, generator=g)
+    batch["rand_vec"] = rand_vec.reshape(Hh, Ww, 6).cuda()
+
+    class One:
+        num_processes, process_index, is_main_process = 1, 0, True
+    pick = torch.randperm(n, generator=g)[:2048]
+    flat = {k: v.reshape(n, -1)[pick.cuda()].cpu() for k, v in batch.items() if k != "rand_vec"}
+    noise = [rm.LevelNoise(rand_vec=rand_vec[pick, 3 * l:3 * l + 3]) for l in range(2)]
+    with torch.no_grad():
+        want, _ = rm.model_forward(spec, sd, flat, noise)
+    for mode in (1, 0):
+        model.nerf_mlp.mlp_mode = mode
+        out = models.render_image(model, One(), batch, False, 1.0, cfg, verbose=False)
+        assert out["rgb"].shape == (Hh, Ww, 3) and out["weights"].shape == (Hh, Ww, 64)
+        assert torch.isfinite(out["rgb"]).all()
+        got = out["rgb"].reshape(n, 3)[pick.cuda()].cpu()
+        assert H.maxdiff(got, want[-1]["rgb"]) <= H.RGB_TOL, mode
+        assert H.maxdiff(out["acc"].reshape(n)[pick.cuda()].cpu(), want[-1]["acc"]) <= 1e-4, mode
 
 
 def test_model_forward_empty_single_and_ragged_batches():
@@ -631,3 +729,60 @@ def test_resample_vs_oracle_at_the_size_limits(n_prev, S, dil, per_sample_jitter
     e_hip = (got.double() - truth).abs()
     assert (near | (e_hip <= 4 * e_ref + 1e-5)).all(), (float((got - want).abs()[~near].max()), float(e_hip.max()), float(e_ref.max()))
     assert float(e_hip.max()) <= 1.5 * float(e_ref.max()) + 2e-6
+
+
+# ------------------------------------------------------------------ (e) multi-rank render_image with a wrapped model
+DDP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import helpers as H
+from oracle import raymarch as rm
+from ucnerf_amd.internal import camera_utils, models
+rank, world = int(sys.argv[3]), 2
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+torch.cuda.set_device(0)                                  # both ranks share the box's one GPU
+spec = rm.make_spec("tiny")
+sd = rm.init_state(spec, seed=77)
+model, cfg = H.hip_model(spec, sd)
+Hh, Ww = 37, 53                                            # 1961 rays: odd -> the last shard is one row short
+K = np.array([[60.0, 0.0, Ww / 2], [0.0, 60.0, Hh / 2], [0.0, 0.0, 1.0]])
+c2w = np.concatenate([np.eye(3), np.array([[0.05], [0.02], [0.1]])], axis=1)
+batch = camera_utils.generate_ray_batch((np.linalg.inv(K)[None], c2w[None], None, None), 0, Ww, Hh, 0.0, 8.0, device="cuda")
+batch = {k: batch[k] for k in ("origins", "directions", "viewdirs", "cam_dirs", "radii", "near", "far")}
+batch["rand_vec"] = torch.randn(Hh, Ww, 6, generator=torch.Generator().manual_seed(5)).cuda()
+class Acc:
+    def __init__(s, n, r): s.num_processes, s.process_index, s.is_main_process = n, r, r == 0
+# what accelerator.prepare(model) hands to render_image at num_processes > 1 (train.py:95,330): a DDP wrapper
+wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+for rw in (False, True):
+    whole = models.render_image(model, Acc(1, 0), batch, False, 1.0, cfg, verbose=False, return_weights=rw)
+    got = models.render_image(wrapped, Acc(world, rank), batch, False, 1.0, cfg, verbose=False, return_weights=rw)
+    for k in ("rgb", "depth", "acc", "distance_mean", "distance_median") + (("weights", "coord") if rw else ()):
+        assert got[k].shape == whole[k].shape, (k, got[k].shape, whole[k].shape)
+        assert torch.equal(got[k], whole[k]), (rw, k, float((got[k] - whole[k]).abs().max()))
+    assert ("weights" in got) == rw          # the 27x payload travels only on request (INTEGRATION.md)
+    assert all(len(got[k]) == 2 for k in got if k.startswith("ray_"))
+assert wrapped.module.training               # models.py:1006: render_image leaves the model in train mode
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_render_image_two_ranks_with_a_ddp_wrapped_model(tmp_path):
+    """SURVEY 8(e) / reference train.py:95,330, render.py:119,146: render_image receives the accelerate-prepared
+    model, a DistributedDataParallel wrapper at num_processes > 1.  Two ranks (gloo, sharing this box's GPU) render
+    row shards of a ragged frame and exchange them with the one packed all-gather; every gathered buffer must equal
+    the single-rank frame bit for bit (a ray's result does not depend on the launch it rides in)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("OK" in o for o in outs)

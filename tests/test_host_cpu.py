@@ -123,3 +123,70 @@ def test_all_gather_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("OK" in o for o in outs)
+
+
+def test_unwrap_model_sees_through_ddp_style_wrappers():
+    """render_image is handed accelerate's prepared model (reference train.py:95,330): `.module` chains are unwrapped,
+    anything else is rejected with a clear message."""
+    from ucnerf_amd.internal import models
+
+    class Core(torch.nn.Module):
+        def _march(self):
+            return "marched"
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    core = Core()
+    assert models.unwrap_model(core) is core
+    assert models.unwrap_model(Wrap(Wrap(core))) is core
+    with pytest.raises(TypeError, match="expected a ucnerf_amd Model"):
+        models.unwrap_model(torch.nn.Linear(2, 2))
+
+
+def test_host_offsets_cache_lives_on_the_tensor():
+    """the host copy of `offsets` must not be keyed on the device address (a freed encoder's block is
+    handed to the next one by the caching allocator)."""
+    from ucnerf_amd.gridencoder import _backend
+    a = torch.tensor([0, 8, 24], dtype=torch.int32)
+    ha = _backend.host_offsets(a)
+    assert list(ha) == [0, 8, 24] and _backend.host_offsets(a) is ha          # cached on the object
+    b = torch.tensor([0, 16, 48], dtype=torch.int32)                         # another tensor never sees a's copy
+    assert list(_backend.host_offsets(b)) == [0, 16, 48]
+    a.copy_(torch.tensor([0, 32, 64], dtype=torch.int32))                    # in-place update invalidates
+    assert list(_backend.host_offsets(a)) == [0, 32, 64]
+
+
+def test_fields_survive_deepcopy_and_pickle():
+    """cached C descriptors (ctypes structs with raw pointers) must not travel with copy / pickle."""
+    import copy
+    import io
+    from ucnerf_amd.internal import configs, models
+    with models.bindings(NerfMLP=dict(grid_log2_hashmap_size=8, grid_disired_resolution=64),
+                         PropMLP=dict(grid_log2_hashmap_size=8)):
+        m = models.Model(config=configs.Config(), num_levels=2, num_prop_samples=8, num_nerf_samples=8)
+    m.nerf_mlp._fields[1] = ("key", object(), None)            # stand-in for a cached descriptor
+    m.nerf_mlp._grid_desc = object()
+    c = copy.deepcopy(m)
+    assert c.nerf_mlp._fields == {} and not hasattr(c.nerf_mlp, "_grid_desc")
+    buf = io.BytesIO()
+    m.nerf_mlp._fields[1] = ("key", ctypes.c_void_p(1), None)
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r.nerf_mlp._fields == {} and torch.equal(r.nerf_mlp.encoder.embeddings, m.nerf_mlp.encoder.embeddings)
+
+
+def test_instance_keeps_its_bound_configuration_after_the_binding_block():
+    """A field built under bindings(NerfMLP=dict(bottleneck_width=64, ...)) must describe itself as 64-wide for its
+    whole life (the C descriptor is filled from instance attributes per call), not fall back to the restored class
+    default -- found by the configs[0] test: a 64-wide field was packed as 256-wide."""
+    from ucnerf_amd.internal import configs, models
+    with models.bindings(NerfMLP=dict(bottleneck_width=64, net_width_viewdirs=64, grid_log2_hashmap_size=8,
+                                      grid_disired_resolution=64), PropMLP=dict(grid_log2_hashmap_size=8)):
+        m = models.Model(config=configs.Config(), num_levels=2, num_prop_samples=8, num_nerf_samples=8)
+    assert models.NerfMLP.bottleneck_width == 256                       # class default restored
+    assert (m.nerf_mlp.bottleneck_width, m.nerf_mlp.net_width_viewdirs) == (64, 64)
+    assert m.nerf_mlp.lin_second_stage_0.weight.shape == (64, 64 + 27)
+    assert m.prop_mlp_0.disable_rgb and not m.nerf_mlp.disable_rgb and m.num_nerf_samples == 8

@@ -81,6 +81,7 @@ def test_g6_alpha_and_composite():
 @pytest.mark.parametrize("name,kind,over", [
     ("model_tiny.npz", "tiny", {}),
     ("model_tinyR.npz", "tinyR", {}),
+    ("model_tiny64.npz", "tiny64", {}),
     ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
     ("model_train.npz", "tiny", {}),
 ])

@@ -373,3 +373,70 @@ def test_fused_heads_forward_kernel_matches_the_per_layer_path(monkeypatch, fiel
     for what, f, l, t in [("dfeat", f_gf, l_gf, t_gf)] + [(n, f_g[n], l_g[n], t_g[n]) for n in sorted(t_g)]:
         scale = max(1e-6, float(t.abs().max()))
         assert float((f - t).abs().max()) <= 1.5 * float((l - t).abs().max()) + 5e-3 * scale, what
+
+
+@pytest.mark.gpu
+def test_config2_bf16_training_step_end_to_end():
+    """BASELINE.json configs[2] as ONE integrated step at full size: config-B model (NeRF grid L16 / C2 / T = 2^19,
+    proposal L6, 64 + 128 samples), 8192 rays, Model.forward(rand=True) under bf16 autocast -> the losses of
+    train.py:173-216 with waymo defaults -> backward -> nan_to_num -> FusedAdam(lr 0.01, betas (0.9, 0.99), eps 1e-8).
+    The oracle cannot run at this size; the step is pinned by properties: (i) the bf16 loss is finite and equals the
+    loss of the fp32 graph on the same batch and random draws within bf16 rounding (the fp32 graph is the one pinned to
+    the reference's own step by test_hip_train_graph_matches_reference_step), (ii) every parameter of both fields gets a
+    finite, non-zero gradient, and the bf16 gradients point the way the fp32 ones do, (iii) three optimiser steps on the
+    same batch decrease the loss."""
+    import types
+    import bench
+    from ucnerf_amd.internal import train_utils as tu
+    dev = torch.device("cuda", 0)
+    model, _, _ = bench.build_model(dev)
+    model.train()
+    cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                                anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                                hash_decay_mults=0.1, disable_multiscale_loss=False)
+    n = 8192
+    rays = {k: v.to(dev) for k, v in rm.synthetic_rays(n, seed=5).items()}
+    g = torch.Generator(device=dev).manual_seed(6)
+    batch = {k: v[:, None, None, :] for k, v in rays.items()}
+    batch['rgb'] = torch.rand(n, 1, 1, 3, device=dev, generator=g)
+    batch['lossmult'] = torch.ones(n, 1, 1, 1, device=dev)
+    batch['rand_vec'] = torch.randn(n, 6, device=dev, generator=g)
+    batch['march_noise'] = [dict(jitter=torch.rand(n, 1, device=dev, generator=g), flip=torch.rand(n, S, device=dev, generator=g),
+                                 spin=torch.rand(n, S, device=dev, generator=g)) for S in (64, 128)]
+
+    def step(bf16):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16):
+            rend, hist = model(True, batch, 0.5, False, zero_glo=False)
+            terms = dict(data=tu.compute_data_loss(batch, rend, cfg)[0], inter=tu.anti_interlevel_loss(hist, cfg),
+                         dist=tu.distortion_loss(hist, cfg), decay=tu.hash_decay_loss(hist, cfg))
+            loss = sum(terms.values())
+        loss.backward()
+        return float(loss), {k: float(v) for k, v in terms.items()}, {n_: p.grad.float().clone() for n_, p in model.named_parameters()
+                                                                       if p.grad is not None}
+
+    l32, t32, g32 = step(False)
+    l16, t16, g16 = step(True)
+    assert np.isfinite(l16) and np.isfinite(l32)
+    # (i) bf16 GEMMs: 8 mantissa bits, averaged over 8192 rays x 3 channels
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32, t16, t32)
+    for k in t32:
+        assert abs(t16[k] - t32[k]) <= 3e-2 * abs(t32[k]) + 1e-6, (k, t16[k], t32[k])
+    # (ii) every trainable tensor of the two fields
+    want = {n_ for n_, p in model.named_parameters() if p.requires_grad}
+    assert set(g16) == want == set(g32), want ^ set(g16)
+    for n_, gr in g16.items():
+        assert torch.isfinite(gr).all() and float(gr.abs().max()) > 0, n_
+        cos = float((gr * g32[n_]).sum() / (gr.norm() * g32[n_].norm() + 1e-30))
+        assert cos >= 0.9, (n_, cos)
+    # (iii) optimiser
+    opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+    losses = []
+    for _ in range(4):
+        l, _, _ = step(True)
+        losses.append(l)
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.nan_to_num_()
+        opt.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

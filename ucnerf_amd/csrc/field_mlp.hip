@@ -258,9 +258,10 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
     a.feat = features; a.packed = f->packed;
     a.b_d0 = f->b_d0; a.b_d1 = f->b_d1; a.b_c0 = f->b_c0; a.b_c1 = f->b_c1; a.b_rgb = f->b_rgb;
     a.dir_bias = dir_bias; a.density = density_out; a.rgb = rgb_out; a.bott = bottleneck_out;
-    UCN_REQUIRE(!rays_fastest || B % samples_per_ray == 0, "field_mlp: B must be rays x samples_per_ray");
+    UCN_REQUIRE(!(rays_fastest & 1) || B % samples_per_ray == 0, "field_mlp: B must be rays x samples_per_ray");
     a.B = B; a.spr = samples_per_ray; a.C = f->level_dim; a.F = pl.F;
-    a.n_rays = B / samples_per_ray; a.rays_fastest = rays_fastest ? 1u : 0u;
+    a.n_rays = B / samples_per_ray; a.rays_fastest = (rays_fastest & 1) ? 1u : 0u;
+    a.small_ring = (rays_fastest & UCN_LAUNCH_CORESIDENT) ? 1u : 0u;
     a.n_chunks = pl.n_groups / kChunkGroups;
     a.p0 = pl.p0; a.pstream = pl.pstream; a.phead = pl.phead;
     a.density_bias = f->density_bias; a.rgb_premult = f->rgb_premultiplier; a.rgb_bias = f->rgb_bias;

@@ -2,6 +2,7 @@
 // mlp_mode 1): layout of ucn_field_t::packed, kernel arguments, small device helpers.
 #pragma once
 #include "mfma_chain.h"
+#include "mlp_ring.h"
 
 struct PackPlan {
     uint64_t p0, pstream, phead, pcomp, total;        // float offsets into ucn_field_t::packed
@@ -13,13 +14,13 @@ struct PackPlan {
 static inline uint32_t stream_groups_f32(uint32_t NTB, uint32_t NTW) {
     return NTB * 2 * 4 + NTW * NTB * 4 + NTW * (NTB * 4 + NTW * 4);
 }
-// split-f16 stream (field_mlp_h.hip): 2 groups of bias tiles + density head, first layer (2 out tiles x
-// kFirstSteps k-steps), the two composed 96-input layers (3 input tiles each), colour layer 1 from the
-// hidden layer, then 4 groups of rgb-head weights
+// split-f16 stream (field_mlp_h.hip), 4 groups per double step: first layer (kFirstSteps k-steps), composed layer 0
+// (NTW/2 output pairs x 3 input tiles x 2 k-steps), colour layer 1 (per output pair: the 3 composed input tiles,
+// then the NTW hidden tiles).  A side table of kSideGroups groups sits in front of it.
 constexpr uint32_t kFirstSteps = 4;                   // first layer: F <= 16*kFirstSteps inputs (zero padded)
 constexpr uint32_t kCompCols = 96;                    // composed layers: [64 hidden | 27 direction | bias | 0...]
 static inline uint32_t stream_groups_h(uint32_t NTW) {
-    return (2 + 2 * kFirstSteps * 2) + 2 * NTW * 3 * 4 + NTW * NTW * 4 + 4;
+    return 4 * (kFirstSteps + 3 * NTW + NTW * (3 + NTW));
 }
 
 static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
@@ -51,11 +52,11 @@ static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
         pl->NTB = f->n_bottleneck / 32;
         pl->NTW = f->n_width / 32;
         const uint32_t g0 = (stream_groups_f32(pl->NTB, pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
-        const uint32_t g1 = (stream_groups_h(pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
+        const uint32_t g1 = kSideGroups + (stream_groups_h(pl->NTW) + kRingChunk - 1) / kRingChunk * kRingChunk;
         pl->n_groups = f->mlp_mode == 1 ? g1 : g0;
         pl->pstream = o; o += (uint64_t)(g0 > g1 ? g0 : g1) * 256;
         pl->phead = o; o += (uint64_t)pl->NTW * 128;
-        pl->pcomp = o; o += 2ull * f->n_width * kCompCols;             // composed fp32 matrices (mode 1)
+        pl->pcomp = o; o += 2ull * f->n_width * kCompCols + 16;        // composed fp32 matrices + scale scratch (mode 1)
     }
     pl->total = o;
     return 0;
@@ -69,6 +70,7 @@ struct MlpArgs {
     float *density, *rgb, *bott;
     uint32_t B, spr, C, F, n_chunks;
     uint32_t n_rays, rays_fastest;   // rays_fastest: feature index b = s*n_rays + ray (else ray*spr + s)
+    uint32_t small_ring;             // mode 1: 64 KiB weight ring (co-resident launches)
     uint64_t p0, pstream, phead;
     float density_bias, rgb_premult, rgb_bias, rgb_padding;
 };

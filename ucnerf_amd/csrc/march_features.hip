@@ -543,13 +543,13 @@ static LevelGroups make_groups(const UcnLevels &lv, uint32_t levels_per_block) {
 }
 
 // layout: 0 = [L][N*S][C] with b = ray*S+s; 1 = [N*S][L*C]; 2 = [L][S*N][C] with b = s*N+ray
-template <uint32_t C>
-__global__ __launch_bounds__(256) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
+template <uint32_t C, uint32_t TPB>
+__global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
                                                         LevelGroups grp, int layout, float *__restrict__ features,
                                                         float *__restrict__ coord_out, float *__restrict__ tmean_out) {
     const size_t B = (size_t)N * S;
-    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t b = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (b >= B) return;
     // layout 2 ("rays fastest"): the 64 lanes of a wave are NEIGHBOURING RAYS at one sample index.
     // On the dense coarse levels neighbouring pixels read the same few lattice cells, which the TA
@@ -1060,6 +1060,8 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     UCN_REQUIRE(N == 0 || (sdist && near_ && far_ && origins && directions && basis && radii && features_out),
                 "march_features: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
+    const bool coresident = (layout & UCN_LAUNCH_CORESIDENT) != 0;
+    layout &= ~UCN_LAUNCH_CORESIDENT;
     UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
@@ -1067,15 +1069,26 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     const size_t B = (size_t)N * S;
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features: too many samples in one call (%zu)", B);
     const LevelGroups grp = make_groups(lv, levels_per_block);
-    const dim3 grid(ucn_div_up(B, 256), grp.n);
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     hipStream_t st = (hipStream_t)stream;
     // experiment knob (tools/feat_occupancy.py): unused dynamic LDS per workgroup caps the workgroups per CU
     static const size_t dummy_lds = getenv("UCN_FEAT_DUMMY_LDS") ? (size_t)atol(getenv("UCN_FEAT_DUMMY_LDS")) : 0;
-#define UCN_MF(CC)                                                                                              \
-    hipLaunchKernelGGL(k_march_features<CC>, grid, dim3(256), dummy_lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
-                       grp, layout, features_out, coord_out, tmean_out)
+    // co-resident shape: 512 threads = two waves per SIMD, 88 KiB of LDS reserved -> ONE such workgroup per CU, and
+    // room for one MLP workgroup (72 KiB, one 296-register wave per SIMD) beside it.  The kernel runs at 97 % of its
+    // full-occupancy rate with two waves per SIMD (profiles/r02*/occupancy.txt): it is bound by the L2 request rate.
+    const uint32_t tpb = coresident ? 512u : 256u;
+    const size_t lds = coresident ? 88u * 1024u : dummy_lds;
+    const dim3 grid(ucn_div_up(B, tpb), grp.n);
+#define UCN_MF(CC)                                                                                                        \
+    do {                                                                                                                  \
+        if (coresident)                                                                                                   \
+            hipLaunchKernelGGL((k_march_features<CC, 512>), grid, dim3(512), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
+                               grp, layout, features_out, coord_out, tmean_out);                                          \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_march_features<CC, 256>), grid, dim3(256), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
+                               grp, layout, features_out, coord_out, tmean_out);                                          \
+    } while (0)
     switch (lv.C) {
         case 1: UCN_MF(1); break;
         case 2: UCN_MF(2); break;

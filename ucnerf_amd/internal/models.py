@@ -27,6 +27,16 @@ from .sky import NeRF, render_rays  # noqa: F401  (names kept importable like up
 
 
 def set_kwargs(self, kwargs):
+    """Instance configuration = the class-level knobs AS THEY ARE NOW (gin bindings set class attributes,
+    configs/waymo.gin:10-20; `bindings()` below restores them when its block ends) overridden by the constructor's
+    keyword arguments.  Frozen on the instance: a field built as 64-wide must still describe itself as 64-wide after
+    the class default is back to 256 (the C descriptor is filled from these attributes on every call)."""
+    for klass in reversed(type(self).__mro__):
+        if klass in (nn.Module, object):
+            continue
+        for k, v in vars(klass).items():
+            if not k.startswith('_') and not callable(v) and not isinstance(v, (property, classmethod, staticmethod)):
+                object.__setattr__(self, k, v) if not isinstance(v, (torch.Tensor, nn.Module)) else None
     for k, v in kwargs.items():
         setattr(self, k, v)
 
@@ -440,6 +450,7 @@ class Model(nn.Module):
             # Two HIP streams: featurisation of pass i+1 (L2-request / VALU bound) runs beside the MLP of pass i
             # (MFMA bound) on a second feature buffer; the hardware splits the CUs between the two kernels.
             overlap = bool(self.overlap_streams) and N > chunk
+            co = _lib.LAUNCH_CORESIDENT if (overlap and not is_prop) else 0     # launch shapes that share a CU
             cur = torch.cuda.current_stream()
             feats = [feat]
             if overlap:
@@ -464,7 +475,7 @@ class Model(nn.Module):
                     ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
-                    float(self.std_scale), n, S, int(self.levels_per_block), 2 if self.rays_fastest else 0,
+                    float(self.std_scale), n, S, int(self.levels_per_block), (2 if self.rays_fastest else 0) | co,
                     fb.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, fstream.cuda_stream))
                 if prof is not None:
                     e1.record(fstream)
@@ -475,7 +486,7 @@ class Model(nn.Module):
                 if prof is not None:
                     m0.record(cur)
                 _lib.check(lib.ucn_field_mlp(
-                    ctypes.byref(desc), fb.data_ptr(), n * S, S, int(bool(self.rays_fastest)),
+                    ctypes.byref(desc), fb.data_ptr(), n * S, S, int(bool(self.rays_fastest)) | co,
                     None if is_prop else dirb[r0 * (dirb.numel() // N):].data_ptr(),
                     density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
                 if overlap:
