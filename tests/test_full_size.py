@@ -139,3 +139,27 @@ def test_featurisation_is_linear_with_closed_form_on_ones_and_exact_adjoint(scen
         b = float((gt[int(off[l]):int(off[l + 1])].double() * T2[int(off[l]):int(off[l + 1])].double()).sum())
         s = float((grad[l].double() * f2[l].double()).abs().sum())
         assert abs(a - b) <= 1e-5 * s, (l, a, b, s)
+
+
+@pytest.mark.gpu
+def test_coresident_launch_shapes_give_identical_pixels():
+    """Model.overlap_streams: featurisation of pass i + 1 on a second HIP stream beside the MLP of pass i, both in their
+    co-resident launch shapes (UCN_LAUNCH_CORESIDENT: 512-thread featurisation workgroups, 64 KiB weight ring).  A ray's
+    result must not depend on the launch it rides in: bit-identical frames."""
+    import bench
+    dev = torch.device("cuda", 0)
+    model, cfg, _ = bench.build_model(dev)
+    batch = bench.frame_rays(dev)
+    n = 3 * 4096 + 517                                        # several passes and a ragged last one
+    flat = {k: v.reshape(-1, v.shape[-1])[:n].contiguous() for k, v in batch.items()}
+    flat["rand_vec"] = torch.randn(n, 6, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    model.max_chunk_rays = 4096
+    out = {}
+    with torch.no_grad():
+        for ov in (False, True):
+            model.overlap_streams = ov
+            r, _ = model(False, flat, 1.0, True)
+            torch.cuda.synchronize()
+            out[ov] = {k: r[-1][k].clone() for k in ("rgb", "depth", "acc", "weights")}
+    for k in out[False]:
+        assert torch.equal(out[False][k], out[True][k]), k

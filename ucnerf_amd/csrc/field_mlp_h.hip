@@ -263,8 +263,16 @@ __device__ __forceinline__ void head_eighth(const f32x16 (&pair)[2], const float
     head_quarter<T0 + E / 4, E % 4>(pair[E / 4], side, h, s0, s1, s2);
 }
 
+#ifdef UCN_EXP_TIMING      // experiment builds: s_memtime stamps of workgroup 64's wave 0 into the (otherwise unused) bottleneck buffer
+#define UCN_STAMP(i) do { if (blockIdx.x == UCN_EXP_TIMING && threadIdx.x == 0) a.bott[i] = (float)(__builtin_readcyclecounter() - t_begin); } while (0)
+#else
+#define UCN_STAMP(i) do { } while (0)
+#endif
 template <int NTW, bool RGB, int CHUNK>
 __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
+#ifdef UCN_EXP_TIMING
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
     extern __shared__ __attribute__((aligned(16))) float s_lds[];   // [side table][ring]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -310,8 +318,9 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
             dma_group(a.packed + a.pstream + (size_t)(i * 4 + wave) * 256, lbase + (uint32_t)(i * 4 + wave) * 1024u, (uint32_t)lane * 16u);
     }
     rstatic_for<kLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
-    ring.drain();
-    __syncthreads();
+    UCN_STAMP(0);
+    ring.template boundary<0>();                    // side table + chunk 0 landed (the later chunks stay in flight)
+    UCN_STAMP(1);
     const float in_scale = side[129];
 
     // ---- density layer 0: F -> 64, ReLU (accumulators start from the bias tiles)
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
         rstatic_for<kKS>([&](auto s) { dstep<4 * s.value, NG>(acc0[0], acc0[1], fhi[s.value], flo[s.value], pipe, ring); });
         relu_tile(acc0[0]);
         relu_tile(acc0[1]);
+        UCN_STAMP(2);
     }
     // ---- raw density = row 0 of the second density layer, on the VALU (models.py:508,581): this lane holds
     //      32 of the 64 hidden units of its sample
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
             split_half<false>(acc0[1], s, in[1]);
             split_half<false>(ev, s, in[2]);
         }
+        UCN_STAMP(3);
         // ---- A: composed colour layer 0, pair by pair; pair p - 1 is ReLU'd and split under pair p's MFMAs
         HPair h1s[NTW];
         f32x16 acc[2][2];                                    // pair q of the whole program lives in acc[q % 2]
@@ -375,6 +386,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
                     dstep<G, NG>(acc[p % 2][0], acc[p % 2][1], in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], pipe, ring);
             });
         });
+        UCN_STAMP(4);
         // ---- B: colour layer 1, pair by pair: skip part (reads `in`), then the hidden part (reads h1s).  Under the skip
         //      part's MFMAs: the split of A's last pair (p = 0) or the rgb head of pair p - 1
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
                 else
                     dstep<G, NG>(acc[qp][0], acc[qp][1], in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], pipe, ring);
             });
+            UCN_STAMP(5 + 2 * p);
             rstatic_for<2 * NTW>([&](auto ic) {                                           // [it < NTW][s]
                 constexpr int i = ic.value, G = GB + p * PB + 24 + i * 4;
                 if constexpr (p > 0 && i < 2)
@@ -402,7 +415,9 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
                     dstep<G, NG>(acc[qp][0], acc[qp][1], h1s[i / 2].hi[i % 2], h1s[i / 2].lo[i % 2], pipe, ring);
             });
         });
+        UCN_STAMP(13);
         rstatic_for<8>([&](auto e) { head_eighth<2 * (NP - 1), e.value>(acc[(2 * NP - 1) % 2], side, h, s0, s1, s2); });
+        UCN_STAMP(14);
         // ---- rgb: sigmoid + padding (models.py:657-674)
         s0 += __shfl_xor(s0, 32, 64);
         s1 += __shfl_xor(s1, 32, 64);
@@ -470,7 +485,9 @@ int ucn_h_dir_enc(const ucn_field_t *f, const float *viewdirs, uint32_t N, float
 }
 
 int ucn_h_launch(const PackPlan &pl, const MlpArgs &a, dim3 grid, hipStream_t st) {
+#ifndef UCN_EXP_TIMING
     UCN_REQUIRE(a.bott == nullptr, "field_mlp: mlp_mode 1 composes the bottleneck away; request bottleneck_out with mlp_mode 0");
+#endif
     // a.small_ring: the 64 KiB ring (+ side table = 72 KiB), so that one 512-thread featurisation workgroup holding
     // 88 KiB can share the CU (DESIGN.md "Co-residency"); default: the 128 KiB ring
 #define UCN_MLP_H(NTW_, RGB_)                                                                                              \

@@ -52,7 +52,7 @@ static inline int make_plan(const ucn_field_t *f, PackPlan *pl) {
         pl->NTB = f->n_bottleneck / 32;
         pl->NTW = f->n_width / 32;
         const uint32_t g0 = (stream_groups_f32(pl->NTB, pl->NTW) + kChunkGroups - 1) / kChunkGroups * kChunkGroups;
-        const uint32_t g1 = kSideGroups + (stream_groups_h(pl->NTW) + kRingChunk - 1) / kRingChunk * kRingChunk;
+        const uint32_t g1 = kSideGroups + (stream_groups_h(pl->NTW) + kRingPad - 1) / kRingPad * kRingPad + kRingPad;   // + slack: the prologue's DMA may run past a short stream
         pl->n_groups = f->mlp_mode == 1 ? g1 : g0;
         pl->pstream = o; o += (uint64_t)(g0 > g1 ? g0 : g1) * 256;
         pl->phead = o; o += (uint64_t)pl->NTW * 128;

@@ -9,13 +9,12 @@
 //
 // Round 1's engine (mfma_chain_h.h: two 64 KiB buffers, the next buffer's DMA spread over the current one) waited
 // at every buffer boundary for DMA pieces issued a few hundred cycles earlier: the whole L2 -> LDS latency
-// (~1.3 us) stood in front of the MFMAs eight times per tile (~40 % of the kernel).  Here the DMA runs kLead = 2
-// whole chunks (64 groups = 16 double steps ~ 1.5 us of MFMA time) ahead of the reads:
-//   * chunk c lives in slot c % 4; while chunk c is being read, the pieces of chunk c + 2 are issued, one per four
-//     groups consumed (a burst of DMA instructions costs the issuing wave 100-185 cycles each);
-//   * at the first read of chunk c a wave waits until at most kPiecesPerChunk of its DMA instructions are
-//     outstanding (vmcnt counts in order: those are chunk c + 1's), then the workgroup barrier publishes chunk c;
-//   * the slot being refilled (chunk c + 2 -> slot of chunk c - 2) was last read a whole chunk ago: no read of it
+// (~1.3 us) stood in front of the MFMAs eight times per tile.  Here the DMA runs kLead whole chunks ahead of the reads:
+//   * chunk c lives in slot c % kRingSlots; while chunk c is being read, the pieces of chunk c + kLead are issued, one
+//     per four groups consumed (a burst of DMA instructions costs the issuing wave 100-185 cycles each);
+//   * at the first read of chunk c a wave waits until at most (kLead - 1) chunks' worth of its DMA instructions are
+//     outstanding (vmcnt counts in order: those are the later chunks'), then the workgroup barrier publishes chunk c;
+//   * the slot being refilled (chunk c + kLead -> slot of chunk c - 2) was last read a whole chunk ago: no read of it
 //     can still be in flight, which the two-buffer engine could not guarantee.
 // A small side table (bias tiles, VALU head weights, scale factors) is loaded once, in front of the ring.
 #pragma once
@@ -25,10 +24,15 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int kRingChunk = 32;                       // groups (KiB) per chunk of the default ring (the packed stream is padded to it)
-constexpr int kRingChunkSmall = 16;                  // ... of the 64 KiB ring used beside a co-resident featurisation workgroup
-constexpr int kRingSlots = 4;
-constexpr int kLead = 2;                             // the DMA runs this many chunks ahead of the reads
+constexpr int kRingChunk = 16;                       // groups (KiB) per chunk of the default ring
+constexpr int kRingChunkSmall = 8;                   // ... of the 64 KiB ring used beside a co-resident featurisation workgroup
+constexpr int kRingPad = 32;                         // the packed stream is padded to a multiple of this many groups
+constexpr int kRingSlots = 8;
+constexpr int kLead = 6;                             // the DMA runs this many chunks ahead of the reads: while chunk c is read
+//                                                      the pieces of chunk c + 6 are issued, so the LAST piece of a chunk has
+//                                                      5 chunks = 20 double steps (~1.6 us) to land; measured L2 -> LDS latency
+//                                                      ~1.3 us.  (kLead 2 of 4 x 32 KiB left the last piece one chunk = 0.64 us:
+//                                                      the boundaries of colour layer 1 ran at 420 cycles per double step)
 constexpr int kSideGroups = 8;                       // side table in front of the ring (8 KiB)
 constexpr int ring_lds_bytes(int chunk) { return (kSideGroups + kRingSlots * chunk) * 1024; }
 #ifdef UCN_EXP_PIPEDEPTH
@@ -85,6 +89,9 @@ __device__ __forceinline__ void split_half(const f32x16 &a, const int s, HPair &
 
 template <int N>
 __device__ __forceinline__ void ring_wait_lds() {     // lgkmcnt only
+#ifdef UCN_EXP_NOHINT
+    return;
+#endif
     static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
     __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
 }
@@ -171,7 +178,11 @@ __device__ __forceinline__ void pipe_fetch(OpPipe &p, RING &ring) {
     if constexpr (G >= 2 * kPipeDepth) return;
 #endif
     p.hi[(G / 2) % kPipeDepth] = ring.template group<G>();
+#ifdef UCN_EXP_HALFLDS
+    p.lo[(G / 2) % kPipeDepth] = p.hi[(G / 2) % kPipeDepth];
+#else
     p.lo[(G / 2) % kPipeDepth] = ring.template group<G + 1>();
+#endif
 }
 constexpr int rmin(int a, int b) { return a < b ? a : b; }
 // reads still in flight that are YOUNGER than the four operands of the double step at G, once everything below
@@ -255,7 +266,9 @@ __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, 
     if constexpr (G + 4 < NG)
         ring_wait_lds<rmin(15, younger_reads<G + 4, rmin(NG, G + 2 * kPipeDepth + 4)>() + EXTRA_LDS)>();
 #endif
+#ifndef UCN_EXP_NOSCHEDBAR
     __builtin_amdgcn_sched_barrier(0);   // keep each step's MFMAs and its requests together, in program order
+#endif
 }
 template <int G, int NG, class RING>
 __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, OpPipe &p, RING &ring) {
