@@ -37,23 +37,42 @@ PEAK_F16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 MAC_NERF_SPLIT = 64 * 64 + 96 * 256 + (256 + 96) * 256
 
 
-def frame_cameras():
-    """One pinhole camera with Waymo-like intrinsics: (pixtocams, camtoworlds, distortion, ndc) as the reference's
-    Dataset.cameras tuple (datasets.py:346-349; pixtocam = inv(K) in float64, datasets.py:855)."""
+def frame_cameras(n_cams=1, virtual=False):
+    """Pinhole cameras with Waymo-like intrinsics: (pixtocams, camtoworlds, distortion, ndc) as the reference's
+    Dataset.cameras tuple (datasets.py:346-349; pixtocam = inv(K) in float64, datasets.py:855).  Camera 0 is the
+    single-camera benchmark pose; the others fan out in yaw like a five-camera rig (front, +-50, +-100 degrees).
+    virtual=True perturbs every pose the way the reference builds its virtual cameras (datasets.py:983-1063: a small
+    rotation about each axis and a shift of a few percent of the scene radius)."""
     K = np.array([[FOCAL, 0.0, W_IMG / 2], [0.0, FOCAL, H_IMG / 2], [0.0, 0.0, 1.0]])
-    yaw = 0.3
-    R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
-    c2w = np.concatenate([R, np.array([[0.1], [-0.05], [0.2]])], axis=1)
-    return (np.linalg.inv(K)[None], c2w[None], None, None)
+    rig = [0.3, 0.3 + 0.87, 0.3 - 0.87, 0.3 + 1.75, 0.3 - 1.75, 0.3 + 2.6, 0.3 - 2.6, 0.3 + 3.1]
+    rng = np.random.default_rng(7)
+    c2ws = []
+    for i in range(n_cams):
+        yaw = rig[i % len(rig)] + 0.05 * (i // len(rig))
+        R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        t = np.array([0.1, -0.05, 0.2])
+        if virtual:
+            ax, ay, az = rng.uniform(-0.03, 0.03, 3)
+            Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+            Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+            Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+            R = Rz @ Ry @ Rx @ R
+            t = t + rng.uniform(-0.03, 0.03, 3)
+        c2ws.append(np.concatenate([R, t[:, None]], axis=1))
+    return (np.repeat(np.linalg.inv(K)[None], n_cams, 0), np.stack(c2ws), None, None)
 
 
-def frame_rays(device):
-    """Every pixel of the frame as the model's ray batch, generated ON the device by the path's own ray generator
-    (ucnerf_amd/internal/camera_utils.py -> ucn_generate_rays, bit-identical to the reference's
-    camera_utils.pixels_to_rays + datasets._make_ray_batch); outside the timed region, timed separately."""
+def frame_rays(device, n_cams=1, virtual=False):
+    """Every pixel of every camera as the model's ray batch ([n_cams * H, W, .]: the cameras stacked along the rows,
+    so that row-tile sharding hands whole-camera or partial-camera tiles to the ranks), generated ON the device by the
+    path's own ray generator (ucnerf_amd/internal/camera_utils.py -> ucn_generate_rays, bit-identical
+    to the reference's camera_utils.pixels_to_rays + datasets._make_ray_batch); outside the timed region, timed
+    separately."""
     from ucnerf_amd.internal import camera_utils
-    b = camera_utils.generate_ray_batch(frame_cameras(), 0, W_IMG, H_IMG, 0.0, 8.0, device=device)
-    return {k: b[k] for k in ("origins", "directions", "viewdirs", "cam_dirs", "radii", "near", "far", "cam_idx", "lossmult")}
+    cams = frame_cameras(n_cams, virtual)
+    keys = ("origins", "directions", "viewdirs", "cam_dirs", "radii", "near", "far", "cam_idx", "lossmult")
+    per = [camera_utils.generate_ray_batch(cams, i, W_IMG, H_IMG, 0.0, 8.0, device=device) for i in range(n_cams)]
+    return {k: torch.cat([b[k] for b in per], dim=0) for k in keys}
 
 
 def ray_generation_ms(device, steps=20):
@@ -151,28 +170,32 @@ class Ranks:
         self.num_processes, self.process_index, self.is_main_process = world, rank, rank == 0
 
 
-def build_model(device):
+def build_model(device, heads=False):
     """Random-init weights of the reference's architecture (module init laws of models.py:438-483),
     same seed on every rank; hash tables re-drawn ~U(-1,1) so density varies (the
-    reference's +-1e-4 table init makes the grid a no-op)."""
+    reference's +-1e-4 table init makes the grid a no-op).  heads=True: BASELINE configs[4] -- the sky NeRF layer
+    and the per-camera colour-correction head (210 training views) on top."""
     from ucnerf_amd.internal import configs, models
     torch.manual_seed(0)
-    cfg = configs.Config()
+    cfg = configs.Config(model_sky=True, brightness_correction=True, training_views=210) if heads else configs.Config()
     kw = dict(grid_level_dim=2, grid_log2_hashmap_size=19)
     with models.bindings(NerfMLP=dict(grid_disired_resolution=524288, **kw), PropMLP=dict(**kw)):
         model = models.Model(config=cfg, num_levels=2, num_prop_samples=S_PROP, num_nerf_samples=S_NERF)
     for mlp in (model.nerf_mlp, model.prop_mlp_0):
         mlp.encoder.embeddings.data.uniform_(-1, 1)
+    if heads:                                        # zero latent codes would make every camera's affine map the same
+        model.brightness_corr.latent_code.data.normal_(0, 0.1)
+        model.brightness_corr.sky_latent_code.data.normal_(0, 0.1)
     sd = {k: v.clone() for k, v in model.state_dict().items()}       # CPU copy for the CPU baseline
     return model.to(device).eval(), cfg, sd
 
 
-def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192):
+def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192, heads=False, eval_camidx=None):
     """The reference's path on the host cores: oracle/raymarch.py (== reference Python, bit-exact in
     the authoring container) + oracle/grid_oracle.c for the CUDA-only grid op, same rays / weights.
     This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check)."""
     from oracle import raymarch as rm
-    spec = rm.make_spec("B")
+    spec = rm.make_spec("B", model_sky=True, brightness_correction=True, training_views=210) if heads else rm.make_spec("B")
     # torch-CPU eager ops stop scaling (and regress) beyond a few dozen threads on these small tensors:
     # 256 threads measured 82 rays/s on the MI355X host; 32 is the better configuration for the baseline.
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -181,14 +204,14 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192
     noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3].cpu()) for l in range(2)]
     with torch.no_grad():
         rm.model_forward(spec, sd, {k: v[:256] for k, v in sub.items()},
-                         [rm.LevelNoise(rand_vec=n.rand_vec[:256]) for n in noise])           # warm-up
+                         [rm.LevelNoise(rand_vec=n.rand_vec[:256]) for n in noise], eval_camidx=eval_camidx)   # warm-up
         t0 = time.perf_counter()
         rgb = []
         for r0 in range(0, n_sample, per_call):          # the reference renders in chunks too (render_chunk_size)
             sl = slice(r0, r0 + per_call)
             rend, _ = rm.model_forward(spec, sd, {k: v[sl] for k, v in sub.items()},
-                                       [rm.LevelNoise(rand_vec=n.rand_vec[sl]) for n in noise])
-            rgb.append(rend[-1]["rgb"])
+                                       [rm.LevelNoise(rand_vec=n.rand_vec[sl]) for n in noise], eval_camidx=eval_camidx)
+            rgb.append(rend[-1]["rgb"].reshape(-1, 3))
         dt = time.perf_counter() - t0
     rgb = torch.cat(rgb)
     linf = float((rgb - gpu_rgb[idx].cpu()).abs().max())
@@ -277,7 +300,14 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="featurisation of pass i+1 beside the MLP of pass i (2 streams)")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cameras", type=int, default=1,
+                    help="cameras per frame: 5 = BASELINE configs[3] (full 5-camera Waymo frame, 12.29 M rays, row tiles over the ranks)")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="BASELINE configs[4]: sky layer + colour-correction head on, rays of VIRTUAL (perturbed) poses; "
+                         "implies --cameras 5 unless given")
     args = ap.parse_args()
+    if args.cfg5 and args.cameras == 1:
+        args.cameras = 5
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,7 +326,7 @@ def main():
     from ucnerf_amd.internal import models, dist as udist
     if args.mlp_mode is not None:
         models.MLP.mlp_mode = args.mlp_mode
-    model, cfg, sd = build_model(device)
+    model, cfg, sd = build_model(device, heads=args.cfg5)
     if args.levels_per_block:
         model.levels_per_block = args.levels_per_block
     if args.chunk:
@@ -305,15 +335,17 @@ def main():
         model.rays_fastest = False
     if args.overlap:
         model.overlap_streams = True
-    batch = frame_rays(device)
-    n_rays = H_IMG * W_IMG
+    batch = frame_rays(device, args.cameras, virtual=args.cfg5)
+    n_rays = args.cameras * H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)
     rand_vec = torch.randn(n_rays, 6, generator=g)                  # pinned cone-basis draws (render.py:140)
-    batch["rand_vec"] = rand_vec.reshape(H_IMG, W_IMG, 6).to(device)
+    batch["rand_vec"] = rand_vec.reshape(args.cameras * H_IMG, W_IMG, 6).to(device)
     acc = Ranks(world, rank)
+    # configs[4]: one colour-correction latent per frame, as render.py:146-147 / eval.py:140-141 pass it
+    eval_camidx = torch.tensor([7]) if args.cfg5 else 0
 
     def step():
-        return models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False)
+        return models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=eval_camidx)
 
     def fence():
         if world > 1:
@@ -376,13 +408,22 @@ def main():
             mlp["executed_frac"] = mlp["executed_mfma_tflops"] / PEAK_F16_MFMA_TF
         dominant, other = (gather, mlp) if feat_ms[1] >= mlp_ms[1] else (mlp, gather)
         total_ms = dt * 1e3 / args.steps
+        if args.cfg5:
+            workload = (f"BASELINE configs[4]: {args.cameras}-camera 1280x1920 frame ({n_rays:,} rays) of VIRTUAL (perturbed) poses, sky NeRF "
+                        "layer + per-camera colour-correction head (210 views) on, proposal 64 + NeRF 128 samples, NeRF grid L=16 C=2 "
+                        "T=2^19; dense layers on f16 MFMA with hi/lo operands and fp32 accumulation (fp32-class: >= the bf16 the config "
+                        "names), grid + compositing fp32")
+        elif args.cameras > 1:
+            workload = (f"BASELINE configs[3]: full {args.cameras}-camera 1280x1920 frame ({n_rays:,} rays), row tiles over the ranks, "
+                        "proposal 64 + NeRF 128 samples, NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render")
+        else:
+            workload = ("BASELINE configs[1]: one 1280x1920 frame (2,457,600 rays), proposal 64 + NeRF 128 samples, "
+                        "NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render, compute_extras=True")
         res = {
             "metric": "rays/sec (fwd render), 1280x1920 @ 64+128 samples", "value": n_rays * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: one 1280x1920 frame (2,457,600 rays), proposal 64 + NeRF 128 samples, "
-                                   "NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render, "
-                                   "compute_extras=True", "rays_per_step": n_rays,
+            "config": {"workload": workload, "rays_per_step": n_rays, "cameras": args.cameras,
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
                        "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
                        "mlp_mode": {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]},
@@ -392,8 +433,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
-            res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3))
-        if world == 1 and not args.no_train:
+            res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=args.cfg5,
+                                               eval_camidx=eval_camidx if args.cfg5 else None,
+                                               n_sample=8192 if args.cfg5 else 32768)
+        if world == 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             res["sky_layer"] = sky_layer_ms(flat, device)

@@ -268,7 +268,7 @@ __device__ __forceinline__ void head_eighth(const f32x16 (&pair)[2], const float
 #else
 #define UCN_STAMP(i) do { } while (0)
 #endif
-template <int NTW, bool RGB, int CHUNK>
+template <int NTW, bool RGB, int CHUNK, int STAGE>
 __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
 #ifdef UCN_EXP_TIMING
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     }
     // ---- weight DMA: side table, then the first kLead chunks of the ring
     const float *side = s_lds;
-    Ring<NG, CHUNK> ring(a.packed + a.pstream + kSideGroups * 256, s_lds + kSideGroups * 256, lane, wave);
+    Ring<NG, CHUNK, 4, kRingSlots, kLead, STAGE> ring(a.packed + a.pstream + kSideGroups * 256, s_lds + kSideGroups * 256, lane, wave);
     {
         const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_lds;
 #pragma unroll
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     }
     rstatic_for<kLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
     UCN_STAMP(0);
+    if constexpr (STAGE > 0) ring.drain();          // the side table came by DMA
     ring.template boundary<0>();                    // side table + chunk 0 landed (the later chunks stay in flight)
     UCN_STAMP(1);
     const float in_scale = side[129];
@@ -435,6 +436,157 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     }
 }
 
+
+// ---- 8-wave variant: 512-thread workgroups, TWO waves per SIMD, 256 samples per pass over the weight stream.
+// k_field_mlp_h above streams 464 KiB of weights through LDS per 128 samples, and the LDS-DMA path lands ~10 B per
+// clock and CU (25 GB/s: cycle stamps in profiles/r02*/mlp_timeline.txt; the same figure as MI355X_MICROARCH.md's
+// "ldsdma-fill" row): 4 KiB per double step = 393 cycles where the six MFMAs need 192 -- the kernel sits at that floor.
+// Here eight waves share the stream, so the DMA moves half the bytes per sample and the two waves of a SIMD take turns
+// on the matrix pipe: one computes while the other splits / runs the rgb head / waits for LDS.  That needs <= 256
+// registers per lane: ONE accumulator pair, nothing in MFMA shadows (the partner wave is the shadow), a short
+// operand pipe.
+template <int NTW, int CHUNK, int SLOTS, int LEAD, int DEPTH>
+__global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
+#ifdef UCN_EXP_TIMING
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#define UCN_STAMP8(i) do { if (blockIdx.x == UCN_EXP_TIMING && (threadIdx.x & 255) == 0) a.bott[(threadIdx.x >> 8) * 32 + (i)] = (float)(__builtin_readcyclecounter() - t_begin); } while (0)
+#else
+#define UCN_STAMP8(i) do { } while (0)
+#endif
+    extern __shared__ __attribute__((aligned(16))) float s_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t b0 = (blockIdx.x * 8u + wave) * 32u;
+    const bool live = b0 + j < a.B;
+    const uint32_t b = live ? b0 + j : a.B - 1;
+    const uint32_t oi = out_index(a, b);
+    constexpr int NP = NTW / 2;
+    constexpr int GA = 4 * kKS;
+    constexpr int GB = GA + NP * 24;
+    constexpr int PB = 24 + NTW * 8;
+    constexpr int NG = GB + NP * PB;
+
+    float fv[kKS][8];
+#pragma unroll
+    for (int s = 0; s < kKS; s++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t k = 16u * s + 8u * h + e, l = k / a.C, c = k - l * a.C;
+            fv[s][e] = k < a.F ? a.feat[((size_t)l * a.B + b) * a.C + c] : 0.0f;
+        }
+    f32x16 ev;
+    {
+        const float4 *ep = reinterpret_cast<const float4 *>(a.dir_bias + (size_t)ray_index(a, b) * 32 + 4 * h);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 v = ep[2 * r4];
+            ev[4 * r4 + 0] = v.x; ev[4 * r4 + 1] = v.y; ev[4 * r4 + 2] = v.z; ev[4 * r4 + 3] = v.w;
+        }
+    }
+    const float *side = s_lds;
+    Ring<NG, CHUNK, 8, SLOTS, LEAD> ring(a.packed + a.pstream + kSideGroups * 256, s_lds + kSideGroups * 256, lane, wave);
+    {
+        const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_lds;
+        static_assert(kSideGroups == 8, "one side-table group per wave");
+        dma_group(a.packed + a.pstream + (size_t)wave * 256, lbase + (uint32_t)wave * 1024u, (uint32_t)lane * 16u);
+    }
+    UCN_STAMP8(0);
+    rstatic_for<LEAD>([&](auto c) { ring.template issue_chunk<c.value>(); });
+    UCN_STAMP8(1);
+    ring.template boundary<0>();
+    UCN_STAMP8(2);
+    const float in_scale = side[129];
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const float4 *pb = reinterpret_cast<const float4 *>(side + t * 32 + h * 16);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 v = pb[r4];
+            acc[t][4 * r4 + 0] = v.x; acc[t][4 * r4 + 1] = v.y; acc[t][4 * r4 + 2] = v.z; acc[t][4 * r4 + 3] = v.w;
+        }
+    }
+    OpPipeD<DEPTH> pipe;
+    pipe_prime_d<NG>(pipe, ring);
+    {
+        h8 fhi[kKS], flo[kKS];
+#pragma unroll
+        for (int s = 0; s < kKS; s++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) fv[s][e] *= in_scale;
+            rsplit8(fv[s], fhi[s], flo[s]);
+        }
+        rstatic_for<kKS>([&](auto s) { dstep_d<4 * s.value, NG>(acc[0], acc[1], fhi[s.value], flo[s.value], pipe, ring); });
+    }
+    {
+        const float *pd = side + 64;
+        float part = 0.0f;
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) part = fmaf(relu_bits(acc[it][r]), pd[(it * 16 + r) * 2 + h], part);
+        const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
+        if (live && h == 0) a.density[oi] = softplus(raw + a.density_bias);
+    }
+    UCN_STAMP8(3);
+    HPair in[3];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        split_half<true>(acc[0], s, in[0]);
+        split_half<true>(acc[1], s, in[1]);
+        split_half<false>(ev, s, in[2]);
+    }
+    UCN_STAMP8(4);
+    HPair h1s[NTW];
+    rstatic_for<NP>([&](auto pc) {
+        constexpr int p = pc.value;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][r] = acc[1][r] = 0.0f;
+        rstatic_for<6>([&](auto ic) {
+            constexpr int i = ic.value, G = GA + (p * 6 + i) * 4;
+            dstep_d<G, NG>(acc[0], acc[1], in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], pipe, ring);
+        });
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            split_half<true>(acc[0], s, h1s[2 * p]);
+            split_half<true>(acc[1], s, h1s[2 * p + 1]);
+        }
+    });
+    UCN_STAMP8(5);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    rstatic_for<NP>([&](auto pc) {
+        constexpr int p = pc.value;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][r] = acc[1][r] = 0.0f;
+        rstatic_for<6>([&](auto ic) {
+            constexpr int i = ic.value, G = GB + p * PB + i * 4;
+            dstep_d<G, NG>(acc[0], acc[1], in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], pipe, ring);
+        });
+        rstatic_for<2 * NTW>([&](auto ic) {
+            constexpr int i = ic.value, G = GB + p * PB + 24 + i * 4;
+            dstep_d<G, NG>(acc[0], acc[1], h1s[i / 2].hi[i % 2], h1s[i / 2].lo[i % 2], pipe, ring);
+        });
+        UCN_STAMP8(6 + 2 * p);
+        rstatic_for<8>([&](auto e) { head_eighth<2 * p, e.value>(acc, side, h, s0, s1, s2); });
+        UCN_STAMP8(7 + 2 * p);
+    });
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (live && h == 0) {
+        const float pad = a.rgb_padding;
+        const float v[3] = {s0 + a.b_rgb[0], s1 + a.b_rgb[1], s2 + a.b_rgb[2]};
+        const size_t o = (size_t)oi * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float sg = 1.0f / (1.0f + expf(-(a.rgb_premult * v[c] + a.rgb_bias)));
+            a.rgb[o + c] = sg * (1.0f + 2.0f * pad) - pad;
+        }
+    }
+}
+
 }  // namespace
 
 int ucn_h_pack(const ucn_field_t *f, const PackPlan &pl, hipStream_t st) {
@@ -493,10 +645,29 @@ int ucn_h_launch(const PackPlan &pl, const MlpArgs &a, dim3 grid, hipStream_t st
 #define UCN_MLP_H(NTW_, RGB_)                                                                                              \
     do {                                                                                                                   \
         if (a.small_ring)                                                                                                  \
-            hipLaunchKernelGGL((k_field_mlp_h<NTW_, RGB_, kRingChunkSmall>), grid, dim3(256), ring_lds_bytes(kRingChunkSmall), st, a); \
+            hipLaunchKernelGGL((k_field_mlp_h<NTW_, RGB_, kRingChunkSmall, 0>), grid, dim3(256), ring_lds_bytes(kRingChunkSmall), st, a); \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_field_mlp_h<NTW_, RGB_, kRingChunk>), grid, dim3(256), ring_lds_bytes(kRingChunk), st, a); \
+            hipLaunchKernelGGL((k_field_mlp_h<NTW_, RGB_, kRingChunk, UCN_MLP4_STAGE>), grid, dim3(256), ring_lds_bytes(kRingChunk), st, a); \
     } while (0)
+#ifndef UCN_MLP8_DEPTH
+#define UCN_MLP8_DEPTH 2
+#endif
+#ifndef UCN_MLP4_STAGE
+#define UCN_MLP4_STAGE 0
+#endif
+    static const bool eight = getenv("UCN_MLP_WAVES") ? atoi(getenv("UCN_MLP_WAVES")) == 8 : true;   // experiment knob
+    if (a.rgb != nullptr && pl.NTW == 8 && !a.small_ring && eight) {
+        const dim3 grid8(ucn_div_up(a.B, 256));
+#ifndef UCN_MLP8_CHUNK
+#define UCN_MLP8_CHUNK 32
+#define UCN_MLP8_SLOTS 4
+#define UCN_MLP8_LEAD 2
+#endif
+        hipLaunchKernelGGL((k_field_mlp_h8<8, UCN_MLP8_CHUNK, UCN_MLP8_SLOTS, UCN_MLP8_LEAD, UCN_MLP8_DEPTH>), grid8, dim3(512),
+                           (kSideGroups + UCN_MLP8_SLOTS * UCN_MLP8_CHUNK) * 1024, st, a);
+        UCN_LAUNCH_CHECK("field_mlp (split-f16, 8 waves)");
+        return 0;
+    }
     if (a.rgb == nullptr) {
         if (pl.NTW == 8) UCN_MLP_H(8, false);
         else UCN_MLP_H(2, false);

@@ -23,6 +23,7 @@
 #include "mfma_chain.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kRingChunk = 16;                       // groups (KiB) per chunk of the default ring
 constexpr int kRingChunkSmall = 8;                   // ... of the 64 KiB ring used beside a co-resident featurisation workgroup
@@ -102,10 +103,20 @@ __device__ __forceinline__ void ring_wait_vm() {      // vmcnt only (6 bits: [3:
 }
 
 // NGROUPS = length of the stream in groups (a multiple of 4; the packed stream is padded to whole chunks)
-template <int NGROUPS, int CHUNK>
+// STAGE = 0: the stream reaches LDS by LDS-DMA (global_load_lds).  STAGE = n > 0: by plain 16-byte global loads into n
+// staging registers per lane and ds_write_b128 n pieces later.  Measured on this kernel (profiles/r02*/mlp_timeline.txt):
+// the DMA path lands ~10 B per clock and CU and stretches the latency of every ds_read issued meanwhile; with one
+// wave per SIMD the registers for the classic path are there.
+template <int NGROUPS, int CHUNK, int NWAVES = 4, int SLOTS = kRingSlots, int LEAD = kLead, int STAGE = 0>
 struct Ring {
+    static constexpr int kStage = STAGE;
+    static constexpr int kExtraLds = STAGE > 0 ? 1 : 0;      // LDS operations per double step besides the operand reads
+    f4v stage[STAGE > 0 ? STAGE : 1];
+    float *ldsw[3];         // staged mode: this lane's WRITE pointers (ring base + wave KiB + lane * 16 + 0 / 60 / 120 KiB)
     static constexpr int kChunk = CHUNK;
-    static constexpr int kPiecesPerChunk = CHUNK / 4;      // DMA instructions per wave and chunk
+    static constexpr int kSlots = SLOTS, kLeadChunks = LEAD;
+    static constexpr int kWaves = NWAVES;                    // waves of the workgroup that share the stream
+    static constexpr int kPiecesPerChunk = CHUNK / NWAVES;  // DMA instructions per wave and chunk
     static constexpr int kChunks = (NGROUPS + CHUNK - 1) / CHUNK;
     const float *wsrc;      // this wave's share of the stream in global memory (group 0 + wave)
     const float *ldsb[3];   // this lane's read pointers at ring base + 0 / 64 / 128 KiB: ds_read takes a 16-bit immediate
@@ -124,6 +135,9 @@ struct Ring {
             uint32_t a = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)lds_ring + (uint32_t)lane_ * 16u + (uint32_t)k * 61440u;
             asm volatile("" : "+v"(a));                    // opaque: keeps the three bases apart
             ldsb[k] = (const float *)(__attribute__((address_space(3))) const float *)(size_t)a;
+            uint32_t w = a + (uint32_t)wave * 1024u;
+            asm volatile("" : "+v"(w));
+            ldsw[k] = (float *)(__attribute__((address_space(3))) float *)(size_t)w;
         }
     }
 
@@ -133,11 +147,25 @@ struct Ring {
     template <int C, int I>
     __device__ __forceinline__ void piece() {
 #ifdef UCN_EXP_NODMA          // experiment builds (tools/build_variant.sh): timing only, results are garbage
-        if constexpr (C >= kLead) return;
+        if constexpr (C >= LEAD) return;
 #endif
+        if constexpr (STAGE > 0) {
+            constexpr int q = C * kPiecesPerChunk + I;               // this wave's piece counter
+            if constexpr (q >= STAGE) {                              // piece q - STAGE has had STAGE double steps to arrive
+                constexpr int qw = q - STAGE, Cw = qw / kPiecesPerChunk, Iw = qw % kPiecesPerChunk;
+                if constexpr (Cw < kChunks) {
+                    constexpr int off = ((Cw % SLOTS) * CHUNK + Iw * NWAVES) * 1024;
+                    constexpr int k = off / 61440, rem = off % 61440;
+                    *reinterpret_cast<f4v *>(ldsw[k] + rem / 4) = stage[qw % STAGE];
+                }
+            }
+            if constexpr (C < kChunks)
+                stage[q % STAGE] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(wsrc + (size_t)(C * CHUNK + I * NWAVES) * 256) + lane);
+            return;
+        }
         if constexpr (C < kChunks) {
-            const float *g = wsrc + (size_t)(C * CHUNK + I * 4) * 256;
-            const uint32_t l = wlds + (uint32_t)(((C % kRingSlots) * CHUNK + I * 4) * 1024);
+            const float *g = wsrc + (size_t)(C * CHUNK + I * NWAVES) * 256;
+            const uint32_t l = wlds + (uint32_t)(((C % SLOTS) * CHUNK + I * NWAVES) * 1024);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(l), "v"(voff), "s"(g) : "memory");
         }
     }
@@ -150,18 +178,25 @@ struct Ring {
     __device__ __forceinline__ void boundary() {
         // DMA instructions of this wave that may still be in flight: those of the chunks behind C that have been
         // issued so far, i.e. chunks C+1 .. C+kLead-1 (chunk C+kLead is issued while C is read)
-        constexpr int later = (C + kLead - 1 < kChunks ? kLead - 1 : (kChunks - 1 - C > 0 ? kChunks - 1 - C : 0));
+        constexpr int later = (C + LEAD - 1 < kChunks ? LEAD - 1 : (kChunks - 1 - C > 0 ? kChunks - 1 - C : 0));
 #ifdef UCN_EXP_NOBAR
         return;
 #endif
-        ring_wait_vm<later * kPiecesPerChunk>();
+        if constexpr (STAGE > 0) {
+            // this wave's ds_writes of chunk C were issued >= (LEAD - 1) * kPiecesPerChunk - STAGE double steps ago and
+            // every double step waits its LDS queue down to a handful of operations: they are done.  (Prologue: drain.)
+            static_assert(STAGE <= (LEAD - 1) * kPiecesPerChunk, "staged pieces would be written after they are needed");
+            if constexpr (C == 0) ring_wait_lds<0>();
+        } else {
+            ring_wait_vm<later * kPiecesPerChunk>();
+        }
         // bare barrier: __syncthreads() adds a fence whose lgkmcnt(0) would drain the operand pipe.  LDS is coherent
         // within the CU and every wave has waited for its own DMA; the slot being refilled was last read a chunk ago.
         asm volatile("s_barrier" ::: "memory");
     }
     template <int G>
     __device__ __forceinline__ h8 group() const {
-        constexpr int off = (((G / CHUNK) % kRingSlots) * CHUNK + G % CHUNK) * 1024;   // bytes from the ring base
+        constexpr int off = (((G / CHUNK) % SLOTS) * CHUNK + G % CHUNK) * 1024;   // bytes from the ring base
         constexpr int k = off / 61440, rem = off % 61440;                                             // rem + 15 < 65536
         return __builtin_bit_cast(h8, *reinterpret_cast<const float4 *>(ldsb[k] + rem / 4));
     }
@@ -173,7 +208,7 @@ template <int G, class RING>
 __device__ __forceinline__ void pipe_fetch(OpPipe &p, RING &ring) {
     constexpr int CH = RING::kChunk;
     if constexpr (G % CH == 0 && G / CH >= 1) ring.template boundary<G / CH>();   // chunk 0: prologue
-    if constexpr (G % 4 == 0) ring.template piece<G / CH + kLead, (G % CH) / 4>();
+    if constexpr (G % RING::kWaves == 0) ring.template piece<G / CH + RING::kLeadChunks, (G % CH) / RING::kWaves>();
 #ifdef UCN_EXP_NOLDS
     if constexpr (G >= 2 * kPipeDepth) return;
 #endif
@@ -264,7 +299,7 @@ __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, 
     }
 #endif
     if constexpr (G + 4 < NG)
-        ring_wait_lds<rmin(15, younger_reads<G + 4, rmin(NG, G + 2 * kPipeDepth + 4)>() + EXTRA_LDS)>();
+        ring_wait_lds<rmin(15, younger_reads<G + 4, rmin(NG, G + 2 * kPipeDepth + 4)>() + EXTRA_LDS + RING::kExtraLds)>();
 #endif
 #ifndef UCN_EXP_NOSCHEDBAR
     __builtin_amdgcn_sched_barrier(0);   // keep each step's MFMAs and its requests together, in program order
@@ -273,4 +308,40 @@ __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, 
 template <int G, int NG, class RING>
 __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, OpPipe &p, RING &ring) {
     dstep<G, NG, 0, 0>(acc0, acc1, bhi, blo, p, ring, [] {});
+}
+
+// ---- plain double step with a DEPTH-pair operand pipe (the 8-wave kernel: two waves per SIMD hide each other's
+//      LDS latency and VALU phases, so the pipe can be short and nothing rides in MFMA shadows)
+template <int DEPTH>
+struct OpPipeD {
+    h8 hi[DEPTH], lo[DEPTH];
+};
+template <int G, int DEPTH, class RING>
+__device__ __forceinline__ void pipe_fetch_d(OpPipeD<DEPTH> &p, RING &ring) {
+    constexpr int CH = RING::kChunk;
+    if constexpr (G % CH == 0 && G / CH >= 1) ring.template boundary<G / CH>();
+    if constexpr (G % RING::kWaves == 0) ring.template piece<G / CH + RING::kLeadChunks, (G % CH) / RING::kWaves>();
+    p.hi[(G / 2) % DEPTH] = ring.template group<G>();
+    p.lo[(G / 2) % DEPTH] = ring.template group<G + 1>();
+}
+template <int NG, int DEPTH, class RING>
+__device__ __forceinline__ void pipe_prime_d(OpPipeD<DEPTH> &p, RING &ring) {
+    rstatic_for<DEPTH>([&](auto d) {
+        if constexpr (2 * d.value < NG) pipe_fetch_d<2 * d.value>(p, ring);
+    });
+    ring_wait_lds<younger_reads<0, rmin(NG, 2 * DEPTH)>()>();
+}
+template <int G, int NG, int DEPTH, class RING>
+__device__ __forceinline__ void dstep_d(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, OpPipeD<DEPTH> &p, RING &ring) {
+    constexpr int s0 = (G / 2) % DEPTH, s1 = (G / 2 + 1) % DEPTH;
+    acc0 = mfma_h(p.hi[s0], bhi, acc0);
+    acc1 = mfma_h(p.hi[s1], bhi, acc1);
+    acc0 = mfma_h(p.hi[s0], blo, acc0);
+    acc1 = mfma_h(p.hi[s1], blo, acc1);
+    acc0 = mfma_h(p.lo[s0], bhi, acc0);
+    acc1 = mfma_h(p.lo[s1], bhi, acc1);
+    if constexpr (G + 2 * DEPTH < NG) pipe_fetch_d<G + 2 * DEPTH>(p, ring);
+    if constexpr (G + 2 * DEPTH + 2 < NG) pipe_fetch_d<G + 2 * DEPTH + 2>(p, ring);
+    if constexpr (G + 4 < NG) ring_wait_lds<younger_reads<G + 4, rmin(NG, G + 2 * DEPTH + 4)>()>();
+    __builtin_amdgcn_sched_barrier(0);
 }

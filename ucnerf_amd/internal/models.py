@@ -539,7 +539,7 @@ class Model(nn.Module):
             if eval_camidx is None:
                 cam_idx = batch['cam_idx'].reshape(N, -1)[:, 0]
             else:
-                cam_idx = eval_camidx.to(dev).reshape(-1)[:1]
+                cam_idx = torch.as_tensor(eval_camidx).to(dev).reshape(-1)[:1]
             A, A_sky, row_of = self.brightness_corr.affines(cam_idx)
             last_w = renderings[-1]['weights'].reshape(N, -1)          # loop-leaked `rendering` (Appendix C.3)
             for r in renderings:

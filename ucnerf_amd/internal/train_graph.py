@@ -626,7 +626,7 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         for r in renderings:
             r['sky_rgbs'] = sky
     if getattr(cfg, 'brightness_correction', False):
-        idx = batch['cam_idx'].reshape(N, -1)[:, 0] if eval_camidx is None else eval_camidx.to(dev).reshape(-1)[:1].repeat(N)
+        idx = batch['cam_idx'].reshape(N, -1)[:, 0] if eval_camidx is None else torch.as_tensor(eval_camidx).to(dev).reshape(-1)[:1].repeat(N)
         A = brightness_forward(model.brightness_corr, idx)
         A_sky = brightness_forward(model.brightness_corr, idx, 'sky_latent_code') if with_sky else None
         last_w = renderings[-1]['weights'].reshape(N, -1)
