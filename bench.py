@@ -300,6 +300,13 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="featurisation of pass i+1 beside the MLP of pass i (2 streams)")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--compact", type=float, default=0.0,
+                    help="Model.compact_min_weight: early-termination sample compaction (colour layers only for samples whose "
+                         "compositing weight reaches this value; 4e-8 bounds the pixel error by 5e-6).  Default off: on the random-init "
+                         "field AND on a fitted one every sample carries weight (tools/fit_scene.py, DESIGN.md)")
+    ap.add_argument("--fit-steps", type=int, default=0,
+                    help="fit the model to tools/fit_scene.py's analytic scene for this many steps before the timed region "
+                         "(a trained-like field instead of BASELINE's random-init one; reported in config.field)")
     ap.add_argument("--cameras", type=int, default=1,
                     help="cameras per frame: 5 = BASELINE configs[3] (full 5-camera Waymo frame, 12.29 M rays, row tiles over the ranks)")
     ap.add_argument("--cfg5", action="store_true",
@@ -335,6 +342,14 @@ def main():
         model.rays_fastest = False
     if args.overlap:
         model.overlap_streams = True
+    if args.fit_steps:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import fit_scene
+        for mlp in (model.nerf_mlp, model.prop_mlp_0):
+            mlp.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+        fit_scene.fit(model, device, args.fit_steps)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.compact_min_weight = args.compact
     batch = frame_rays(device, args.cameras, virtual=args.cfg5)
     n_rays = args.cameras * H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)
@@ -424,6 +439,9 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "rays_per_step": n_rays, "cameras": args.cameras,
+                       "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
+                                 else "random-init weights, tables U(-1,1) (BASELINE configs)"),
+                       "compact_min_weight": args.compact,
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
                        "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
                        "mlp_mode": {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]},

@@ -183,6 +183,22 @@ int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32_t B, uint3
                   float *density_out /*[B]*/, float *rgb_out /*[B,3]|NULL*/, float *bottleneck_out,
                   ucn_stream_t stream);
 
+/* Early-termination sample compaction (BASELINE.json north_star).  The reference runs the colour MLP on every sample
+ * (models.py:221-243 -> :581-674) although a sample whose compositing weight w = alpha * T (render.py:155-174) is ~0
+ * cannot change the pixel.  The path here, per pass of the last level: density head first (ucn_field_mlp with
+ * rgb_out = NULL), weights by ucn_composite (rgbs = NULL), then
+ *   ucn_compact_alive: idx_out[0 .. *count) = the FEATURE indices b (b = s * n_rays + ray when rays_fastest, else
+ *     ray * S + s) of the samples with weight >= min_weight, in unspecified order (per wave: ballot + popcount, one
+ *     atomic per wave for the base); *count is reset by the call (stream-ordered);
+ *   ucn_field_rgb_compacted: the colour layers of those samples only, rgb_out[ray][s] written for them (the caller
+ *     zero-fills the rest).  Workgroups beyond *count exit at once: no host read-back.
+ * Pixel error <= S * min_weight * max|rgb| by construction. */
+int ucn_compact_alive(const float *weights /*[N,S]*/, uint32_t N, uint32_t S, int rays_fastest, float min_weight,
+                      uint32_t *idx_out /*[N*S]*/, uint32_t *count /*[1]*/, ucn_stream_t stream);
+int ucn_field_rgb_compacted(const ucn_field_t *f, const float *features, uint32_t B, uint32_t samples_per_ray,
+                            int rays_fastest, const float *dir_bias, const uint32_t *idx, const uint32_t *count,
+                            float *rgb_out /*[B,3]*/, ucn_stream_t stream);
+
 /* ref: render.py:155-174 compute_alpha_weights + :177-244 volumetric_rendering +
  * stepfun.py:329-339 weighted_percentile.  rgbs NULL = PropMLP zeros (models.py:584-585).
  * out_main [N,5] = r,g,b,depth,acc ; out_extras [N,4] = distance_mean, p5, median, p95 (or NULL). */

@@ -244,6 +244,9 @@ extern "C" int ucn_field_dir_bias(const ucn_field_t *f, const float *viewdirs, u
     return 0;
 }
 
+// set (and cleared) by ucn_field_rgb_compacted around its call of ucn_field_mlp on the same host thread
+static thread_local const uint32_t *g_mlp_idx = nullptr, *g_mlp_count = nullptr;
+
 extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32_t B, uint32_t samples_per_ray,
                              int rays_fastest, const float *dir_bias, float *density_out, float *rgb_out,
                              float *bottleneck_out, ucn_stream_t stream) {
@@ -262,6 +265,7 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
     a.B = B; a.spr = samples_per_ray; a.C = f->level_dim; a.F = pl.F;
     a.n_rays = B / samples_per_ray; a.rays_fastest = (rays_fastest & 1) ? 1u : 0u;
     a.small_ring = (rays_fastest & UCN_LAUNCH_CORESIDENT) ? 1u : 0u;
+    a.idx = g_mlp_idx; a.count = g_mlp_count;
     a.n_chunks = pl.n_groups / kChunkGroups;
     a.p0 = pl.p0; a.pstream = pl.pstream; a.phead = pl.phead;
     a.density_bias = f->density_bias; a.rgb_premult = f->rgb_premultiplier; a.rgb_bias = f->rgb_bias;
@@ -275,4 +279,16 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
     else hipLaunchKernelGGL((k_field_mlp<2, 2>), grid, dim3(256), lds, st, a);
     UCN_LAUNCH_CHECK("field_mlp");
     return 0;
+}
+
+extern "C" int ucn_field_rgb_compacted(const ucn_field_t *f, const float *features, uint32_t B, uint32_t samples_per_ray,
+                                       int rays_fastest, const float *dir_bias, const uint32_t *idx, const uint32_t *count,
+                                       float *rgb_out, ucn_stream_t stream) {
+    UCN_REQUIRE(f && f->mlp_mode == 1 && f->n_bottleneck != 1, "field_rgb_compacted: needs a colour field in mlp_mode 1");
+    UCN_REQUIRE(B == 0 || (idx && count && rgb_out), "field_rgb_compacted: null pointer argument");
+    g_mlp_idx = idx; g_mlp_count = count;
+    // density_out is not written in this mode; any non-null pointer satisfies the common argument checks
+    const int rc = ucn_field_mlp(f, features, B, samples_per_ray, rays_fastest, dir_bias, rgb_out, rgb_out, nullptr, stream);
+    g_mlp_idx = g_mlp_count = nullptr;
+    return rc;
 }

@@ -280,8 +280,14 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     // every wave runs the whole program (workgroup-wide barriers); waves past the end of the batch
     // compute on a clamped sample and store nothing
     const uint32_t b0 = (blockIdx.x * 4u + wave) * 32u;
-    const bool live = b0 + j < a.B;
-    const uint32_t b = live ? b0 + j : a.B - 1;
+    bool live = b0 + j < a.B;
+    uint32_t b = live ? b0 + j : a.B - 1;
+    if (a.idx) {                                         // compacted colour pass: slot -> sample through the alive list
+        const uint32_t cnt = *a.count;
+        if (blockIdx.x * 128u >= cnt) return;            // workgroup-uniform, before any barrier or DMA
+        live = b0 + j < cnt;
+        b = a.idx[live ? b0 + j : cnt - 1];
+    }
     const uint32_t oi = out_index(a, b);                 // position in the [ray][sample]-ordered outputs
 
     constexpr int NP = NTW / 2;                          // output pairs of a hidden layer
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) part = fmaf(acc0[it][r], pd[(it * 16 + r) * 2 + h], part);
         const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
-        if (live && h == 0) a.density[oi] = softplus(raw + a.density_bias);
+        if (live && h == 0 && a.idx == nullptr) a.density[oi] = softplus(raw + a.density_bias);
     }
     if constexpr (RGB) {
         HPair in[3];                                         // h0 (2 tiles) and the direction tile
@@ -458,8 +464,14 @@ __global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const uint32_t b0 = (blockIdx.x * 8u + wave) * 32u;
-    const bool live = b0 + j < a.B;
-    const uint32_t b = live ? b0 + j : a.B - 1;
+    bool live = b0 + j < a.B;
+    uint32_t b = live ? b0 + j : a.B - 1;
+    if (a.idx) {                                         // compacted colour pass (see k_field_mlp_h)
+        const uint32_t cnt = *a.count;
+        if (blockIdx.x * 256u >= cnt) return;
+        live = b0 + j < cnt;
+        b = a.idx[live ? b0 + j : cnt - 1];
+    }
     const uint32_t oi = out_index(a, b);
     constexpr int NP = NTW / 2;
     constexpr int GA = 4 * kKS;
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) part = fmaf(relu_bits(acc[it][r]), pd[(it * 16 + r) * 2 + h], part);
         const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
-        if (live && h == 0) a.density[oi] = softplus(raw + a.density_bias);
+        if (live && h == 0 && a.idx == nullptr) a.density[oi] = softplus(raw + a.density_bias);
     }
     UCN_STAMP8(3);
     HPair in[3];

@@ -71,6 +71,7 @@ struct MlpArgs {
     uint32_t B, spr, C, F, n_chunks;
     uint32_t n_rays, rays_fastest;   // rays_fastest: feature index b = s*n_rays + ray (else ray*spr + s)
     uint32_t small_ring;             // mode 1: 64 KiB weight ring (co-resident launches)
+    const uint32_t *idx, *count;     // compacted colour pass: tile slot i evaluates sample idx[i], i < *count (else NULL)
     uint64_t p0, pstream, phead;
     float density_bias, rgb_premult, rgb_bias, rgb_padding;
 };

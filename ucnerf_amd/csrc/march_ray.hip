@@ -528,6 +528,41 @@ extern "C" int ucn_composite(const float *density, const float *rgbs, const floa
     return 0;
 }
 
+namespace {
+// alive list of a pass: thread = feature index b; lanes of a wave are neighbouring rays at one sample (rays_fastest)
+// or consecutive samples of a ray.  Ballot + popcount give the rank inside the wave, one atomic per wave the base.
+__global__ __launch_bounds__(256) void k_compact_alive(const float *__restrict__ weights, uint32_t N, uint32_t S, int rays_fastest,
+                                                       float min_weight, uint32_t *__restrict__ idx, uint32_t *__restrict__ count) {
+    const uint32_t B = N * S;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    bool alive = false;
+    if (b < B) {
+        const uint32_t ray = rays_fastest ? b % N : b / S, s = rays_fastest ? b / N : b % S;
+        alive = weights[(size_t)ray * S + s] >= min_weight;          // NaN weights are not alive
+    }
+    const unsigned long long m = __ballot(alive);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (alive) idx[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+__global__ void k_zero_u32(uint32_t *p) { *p = 0u; }
+}  // namespace
+
+extern "C" int ucn_compact_alive(const float *weights, uint32_t N, uint32_t S, int rays_fastest, float min_weight,
+                                 uint32_t *idx_out, uint32_t *count, ucn_stream_t stream) {
+    UCN_REQUIRE(count && (N == 0 || (weights && idx_out)), "compact_alive: null pointer argument");
+    UCN_REQUIRE((uint64_t)N * S <= 0xFFFFFF00ull, "compact_alive: too many samples in one call");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(1), 0, st, count);
+    if (N)
+        hipLaunchKernelGGL(k_compact_alive, dim3(ucn_div_up((uint64_t)N * S, 256)), dim3(256), 0, st, weights, N, S, rays_fastest,
+                           min_weight, idx_out, count);
+    UCN_LAUNCH_CHECK("compact_alive");
+    return 0;
+}
+
 extern "C" int ucn_composite_backward(const float *density, const float *rgbs, const float *sdist, const float *near_,
                                       const float *far_, const float *directions, float bg_intensity, int opaque_background,
                                       uint32_t N, uint32_t S, const float *g_weights, const float *g_main,

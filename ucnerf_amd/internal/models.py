@@ -303,6 +303,13 @@ class PropMLP(MLP):
 
 class Model(nn.Module):
     """ref models.py:31-365."""
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ('_side_stream', '_prof', '_alive_idx', '_alive_cnt', '_alive_stats'):
+            state.pop(k, None)
+        return state
+
     num_prop_samples: int = 64
     num_nerf_samples: int = 32
     num_levels: int = 3
@@ -334,6 +341,12 @@ class Model(nn.Module):
     overlap_streams: bool = False        # featurisation of pass i+1 beside the MLP of pass i on a second HIP stream:
     #                                      measured +1 % only (both kernels want every CU), so off by default
     rays_fastest: bool = True            # wave lanes = neighbouring rays at one sample index (L1/L2 locality)
+    compact_min_weight: float = 0.0      # > 0: early-termination sample compaction at the last level of inference marches
+    #                                      that return no per-sample history (render_image): density head first, then the
+    #                                      colour layers only for samples whose compositing weight alpha * T reaches this
+    #                                      value (pixel error <= num_nerf_samples * compact_min_weight).  The reference
+    #                                      evaluates every sample (models.py:221-243).  0 = off: on a field whose samples all
+    #                                      carry weight (random initialisation) the extra density pass is pure overhead
 
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -485,10 +498,33 @@ class Model(nn.Module):
                     cur.wait_event(ready)
                 if prof is not None:
                     m0.record(cur)
-                _lib.check(lib.ucn_field_mlp(
-                    ctypes.byref(desc), fb.data_ptr(), n * S, S, int(bool(self.rays_fastest)) | co,
-                    None if is_prop else dirb[r0 * (dirb.numel() // N):].data_ptr(),
-                    density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
+                compact = (not is_prop) and (not want_history) and self.compact_min_weight > 0 and mlp.mlp_mode == 1
+                if compact:
+                    # density head -> weights of this pass's rays -> alive list -> colour layers of the alive samples
+                    rf = int(bool(self.rays_fastest))
+                    _lib.check(lib.ucn_field_mlp(ctypes.byref(desc), fb.data_ptr(), n * S, S, rf, None, density[sl].data_ptr(),
+                                                 None, None, st))
+                    _lib.check(lib.ucn_composite(density[sl].data_ptr(), None, sdist[sl].data_ptr(), near[sl].data_ptr(),
+                                                 far[sl].data_ptr(), d[sl].data_ptr(), float(self.bg_intensity_range[0]),
+                                                 int(bool(self.opaque_background)), n, S, weights[sl].data_ptr(), main[sl].data_ptr(),
+                                                 None, st))
+                    if getattr(self, '_alive_idx', None) is None or self._alive_idx.numel() < n * S or self._alive_idx.device != dev:
+                        self._alive_idx = torch.empty(max(n, nc) * S, dtype=torch.int32, device=dev)
+                        self._alive_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+                    _lib.check(lib.ucn_compact_alive(weights[sl].data_ptr(), n, S, rf, float(self.compact_min_weight),
+                                                     self._alive_idx.data_ptr(), self._alive_cnt.data_ptr(), st))
+                    rgbs[sl].zero_()
+                    _lib.check(lib.ucn_field_rgb_compacted(ctypes.byref(desc), fb.data_ptr(), n * S, S, rf,
+                                                           dirb[r0 * (dirb.numel() // N):].data_ptr(), self._alive_idx.data_ptr(),
+                                                           self._alive_cnt.data_ptr(), rgbs[sl].data_ptr(), st))
+                    stats = getattr(self, '_alive_stats', None)
+                    if stats is not None:                              # diagnostics (tools/alive_fraction.py): forces a sync
+                        stats.append((int(self._alive_cnt.item()), n * S))
+                else:
+                    _lib.check(lib.ucn_field_mlp(
+                        ctypes.byref(desc), fb.data_ptr(), n * S, S, int(bool(self.rays_fastest)) | co,
+                        None if is_prop else dirb[r0 * (dirb.numel() // N):].data_ptr(),
+                        density[sl].data_ptr(), None if is_prop else rgbs[sl].data_ptr(), None, st))
                 if overlap:
                     mlp_done[i_pass % 2] = torch.cuda.Event()
                     mlp_done[i_pass % 2].record(cur)
