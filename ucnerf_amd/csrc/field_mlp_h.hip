@@ -263,6 +263,21 @@ __device__ __forceinline__ void head_eighth(const f32x16 (&pair)[2], const float
     head_quarter<T0 + E / 4, E % 4>(pair[E / 4], side, h, s0, s1, s2);
 }
 
+#ifdef UCN_EXP_STOP        // experiment builds: leave the kernel after a phase (timing by difference; results are garbage)
+#define UCN_STOP_AT(k, accpair)                                                                       \
+    do {                                                                                              \
+        if constexpr (UCN_EXP_STOP == (k)) {                                                          \
+            float keep = 0.0f;                                                                        \
+            for (int r = 0; r < 16; r++) keep += accpair[0][r] + accpair[1][r];                       \
+            if (live && h == 0) a.rgb[(size_t)oi * 3] = keep;                                         \
+            ring.drain();                                                                             \
+            __syncthreads();                                                                          \
+            return;                                                                                   \
+        }                                                                                             \
+    } while (0)
+#else
+#define UCN_STOP_AT(k, accpair) do { } while (0)
+#endif
 #ifdef UCN_EXP_TIMING      // experiment builds: s_memtime stamps of workgroup 64's wave 0 into the (otherwise unused) bottleneck buffer
 #define UCN_STAMP(i) do { if (blockIdx.x == UCN_EXP_TIMING && threadIdx.x == 0) a.bott[i] = (float)(__builtin_readcyclecounter() - t_begin); } while (0)
 #else
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
         relu_tile(acc0[1]);
         UCN_STAMP(2);
     }
+    if constexpr (RGB) UCN_STOP_AT(1, acc0);
     // ---- raw density = row 0 of the second density layer, on the VALU (models.py:508,581): this lane holds
     //      32 of the 64 hidden units of its sample
     {
@@ -393,6 +409,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
                     dstep<G, NG>(acc[p % 2][0], acc[p % 2][1], in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], pipe, ring);
             });
         });
+        UCN_STOP_AT(2, acc[(NP - 1) % 2]);
         UCN_STAMP(4);
         // ---- B: colour layer 1, pair by pair: skip part (reads `in`), then the hidden part (reads h1s).  Under the skip
         //      part's MFMAs: the split of A's last pair (p = 0) or the rgb head of pair p - 1
@@ -421,6 +438,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
                 else
                     dstep<G, NG>(acc[qp][0], acc[qp][1], h1s[i / 2].hi[i % 2], h1s[i / 2].lo[i % 2], pipe, ring);
             });
+            UCN_STOP_AT(3 + p, acc[qp]);
         });
         UCN_STAMP(13);
         rstatic_for<8>([&](auto e) { head_eighth<2 * (NP - 1), e.value>(acc[(2 * NP - 1) % 2], side, h, s0, s1, s2); });
@@ -451,8 +469,8 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
 // on the matrix pipe: one computes while the other splits / runs the rgb head / waits for LDS.  That needs <= 256
 // registers per lane: ONE accumulator pair, nothing in MFMA shadows (the partner wave is the shadow), a short
 // operand pipe.
-template <int NTW, int CHUNK, int SLOTS, int LEAD, int DEPTH>
-__global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
+template <int NTW, int NWAVES, int CHUNK, int SLOTS, int LEAD, int DEPTH>
+__global__ __launch_bounds__(NWAVES * 64, 2) void k_field_mlp_h8(MlpArgs a) {
 #ifdef UCN_EXP_TIMING
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #define UCN_STAMP8(i) do { if (blockIdx.x == UCN_EXP_TIMING && (threadIdx.x & 255) == 0) a.bott[(threadIdx.x >> 8) * 32 + (i)] = (float)(__builtin_readcyclecounter() - t_begin); } while (0)
@@ -463,12 +481,12 @@ __global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t b0 = (blockIdx.x * 8u + wave) * 32u;
+    const uint32_t b0 = (blockIdx.x * NWAVES + wave) * 32u;
     bool live = b0 + j < a.B;
     uint32_t b = live ? b0 + j : a.B - 1;
     if (a.idx) {                                         // compacted colour pass (see k_field_mlp_h)
         const uint32_t cnt = *a.count;
-        if (blockIdx.x * 256u >= cnt) return;
+        if (blockIdx.x * (NWAVES * 32u) >= cnt) return;
         live = b0 + j < cnt;
         b = a.idx[live ? b0 + j : cnt - 1];
     }
@@ -497,11 +515,12 @@ __global__ __launch_bounds__(512) void k_field_mlp_h8(MlpArgs a) {
         }
     }
     const float *side = s_lds;
-    Ring<NG, CHUNK, 8, SLOTS, LEAD> ring(a.packed + a.pstream + kSideGroups * 256, s_lds + kSideGroups * 256, lane, wave);
+    Ring<NG, CHUNK, NWAVES, SLOTS, LEAD> ring(a.packed + a.pstream + kSideGroups * 256, s_lds + kSideGroups * 256, lane, wave);
     {
         const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_lds;
-        static_assert(kSideGroups == 8, "one side-table group per wave");
-        dma_group(a.packed + a.pstream + (size_t)wave * 256, lbase + (uint32_t)wave * 1024u, (uint32_t)lane * 16u);
+#pragma unroll
+        for (int i = 0; i < kSideGroups / NWAVES; i++)
+            dma_group(a.packed + a.pstream + (size_t)(i * NWAVES + wave) * 256, lbase + (uint32_t)(i * NWAVES + wave) * 1024u, (uint32_t)lane * 16u);
     }
     UCN_STAMP8(0);
     rstatic_for<LEAD>([&](auto c) { ring.template issue_chunk<c.value>(); });
@@ -667,17 +686,33 @@ int ucn_h_launch(const PackPlan &pl, const MlpArgs &a, dim3 grid, hipStream_t st
 #ifndef UCN_MLP4_STAGE
 #define UCN_MLP4_STAGE 0
 #endif
-    static const bool eight = getenv("UCN_MLP_WAVES") ? atoi(getenv("UCN_MLP_WAVES")) == 8 : true;   // experiment knob
-    if (a.rgb != nullptr && pl.NTW == 8 && !a.small_ring && eight) {
-        const dim3 grid8(ucn_div_up(a.B, 256));
 #ifndef UCN_MLP8_CHUNK
 #define UCN_MLP8_CHUNK 32
 #define UCN_MLP8_SLOTS 4
 #define UCN_MLP8_LEAD 2
 #endif
-        hipLaunchKernelGGL((k_field_mlp_h8<8, UCN_MLP8_CHUNK, UCN_MLP8_SLOTS, UCN_MLP8_LEAD, UCN_MLP8_DEPTH>), grid8, dim3(512),
+#ifndef UCN_MLP2_CHUNK          // 64 KiB ring of the two-workgroups-per-CU kernel
+#define UCN_MLP2_CHUNK 16
+#define UCN_MLP2_SLOTS 4
+#define UCN_MLP2_LEAD 2
+#endif
+    // default for the 256-wide colour field: 4-wave workgroups of <= 256 registers, TWO per CU (72 KiB of LDS each), so
+    // every SIMD holds two waves of DIFFERENT workgroups: one wave's MFMAs run while the other splits, reads LDS, issues
+    // DMA or sits in its prologue.  Within one wave nothing overlaps an MFMA (tools/mfma_valu_bench.hip: 33 cycles per MFMA
+    // alone, 33 + 2.6 per VALU instruction behind it), and the two waves of ONE workgroup move in lockstep between the
+    // ring's barriers.  UCN_MLP_WAVES = 8 / 1: the 8-wave and the one-workgroup-per-CU kernels (experiments).
+    static const int waves = getenv("UCN_MLP_WAVES") ? atoi(getenv("UCN_MLP_WAVES")) : 4;
+    if (a.rgb != nullptr && pl.NTW == 8 && !a.small_ring && waves == 8) {
+        const dim3 grid8(ucn_div_up(a.B, 256));
+        hipLaunchKernelGGL((k_field_mlp_h8<8, 8, UCN_MLP8_CHUNK, UCN_MLP8_SLOTS, UCN_MLP8_LEAD, UCN_MLP8_DEPTH>), grid8, dim3(512),
                            (kSideGroups + UCN_MLP8_SLOTS * UCN_MLP8_CHUNK) * 1024, st, a);
         UCN_LAUNCH_CHECK("field_mlp (split-f16, 8 waves)");
+        return 0;
+    }
+    if (a.rgb != nullptr && pl.NTW == 8 && !a.small_ring && waves == 4) {
+        hipLaunchKernelGGL((k_field_mlp_h8<8, 4, UCN_MLP2_CHUNK, UCN_MLP2_SLOTS, UCN_MLP2_LEAD, UCN_MLP8_DEPTH>), grid, dim3(256),
+                           (kSideGroups + UCN_MLP2_SLOTS * UCN_MLP2_CHUNK) * 1024, st, a);
+        UCN_LAUNCH_CHECK("field_mlp (split-f16, 2 workgroups per CU)");
         return 0;
     }
     if (a.rgb == nullptr) {
