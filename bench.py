@@ -395,10 +395,10 @@ def main():
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         gather["frac"] = gather["achieved"] / gather["peak"]
         # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
-        # same command (profiles/r01j_chunk/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
+        # same command (profiles/r02b/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
         # when this run's launches have the size those passes measured
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_chunk", "traffic.json")))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02b", "traffic.json")))
             if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5:
                 gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
                 gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
@@ -411,11 +411,13 @@ def main():
         # mode 1: v_mfma_f32_32x32x16_f16 (2500 TF); every fp32 product costs three f16 MFMA products
         # (hi*hi + hi*lo + lo*hi) while the composed layers need 0.52x the reference's MACs -- executed_mfma_tflops
         # is what the matrix cores actually ran.
-        mlp = dict(bound="mfma", kernel=("k_field_mlp_h<8>" if split else "k_field_mlp<8,8>") + " (NeRF level)",
+        mlp = dict(bound="mfma", kernel=("k_field_mlp_h8<8,4,...> (two 4-wave workgroups per CU)" if split else "k_field_mlp<8,8>") + " (NeRF level)",
                    achieved=rays_seen[1] * FLOP_NERF_RAY / (mlp_ms[1] * 1e-3) / 1e12,
                    peak=PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF, unit="TFLOP/s",
                    avg_launch_ms=mlp_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         mlp["frac"] = mlp["achieved"] / mlp["peak"]
+        mlp["issue_model_note"] = ("a gfx950 SIMD does not overlap VALU with MFMA (tools/mfma_valu_bench.hip): the kernel's 2170 VALU "
+                                   "instructions per 696 MFMAs put its ceiling at ~0.79 of the MFMA peak before any memory wait")
         mlp["peak_note"] = ("dense f16 MFMA peak; fp32-class products = 3 f16 MFMAs each, composed layers = 0.52x MACs" if split
                             else "fp32-input MFMA peak (= fp32 vector rate on CDNA4)")
         if split:

