@@ -223,14 +223,14 @@ constexpr int rmin(int a, int b) { return a < b ? a : b; }
 // reads still in flight that are YOUNGER than the four operands of the double step at G, once everything below
 // `fetched` (group index, exclusive) has been requested
 template <int G, int FETCHED>
-constexpr int younger_reads() { return FETCHED - (G + 4) > 0 ? FETCHED - (G + 4) : 0; }
+constexpr int ring_younger() { return FETCHED - (G + 4) > 0 ? FETCHED - (G + 4) : 0; }
 
 template <int NG, class RING>
 __device__ __forceinline__ void pipe_prime(OpPipe &p, RING &ring) {
     rstatic_for<kPipeDepth>([&](auto d) {
         if constexpr (2 * d.value < NG) pipe_fetch<2 * d.value>(p, ring);
     });
-    ring_wait_lds<younger_reads<0, rmin(NG, 2 * kPipeDepth)>()>();
+    ring_wait_lds<ring_younger<0, rmin(NG, 2 * kPipeDepth)>()>();
 }
 
 // One double step: two OUTPUT tiles (A pairs G and G+2) against the same 16 k's of the input,
@@ -276,7 +276,7 @@ __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, 
     // registers to the reads issued above, and a ds_read cannot issue while an MFMA in flight still reads its target
     asm volatile("" ::"v"(p.hi[s0]), "v"(p.hi[s1]), "v"(p.lo[s0]), "v"(p.lo[s1]));
     if constexpr (G + 4 < NG)
-        ring_wait_lds<rmin(15, younger_reads<G + 4, rmin(NG, G >= 4 ? GF + 4 : 2 * kPipeDepth)>() + EXTRA_LDS)>();
+        ring_wait_lds<rmin(15, ring_younger<G + 4, rmin(NG, G >= 4 ? GF + 4 : 2 * kPipeDepth)>() + EXTRA_LDS)>();
 #else
 #ifdef UCN_EXP_NOSHADOW
     if constexpr (false) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void dstep(f32x16 &acc0, f32x16 &acc1, const h8 bhi, 
     }
 #endif
     if constexpr (G + 4 < NG)
-        ring_wait_lds<rmin(15, younger_reads<G + 4, rmin(NG, G + 2 * kPipeDepth + 4)>() + EXTRA_LDS + RING::kExtraLds)>();
+        ring_wait_lds<rmin(15, ring_younger<G + 4, rmin(NG, G + 2 * kPipeDepth + 4)>() + EXTRA_LDS + RING::kExtraLds)>();
 #endif
 #ifndef UCN_EXP_NOSCHEDBAR
     __builtin_amdgcn_sched_barrier(0);   // keep each step's MFMAs and its requests together, in program order
@@ -329,7 +329,7 @@ __device__ __forceinline__ void pipe_prime_d(OpPipeD<DEPTH> &p, RING &ring) {
     rstatic_for<DEPTH>([&](auto d) {
         if constexpr (2 * d.value < NG) pipe_fetch_d<2 * d.value>(p, ring);
     });
-    ring_wait_lds<younger_reads<0, rmin(NG, 2 * DEPTH)>()>();
+    ring_wait_lds<ring_younger<0, rmin(NG, 2 * DEPTH)>()>();
 }
 template <int G, int NG, int DEPTH, class RING>
 __device__ __forceinline__ void dstep_d(f32x16 &acc0, f32x16 &acc1, const h8 bhi, const h8 blo, OpPipeD<DEPTH> &p, RING &ring) {
@@ -342,6 +342,6 @@ __device__ __forceinline__ void dstep_d(f32x16 &acc0, f32x16 &acc1, const h8 bhi
     acc1 = mfma_h(p.lo[s1], bhi, acc1);
     if constexpr (G + 2 * DEPTH < NG) pipe_fetch_d<G + 2 * DEPTH>(p, ring);
     if constexpr (G + 2 * DEPTH + 2 < NG) pipe_fetch_d<G + 2 * DEPTH + 2>(p, ring);
-    if constexpr (G + 4 < NG) ring_wait_lds<younger_reads<G + 4, rmin(NG, G + 2 * DEPTH + 4)>()>();
+    if constexpr (G + 4 < NG) ring_wait_lds<ring_younger<G + 4, rmin(NG, G + 2 * DEPTH + 4)>()>();
     __builtin_amdgcn_sched_barrier(0);
 }

@@ -4,12 +4,15 @@
 // :743-820 (NeRF, D=8, W=256, skips=[4], multires_view=4) of /root/reference/nerf/internal/models.py.
 // 562,688 MAC per sample x 120 samples: the largest FLOP term of the path when model_sky is on.
 //
-// It runs on the split-f16 MFMA engine (mfma_chain_h.h: fp32-class products as 3 f16 MFMAs, fp32
-// accumulation), as ONE software-pipelined sequence of "pair chains": a wave owns 32 samples; a pair
-// chain produces two 32-neuron output tiles of a layer from the layer's input tiles (16 or 18 double
-// steps of six MFMAs), and carries in the MFMA shadow of its first four double steps the ReLU + hi/lo
-// split of the PREVIOUS pair's accumulators into the other activation buffer (XA <-> XB ping-pong), so
-// the matrix pipe never waits for an activation pass.  Weights stream L2 -> LDS once per workgroup.
+// It runs on the split-f16 MFMA engine (mlp_ring.h: fp32-class products as 3 f16 MFMAs, fp32
+// accumulation), as ONE sequence of "pair chains": a wave owns 32 samples; a pair chain produces two
+// 32-neuron output tiles of a layer from the layer's input tiles (16 or 18 double steps of six MFMAs);
+// the ReLU + hi/lo split of the PREVIOUS pair's accumulators into the other activation buffer (XA <-> XB
+// ping-pong) is interleaved with its first four double steps (it does not overlap the MFMAs -- a gfx950
+// SIMD never overlaps VALU with MFMA -- but it needs no second pass over the accumulators).  Weights
+// stream L2 -> LDS once per workgroup through the 8 x 16 KiB ring of mlp_ring.h, six chunks ahead (r02:
+// round 1's two 64 KiB buffers exposed the L2 -> LDS latency at each of this kernel's 31 buffer boundaries,
+// a third of its time).  Two 9-tile activation buffers = 288 registers: one wave per SIMD.
 //   * feature_linear (256 -> 256, no activation) feeds only views_linears.0 and is composed into it at
 //     pack time: W_view[:, :256] W_feat (128 x 256), like the field MLP's bottleneck (field_mlp_h.hip);
 //   * one auxiliary input tile per sample [px, py, pz, 1, embed(cam_dir) (27), 0] carries the skip
@@ -20,7 +23,8 @@
 // Reference quirks kept: z = near(1-t) + t/far with near = batch.far and
 // far = 1.5*near[0], i.e. z DEcreases; the last interval is 1e10; 1e-10 is added inside the
 // transmittance product.
-#include "mfma_chain_h.h"
+#include "mlp_ring.h"
+#include "pack_split.h"
 
 namespace {
 
@@ -28,8 +32,10 @@ constexpr int kSkySamples = 120;
 // ---- weight stream (1 KiB groups, pairs [otp][it][s][o2]): pts_linears 1..4, 5 (9 input tiles), 6, 7, views (9 tiles)
 constexpr int kGL1 = 0, kGL2 = 256, kGL3 = 512, kGL4 = 768, kGL5 = 1024, kGL6 = kGL5 + 288, kGL7 = kGL6 + 256;
 constexpr int kGV = kGL7 + 256, kGEnd = kGV + 144;                       // 1968
-constexpr uint64_t kSkyStreamGroups = (kGEnd + kTailGroups + kChunkGroups - 1) / kChunkGroups * kChunkGroups;   // 1984
-// ---- side table (floats), resident in LDS behind the two stream buffers
+constexpr uint64_t kSkyStreamGroups = (kGEnd + 4 + kChunkGroups - 1) / kChunkGroups * kChunkGroups;   // 1984
+constexpr int kSkyChunk = 16, kSkySlots = 8, kSkyLead = 6;        // ring geometry (128 KiB)
+using SkyRing = Ring<kGEnd, kSkyChunk, 4, kSkySlots, kSkyLead>;
+// ---- side table (floats), resident in LDS behind the ring
 constexpr int kSB = 0;            // 6 x 256: biases of pts_linears 1,2,3,4,6,7 as bias tiles [t][h][16]
 constexpr int kSL0 = 1536;        // 256 x {w0,w1,w2,b} of pts_linears.0, accumulator-slot order
 constexpr int kSAlpha = 2560;     // 256 alpha_linear weights (slot order), then b_alpha
@@ -54,22 +60,20 @@ struct SkyArgs {
 };
 
 template <int P>
-__device__ __forceinline__ HTile (&pick(HTile (&a)[9], HTile (&b)[9]))[9] {
+__device__ __forceinline__ HPair (&pick(HPair (&a)[8], HPair (&b)[8]))[8] {
     if constexpr (P == 0) return a;
     else return b;
 }
 
-// One pair chain: acc pair (already initialised) += W[pair] . in, NT_IN input tiles from stream position G;
-// `carry(i)`, i < 4, is the previous pair's activation work for its i-th half tile.
-template <int G, int NT_IN, class F>
-__device__ __forceinline__ void pair_chain(f32x16 &acc0, f32x16 &acc1, const HTile (&in)[9], APipe &p, WeightStream &ws,
-                                           F &&carry) {
-    static_for<NT_IN * 2>([&](auto ic) {
+// One pair chain: acc pair (already initialised) += W[pair] . in, NT_IN input tiles from stream position G.
+// (input tile 8 of the two 9-tile layers is the auxiliary tile, shared by both activation buffers)
+template <int G, int NT_IN>
+__device__ __forceinline__ void pair_chain(f32x16 &acc0, f32x16 &acc1, const HPair (&in)[8], const HPair &aux, OpPipe &p,
+                                           SkyRing &ring) {
+    rstatic_for<NT_IN * 2>([&](auto ic) {
         constexpr int i = ic.value;
-        if constexpr (i < 4)
-            dstep_h_with<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ws, [&] { carry(ic); });
-        else
-            dstep_h<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ws);
+        if constexpr (i / 2 < 8) dstep<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ring);
+        else dstep<G + 4 * i, kGEnd>(acc0, acc1, aux.hi[i % 2], aux.lo[i % 2], p, ring);
     });
 }
 
@@ -78,7 +82,7 @@ __device__ __forceinline__ void pair_chain(f32x16 &acc0, f32x16 &acc1, const HTi
 template <int TILE, int S>
 __device__ __forceinline__ void alpha_partial(const f32x16 &acc, const float *__restrict__ pa_h, float &sig) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) sig = fmaf(fmaxf(acc[8 * S + e], 0.0f), pa_h[(TILE * 16 + 8 * S + e) * 2], sig);
+    for (int e = 0; e < 8; e++) sig = fmaf(relu_bits(acc[8 * S + e]), pa_h[(TILE * 16 + 8 * S + e) * 2], sig);
 }
 
 __device__ __forceinline__ void side_bias_tile(const float *side, int off, int tile, f32x16 &acc, int h) {
@@ -91,8 +95,8 @@ __device__ __forceinline__ void side_bias_tile(const float *side, int off, int t
 }
 
 __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];   // 2 x 64 KiB stream buffers + side table
-    const float *side = s_w + 2 * kChunkGroups * 256;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring (128 KiB) + side table
+    const float *side = s_w + kSkySlots * kSkyChunk * 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -119,10 +123,9 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
         if (h == 0) { av[0] = px; av[1] = py; av[2] = pz; }                             // slots k = 0,1,2 (k = 3 is the 1)
     }
 
-    WeightStream ws{a.packed, s_w, lane, wave, (uint32_t)(kSkyStreamGroups / kChunkGroups)};
-    ws.issue(0);
-    {   // side table: 14 pieces of 1 KiB, DMA'd once; published by the first sync of the stream
-        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + 2u * kChunkGroups * 1024u;
+    SkyRing ring(a.packed, s_w, lane, wave);
+    {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kSkySlots * kSkyChunk) * 1024u;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int piece = k * 4 + wave;
@@ -133,11 +136,13 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
                              : "memory");
         }
     }
-    APipe p;
-    pipe_prime<0, kGEnd>(p, ws);
+    rstatic_for<kSkyLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
+    ring.template boundary<0>();                    // side table + chunk 0 landed
+    OpPipe p;
+    pipe_prime<kGEnd>(p, ring);
 
     // ---- layer 0 (3 -> 256) on the VALU, straight into XA
-    HTile XA[9], XB[9];
+    HPair XA[8], XB[8], aux;
     {
         const float4 *p0 = reinterpret_cast<const float4 *>(side + kSL0) + h;   // lane part in the base: offsets stay immediates
 #pragma unroll
@@ -148,23 +153,26 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
                 const float4 w = p0[(t * 16 + r) * 2];
                 acc[r] = ((w.x * px + w.y * py) + w.z * pz) + w.w;
             }
-            relu_split_half(acc, 0, XA[t]);
-            relu_split_half(acc, 1, XA[t]);
+            split_half<true>(acc, 0, XA[t]);
+            split_half<true>(acc, 1, XA[t]);
             __builtin_amdgcn_sched_barrier(0);          // one tile at a time: 8 tiles of float4 operands in flight spill
         }
-        split_tile(av, XA[8]);
-        XB[8] = XA[8];
+        split_half<false>(av, 0, aux);
+        split_half<false>(av, 1, aux);
     }
 
     // ---- the pair-chain sequence.  Layer li (0..6 = pts_linears 1..7) reads pick<li%2>, writes pick<(li+1)%2>.
-    f32x16 cur[2], prev[2];
+    //      A finished pair is ReLU'd and split straight into the other buffer (round 1 carried that work into the next
+    //      pair's double steps "in the MFMA shadow" with a second accumulator pair alive: nothing overlaps an MFMA on
+    //      this part, and the extra live registers pushed the kernel into 684 bytes of scratch per lane).
+    f32x16 cur[2];
     float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;                         // alpha_linear weights, accumulator-slot order
-    static_for<7>([&](auto lic) {
+    rstatic_for<7>([&](auto lic) {
         constexpr int li = lic.value, NT_IN = li == 4 ? 9 : 8;
-        HTile (&in)[9] = pick<li % 2>(XA, XB);
-        HTile (&out)[9] = pick<(li + 1) % 2>(XA, XB);
-        static_for<4>([&](auto pc) {
+        HPair (&in)[8] = pick<li % 2>(XA, XB);
+        HPair (&out)[8] = pick<(li + 1) % 2>(XA, XB);
+        rstatic_for<4>([&](auto pc) {
             constexpr int pr = pc.value;
             if constexpr (kBiasIdx[li] >= 0) {
                 side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr, cur[0], h);
@@ -173,34 +181,28 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) cur[0][r] = cur[1][r] = 0.0f;
             }
-            // carry: the previous pair's ReLU + split.  For (li, pr) it is pair pr-1 of this layer (-> out), or pair 3
-            // of the previous layer (-> in, tiles 6,7: read by this chain only from double step 12 on).
-            pair_chain<kLayerG[li] + pr * NT_IN * 8, NT_IN>(cur[0], cur[1], in, p, ws, [&](auto hc) {
-                constexpr int hi = hc.value;                     // half tile 0..3 of the carried pair
-                if constexpr (pr > 0) {
-                    relu_split_half(prev[hi / 2], hi % 2, out[2 * (pr - 1) + hi / 2]);
-                    if constexpr (li == 6) alpha_partial<2 * (pr - 1) + hi / 2, hi % 2>(prev[hi / 2], pa, sig);
-                }
-                else if constexpr (li > 0) relu_split_half(prev[hi / 2], hi % 2, in[6 + hi / 2]);
-            });
-            prev[0] = cur[0];
-            prev[1] = cur[1];
+            pair_chain<kLayerG[li] + pr * NT_IN * 8, NT_IN>(cur[0], cur[1], in, aux, p, ring);
+            if constexpr (li == 6) {                              // alpha head (VALU) on the fp32 ReLU output of layer 7
+                alpha_partial<2 * pr, 0>(cur[0], pa, sig);
+                alpha_partial<2 * pr, 1>(cur[0], pa, sig);
+                alpha_partial<2 * pr + 1, 0>(cur[1], pa, sig);
+                alpha_partial<2 * pr + 1, 1>(cur[1], pa, sig);
+            }
+            split_half<true>(cur[0], 0, out[2 * pr]);
+            split_half<true>(cur[0], 1, out[2 * pr]);
+            split_half<true>(cur[1], 0, out[2 * pr + 1]);
+            split_half<true>(cur[1], 1, out[2 * pr + 1]);
         });
     });
-    // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = pick<1> (7 layers); the first chain carries
-    //      the split of layer 7's last pair; the alpha head (VALU, fp32 h7) rides along
-    HTile (&h7)[9] = pick<1>(XA, XB);
+    // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = pick<1> (7 layers)
+    HPair (&h7)[8] = pick<1>(XA, XB);
     f32x16 v[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[t][r] = 0.0f;
-    pair_chain<kGV, 9>(v[0], v[1], h7, p, ws, [&](auto hc) {
-        constexpr int hi = hc.value;
-        relu_split_half(prev[hi / 2], hi % 2, h7[6 + hi / 2]);
-        alpha_partial<6 + hi / 2, hi % 2>(prev[hi / 2], pa, sig);
-    });
-    pair_chain<kGV + 9 * 8, 9>(v[2], v[3], h7, p, ws, [&](auto) {});
+    pair_chain<kGV, 9>(v[0], v[1], h7, aux, p, ring);
+    pair_chain<kGV + 9 * 8, 9>(v[2], v[3], h7, aux, p, ring);
     sig = (sig + __shfl_xor(sig, 32, 64)) + side[kSAlpha + 256];
     const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
@@ -367,7 +369,7 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
     a.inv_sky_far = 1.0f / far0_times_1p5;
     a.N = N; a.raw = raw;
     const uint64_t B = (uint64_t)N * kSkySamples;
-    const size_t lds = (2 * kChunkGroups * 256 + kSideFloats) * sizeof(float);
+    const size_t lds = ((size_t)kSkySlots * kSkyChunk * 256 + kSideFloats) * sizeof(float);
     hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite, dim3(ucn_div_up(N, 256)), dim3(256), 0, st, raw, directions, far_, t_vals,
                        a.inv_sky_far, N, sky_rgb_out);
