@@ -143,6 +143,34 @@ def density_query_ms(model, device, side=256, chunk=1 << 21):
                 call="nerf_mlp.predict_density(means[:, None], stds[:, None], no_warp=True)  (extract.py:54)")
 
 
+def tsdf_fusion_ms(device, resolution=512, views=4):
+    """TSDF.integrate_tsdf (reference tsdf.py:115-219) of `views` 1280x1920 depth + colour images into a
+    512^3 volume (the reference's default): one launch, one read-modify-write of the volume (36 B per voxel)."""
+    import types
+    from ucnerf_amd.internal.tsdf import TSDF
+    cfg = types.SimpleNamespace(tsdf_radius=2.0, tsdf_resolution=resolution, truncation_margin=5.0, tsdf_max_radius=10.0)
+    acc = types.SimpleNamespace(device=device, num_processes=1, process_index=0, is_main_process=True)
+    vol = TSDF(cfg, acc)
+    g = torch.Generator(device=device).manual_seed(4)
+    depth = torch.rand(views, 1, H_IMG, W_IMG, device=device, generator=g) * 4 + 1
+    color = torch.rand(views, 3, H_IMG, W_IMG, device=device, generator=g)
+    c2w = torch.eye(4, device=device)[None].repeat(views, 1, 1)
+    c2w[:, 0, 3] = torch.linspace(-0.3, 0.3, views, device=device)
+    K = torch.tensor([[FOCAL, 0.0, W_IMG / 2], [0.0, FOCAL, H_IMG / 2], [0.0, 0.0, 1.0]], device=device)
+    vol.integrate_tsdf(c2w, K, depth, color)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        vol.integrate_tsdf(c2w, K, depth, color)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    n = resolution ** 3
+    return dict(ms=ms, voxels=n, views=views, voxel_views_per_s=n * views / (ms * 1e-3), volume_GBps=n * 56 / (ms * 1e-3) / 1e9,
+                peak_GBps=PEAK_HBM_GBS, updated_fraction=float((vol.weights > 0).float().mean()),
+                kernel="k_tsdf_integrate (thread = voxel, the call's views in registers; 16 B world + 20 B state read, 20 B written)")
+
+
 def hbm_probe(device, n_floats=1 << 28, steps=10):
     """What a plain device-to-device copy kernel (`ucn_probe_copy`, float4 per lane) reaches on this part: the
     practical ceiling behind the 8 TB/s spec figure that `roofline.peak` uses."""
@@ -463,6 +491,7 @@ def main():
             res["ray_generation"] = ray_generation_ms(device)
             res["virtual_warp"] = virtual_warp_ms(device)
             res["density_query"] = density_query_ms(model, device)
+            res["tsdf_fusion"] = tsdf_fusion_ms(device)
             res["hbm_probe"] = hbm_probe(device)
         print(json.dumps(res))
     if world > 1:

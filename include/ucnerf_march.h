@@ -114,6 +114,15 @@ int ucn_resample(const float *sdist_prev /*[N,n_prev+1]*/, const float *weights_
 int ucn_cone_basis(const float *cam_dirs /*[N,3]*/, const float *rand_vec /*[N,3]*/, uint32_t N,
                    float *basis_out /*[N,6] = e1,e2*/, ucn_stream_t stream);
 
+/* ref: tsdf.py:115-219 TSDF.integrate_tsdf -- fuse B depth (and colour) images into the volume, one thread per voxel,
+ * the views of the call applied in order (running weighted mean, new weight 1).  voxel_world = the reference's
+ * `voxel_world_coords` [4][N] (homogeneous, inverse-contracted voxel centres); w2c = rows 0..2 of inverse(c2w) per view;
+ * sampling = grid_sample(nearest, zeros, align_corners=False).  colors / color NULL together. */
+int ucn_tsdf_integrate(const float *voxel_world, uint32_t N, const float *w2c /*[B][3][4]*/, const float *K /*[3][3]*/,
+                       const float *depth /*[B][H][W]*/, const float *color /*[B][3][H][W]|NULL*/, uint32_t B,
+                       uint32_t H, uint32_t W, float truncation, float *values /*[N]*/, float *weights /*[N]*/,
+                       float *colors /*[N][3]|NULL*/, ucn_stream_t stream);
+
 /* Launch-shape flag, OR-ed into ucn_march_features' `sample_major` and ucn_field_mlp's `rays_fastest` argument:
  * the two kernels are meant to run SIMULTANEOUSLY on two HIP streams and share every CU -- the featurisation as
  * 512-thread workgroups (two waves per SIMD) that reserve 88 KiB of LDS, the MLP with its 64 KiB weight ring

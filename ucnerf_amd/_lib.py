@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 LAUNCH_CORESIDENT = 0x100          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
@@ -67,6 +67,7 @@ SIGNATURES = {
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],
     "ucn_field_mlp": [ctypes.POINTER(UcnField), c_vp, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_composite": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_tsdf_integrate": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "ucn_compact_alive": [c_vp, c_u32, c_u32, c_i32, c_f32, c_vp, c_vp, c_vp],
     "ucn_field_rgb_compacted": [c_vp, c_vp, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_composite_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
