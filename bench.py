@@ -301,9 +301,7 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
                     + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg))
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        for p in model.parameters():
-            if p.grad is not None:
-                p.grad.nan_to_num_()
+        tu.clip_gradients(model, None, cfg)                         # train_utils.py:335-344: nan_to_num on every gradient
         opt.step()
         torch.cuda.synchronize()
         if it >= 2:
@@ -332,6 +330,10 @@ def main():
                     help="Model.compact_min_weight: early-termination sample compaction (colour layers only for samples whose "
                          "compositing weight reaches this value; 4e-8 bounds the pixel error by 5e-6).  Default off: on the random-init "
                          "field AND on a fitted one every sample carries weight (tools/fit_scene.py, DESIGN.md)")
+    ap.add_argument("--sky-skip", type=float, default=0.0,
+                    help="Model.sky_min_background (with --cfg5): sky layer only for rays whose background weight reaches this "
+                         "value.  Default off: the reference returns sky_rgbs for every ray, and on the random-init field "
+                         "every ray has background weight ~0.11")
     ap.add_argument("--fit-steps", type=int, default=0,
                     help="fit the model to tools/fit_scene.py's analytic scene for this many steps before the timed region "
                          "(a trained-like field instead of BASELINE's random-init one; reported in config.field)")
@@ -378,6 +380,7 @@ def main():
         fit_scene.fit(model, device, args.fit_steps)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     model.compact_min_weight = args.compact
+    model.sky_min_background = args.sky_skip
     batch = frame_rays(device, args.cameras, virtual=args.cfg5)
     n_rays = args.cameras * H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)
@@ -472,6 +475,8 @@ def main():
                        "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
                                  else "random-init weights, tables U(-1,1) (BASELINE configs)"),
                        "compact_min_weight": args.compact,
+                       **({"sky_min_background": args.sky_skip,
+                           "sky_rays_kept": getattr(model, "_sky_kept", None)} if args.cfg5 else {}),
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
                        "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
                        "mlp_mode": {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]},

@@ -235,6 +235,9 @@ int ucn_composite_backward(const float *density, const float *rgbs, const float 
  * ray; g_loss [N] -> out [N,S] = d(sum_n g_loss[n] loss[n]) / d w (t carries no gradient). */
 int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
                   float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream);
+/* ref: train_utils.py:342-344 `param.grad.nan_to_num_()` for every parameter: `count` fp32 DEVICE tensors (HOST arrays of
+ * their pointers and element counts) sanitised in place by one launch per 48 tensors. */
+int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *numel_host, uint32_t count, ucn_stream_t stream);
 int ucn_distortion_loss(const float *t /*[N,S+1]*/, const float *w /*[N,S]*/, uint32_t N, uint32_t S,
                         const float *g_loss, float *out, ucn_stream_t stream);
 /* ref: train_utils.py:247-270 anti_interlevel_loss for ONE proposal level (stepfun.py:395-403 blur_stepfun +
@@ -276,17 +279,29 @@ int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d
  * plus its bias).  Widths are the reference's (64, 256, 256, 256, 3); feat [M,F] fp32 with F <= 64 (one feature tile up to 32, two above:
  * the first and last matrices then have 4 more fragments). */
 uint64_t ucn_train_fwd_fragments(void);
+/* act_ld: 0 = h0 / x / h1 / h2 are dense [M,64] / [M,256] matrices; otherwise all four are column blocks of ONE row-major
+ * [M, act_ld] bf16 buffer (the caller passes the four column-offset pointers), so that the weight-gradient GEMMs can
+ * take adjacent blocks as one operand ([h1 | x | per-ray columns] is the input of the reference's concatenated layer,
+ * models.py:620-640).  ray_cols [N,32] bf16 | NULL: per-RAY columns (direction encoding, a constant 1 for the bias)
+ * copied into every sample's row at ray_dst (a column-offset pointer into the same buffer).  feat_bf16 [M,F] | NULL: bf16 copy of the features (operand of the first layer's weight gradient;
+ * F % 8 == 0).  head: HOST float[4] {density_bias, rgb_premultiplier, rgb_bias, rgb_padding} | NULL.  With head the
+ * output activations (models.py:515 softplus, :667-672 sigmoid + padding) are applied in fp32 before the store:
+ * raw := density, y := rgb. */
 int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
-                  void *h1, void *h2, float *raw, float *y, uint32_t *m0 /*[M,2]*/, void *m1 /*[M,2] x 16 B*/,
-                  void *m2, ucn_stream_t stream);
+                  void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16,
+                  const float *head, float *raw, float *y, uint32_t *m0 /*[M,2]*/, void *m1 /*[M,2] x 16 B*/, void *m2,
+                  ucn_stream_t stream);
 /* The same chain backwards (dgrad): gy [M,3] bf16 (gradient of y), graw [M] bf16|NULL (gradient of raw), packed_t =
  * the TRANSPOSED weights in the same fragment format (Wr^T, W1h^T, [W1x^T | W0x^T], Wd1^T, Wd0^T), m0/m1/m2 = the ReLU
- * masks ucn_train_fwd wrote.  Outputs: the pre-activation gradients the weight-gradient GEMMs need, d1, d0, gx
+ * masks ucn_train_fwd wrote.  With head (the same HOST float[4]) gy / graw are the fp32 gradients of rgb [M,3] /
+ * density [M] and the activation derivatives are taken from the forward's outputs `density`, `rgb`.
+ * Outputs: the pre-activation gradients the weight-gradient GEMMs need, d1, d0, gx
  * [M,256] and gh0 [M,64] as bf16, and the feature gradient gfeat [M,F] fp32. */
-int ucn_train_bwd(const void *gy, const void *graw, const void *packed_t, const uint32_t *m0, const void *m1,
-                  const void *m2, uint32_t N, uint32_t S, uint32_t F, void *d1, void *d0, void *gx, void *gh0,
-                  float *gfeat, ucn_stream_t stream);
+int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
+                  const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S,
+                  uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M,4] bf16 | NULL: the colour-logit
+                  gradient consumed, for the rgb layer's weight gradient*/, float *gfeat, ucn_stream_t stream);
 
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608

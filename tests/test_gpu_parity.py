@@ -823,3 +823,41 @@ def test_sample_compaction_matches_the_full_evaluation():
     alive = sum(a for a, _ in st1) / sum(t for _, t in st1)
     assert alive < 0.6, alive                                  # most samples sit behind an opaque medium here
     model.compact_min_weight, model._alive_stats = 0.0, None
+
+
+# ------------------------------------------------------------------ sky layer only where there is background weight
+def test_sky_is_skipped_for_rays_without_background_weight():
+    """Model.sky_min_background: the sky NeRF runs only for rays whose background weight 1 - sum(weights) reaches the
+    threshold (the reference evaluates it for every ray, models.py:326-337).  Kept rays: bit-identical sky and pixel;
+    skipped rays: sky_rgbs = 0 and the pixel moves by at most background weight * |A_sky sky + b|."""
+    spec = rm.make_spec("tiny", model_sky=True, brightness_correction=True)
+    sd = rm.init_state(spec, seed=31)
+    model, cfg = H.hip_model(spec, sd)
+    n = 1500
+    rays = H.to_dev(rm.synthetic_rays(n, seed=32))
+    rays["rand_vec"] = torch.randn(n, 6, generator=torch.Generator().manual_seed(33)).cuda()
+    cam = torch.tensor([1]).cuda()
+
+    def march(thr):
+        model.sky_min_background = thr
+        with torch.no_grad():
+            r, _ = model._march(False, rays, 1.0, False, cam, want_history=False)
+        torch.cuda.synchronize()
+        return {k: r[-1][k].clone() for k in ("rgb", "sky_rgbs", "weights")}
+
+    full = march(0.0)
+    bgw = 1 - full["weights"].reshape(n, -1).sum(-1)
+    thr = float(bgw.median())
+    cut = march(thr)
+    kept = bgw >= thr
+    assert model._sky_kept == (int(kept.sum()), n) and 0.3 * n < int(kept.sum()) < 0.7 * n
+    assert torch.equal(cut["sky_rgbs"][kept], full["sky_rgbs"][kept])
+    assert torch.equal(cut["rgb"].reshape(n, 3)[kept], full["rgb"].reshape(n, 3)[kept])
+    assert float(cut["sky_rgbs"][~kept].abs().max()) == 0.0
+    moved = (cut["rgb"].reshape(n, 3) - full["rgb"].reshape(n, 3)).abs().max(-1).values
+    A_sky = model.brightness_corr.affines(cam)[1].reshape(-1, 3, 4)[0]
+    bound = bgw * float(A_sky.abs().sum(-1).max()) * 1.001 + 1e-7
+    assert bool((moved[~kept] <= bound[~kept]).all())
+    everything = march(1e-30)                                  # threshold below every background weight: nothing skipped
+    assert torch.equal(everything["rgb"], full["rgb"])
+    model.sky_min_background = 0.0

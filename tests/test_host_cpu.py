@@ -190,3 +190,64 @@ def test_instance_keeps_its_bound_configuration_after_the_binding_block():
     assert (m.nerf_mlp.bottleneck_width, m.nerf_mlp.net_width_viewdirs) == (64, 64)
     assert m.nerf_mlp.lin_second_stage_0.weight.shape == (64, 64 + 27)
     assert m.prop_mlp_0.disable_rgb and not m.nerf_mlp.disable_rgb and m.num_nerf_samples == 8
+
+
+def test_fused_heads_weight_preparation_is_one_gather():
+    """train_graph._head_gather_index: ONE gather over the flat bf16 copy of the NeRF field's dense parameters yields the
+    forward and the dgrad fragment streams, the direction blocks / biases in accumulator order -- element for element
+    what the per-matrix packers build from the sliced, transposed and concatenated matrices."""
+    from ucnerf_amd.internal import train_graph as tg
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    for F_in in (32, 40):
+        NB = NW = 256
+        E, T = 27, 448
+        Wd0, Wd1, W0 = torch.randn(64, F_in), torch.randn(NB, 64), torch.randn(NW, NB + E)
+        W1, Wr = torch.randn(NW, NW + NB + E), torch.randn(3, NW)
+        bd0, bd1, b0, b1, br = torch.randn(64), torch.randn(NB), torch.randn(NW), torch.randn(NW), torch.randn(3)
+        idx, n = tg._head_gather_index(F_in, NB, NW, E, T, "cpu")
+        src = torch.cat([t.reshape(-1) for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br)] + [torch.zeros(1)]).to(dt)
+        assert src.numel() == n
+        got = src[idx]
+        W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
+        W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
+        Wd0b, Wd1b, Wrb = Wd0.to(dt), Wd1.to(dt), Wr.to(dt)
+        fwd = tg._pack_fragments([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], 1), False), (Wrb, False)], "cpu", total=T)
+        bwd = tg._pack_fragments([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], 1), False), (Wd1b.t(), False),
+                                  (Wd0b.t(), False)], "cpu", total=T)
+        assert torch.equal(got[:T * 512], fwd) and torch.equal(got[T * 512:2 * T * 512], bwd)
+        o = 2 * T * 512
+        We, be = got[o:o + 2 * NW * E].view(2 * NW, E), got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]
+        bv = got[o + 2 * NW * E + 2 * NW:].float()
+        eb = torch.randn(5, E).to(dt)
+        for half, (b, We_ref) in enumerate(((b0, W0e), (b1, W1e))):
+            pr = torch.addmm(be[half * NW:(half + 1) * NW], eb, We[half * NW:(half + 1) * NW].t()).float()
+            assert torch.equal(pr, tg._acc_vec(torch.addmm(b.to(dt), eb, We_ref.t()).float(), NW, "cpu"))
+        for got_v, (b, w) in zip((bv[:64], bv[64:64 + NB], bv[64 + NB:]), ((bd0, 64), (bd1, NB), (br, 32))):
+            assert torch.equal(got_v, tg._acc_vec(b.to(dt).float(), w, "cpu"))
+
+
+def test_data_loss_levels_and_lazy_stats():
+    """compute_data_loss (train_utils.py:171-230): every level through one set of launches; value and stats equal the
+    per-level loop of the reference, and the mse statistics are fetched on first read (no host sync inside the loss)."""
+    import types
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator().manual_seed(3)
+    batch = dict(rgb=torch.rand(50, 1, 1, 3, generator=g), lossmult=torch.rand(50, 1, 1, 1, generator=g) + 0.5)
+    rend = [dict(rgb=torch.rand(50, 1, 1, 3, generator=g)) for _ in range(3)]
+    for kind in ("charb", "mse"):
+        for multiscale_off in (False, True):
+            cfg = types.SimpleNamespace(data_loss_type=kind, charb_padding=0.001, data_loss_mult=0.7, data_coarse_loss_mult=0.3,
+                                        disable_multiscale_loss=multiscale_off)
+            loss, stats = tu.compute_data_loss(batch, rend, cfg)
+            lm = torch.ones_like(batch['rgb']) if multiscale_off else torch.broadcast_to(batch['lossmult'], batch['rgb'].shape)
+            per, mses = [], []
+            for r in rend:
+                sq = (r['rgb'] - batch['rgb']) ** 2
+                mses.append(float((lm * sq).sum() / lm.sum()))
+                per.append((lm * (sq if kind == "mse" else torch.sqrt(sq + 0.001 ** 2))).sum() / lm.sum())
+            want = 0.3 * sum(per[:-1]) + 0.7 * per[-1]
+            assert abs(float(loss) - float(want)) <= 1e-6
+            assert isinstance(dict.__getitem__(stats, 'mses'), torch.Tensor)         # not fetched yet
+            assert isinstance(stats['mses'], np.ndarray) and np.allclose(stats['mses'], mses, atol=1e-6)
+            assert isinstance(dict.__getitem__(stats, 'mses'), np.ndarray) and list(stats.keys()) == ['mses']

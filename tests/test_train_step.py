@@ -581,3 +581,30 @@ def test_ddp_training_step_two_ranks(tmp_path):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert all("OK" in o for o in outs)
+
+
+@pytest.mark.gpu
+def test_sanitize_gradients_is_nan_to_num_on_every_gradient():
+    """train_utils.py:342-344 (`param.grad.nan_to_num_()` per parameter) as one launch: same values as torch's op on
+    tensors of assorted sizes with nan / +-inf planted, non-contiguous / half gradients through torch's path."""
+    from ucnerf_amd.internal import train_utils as tu
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sizes = [1, 3, 64, 257, 4096, 70000, 300001] + [17] * 60            # > 48 tensors: two launches
+    params = [torch.nn.Parameter(torch.zeros(n, device="cuda")) for n in sizes]
+    params.append(torch.nn.Parameter(torch.zeros(8, 6, device="cuda")))
+    params.append(torch.nn.Parameter(torch.zeros(9, device="cuda", dtype=torch.float16)))
+    params.append(torch.nn.Parameter(torch.zeros(5, device="cuda")))     # no gradient
+    want = []
+    for i, p in enumerate(params[:-1]):
+        gr = torch.randn(p.shape, device="cuda", generator=g).to(p.dtype)
+        flat = gr.reshape(-1)
+        flat[0] = float("nan")
+        if flat.numel() > 2:
+            flat[1], flat[-1] = float("inf"), float("-inf")
+        p.grad = gr.t().contiguous().t() if (gr.dim() == 2) else gr      # the 2-D one is non-contiguous
+        want.append(p.grad.clone().nan_to_num())
+    assert not params[-3].grad.is_contiguous()
+    tu.sanitize_gradients(params)
+    for p, w in zip(params[:-1], want):
+        assert torch.equal(p.grad, w)
+    assert params[-1].grad is None

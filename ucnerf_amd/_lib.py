@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 LAUNCH_CORESIDENT = 0x100          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
@@ -80,10 +80,12 @@ SIGNATURES = {
     "ucn_interlevel_loss": [c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_f32, c_u32, c_vp, c_vp, c_vp],
     "ucn_bias_relu": [c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_relu_backward_reduce": [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
+    "ucn_nan_to_num_many": [c_vp, c_vp, c_u32, c_vp],
     "ucn_train_fwd_fragments": [],
-    "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                      c_vp, c_vp],
-    "ucn_train_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp,
+                      ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_train_bwd": [c_vp, c_vp, ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
+                      c_vp, c_vp, c_vp, c_vp],
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],

@@ -29,8 +29,14 @@ struct TrainFwdArgs {
     const uint4 *w;           // packed fragments: L0 (2x1x2), L1 (8x2x2), L2 (8x8x2), L3 (8x16x2), L4 (1x8x2)
     const float *bias_d0, *bias_d1, *bias_rgb;   // accumulator order: [tile][h][16]
     const float *pr0, *pr1;   // [N, 8][2][16] fp32, accumulator order per ray
-    uint16_t *h0, *x, *h1, *h2;                  // bf16 [M, 64] / [M, 256] row-major
-    float *raw, *y;           // [M], [M, 3]
+    uint16_t *h0, *x, *h1, *h2;                  // bf16 [M, 64] / [M, 256] row-major, row strides ld_h0 / ld_act elements
+    const uint16_t *ray_cols; // [N, 32] bf16 per-RAY columns copied to every sample's row at ray_dst (row stride ld_act), or NULL
+    uint16_t *ray_dst;
+    uint16_t *fb;             // [M, F] bf16 copy of the features (the density layer's weight-gradient operand) or NULL
+    float *raw, *y;           // [M], [M, 3]: raw density and colour logits, or (head) density and rgb
+    uint32_t ld_h0, ld_act;
+    int head;                 // 1: raw := softplus(raw + density_bias), y := sigmoid(premult y + rgb_bias) (1 + 2 pad) - pad
+    float density_bias, rgb_premult, rgb_bias, rgb_padding;
     uint32_t *m0;             // [M][2] : ReLU masks of h0, bit 16 t + r of wave half h  (2 tiles)
     uint4 *m1, *m2;           // [M][2] : ReLU masks of h1 / h2, 16 bits per tile, 8 tiles
     uint32_t M, S, F;
@@ -141,7 +147,15 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
                 v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
             }
             fin[ft][s] = pack8(v);
+            if (a.fb && live && a.F % 8 == 0 && 32u * ft + 16u * s + 8u * h < a.F)
+                *reinterpret_cast<uint4 *>(a.fb + (size_t)sample * a.F + 32u * ft + 16u * s + 8u * h) = __builtin_bit_cast(uint4, fin[ft][s]);
         }
+    if (a.ray_cols && live) {               // lane (j, h): columns 16 h .. 16 h + 15 of its sample's row
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.ray_cols + (size_t)ray * 32 + 16 * h);
+        uint4 *dst = reinterpret_cast<uint4 *>(a.ray_dst + (size_t)sample * a.ld_act + 16 * h);
+        dst[0] = src[0];
+        dst[1] = src[1];
+    }
     ws.sync();                              // chunk 0 and the feature loads above land together
     // ---- density layer 0
     f32x16 a0[2];
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     for (int t = 0; t < 2; t++) {
         h0[t][0] = to_b(a0[t], 0, true);
         h0[t][1] = to_b(a0[t], 1, true);
-        store_tile(a.h0, 64, sample, t, h, h0[t], live);
+        store_tile(a.h0, a.ld_h0, sample, t, h, h0[t], live);
     }
     if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
@@ -167,11 +181,14 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     for (int t = 0; t < 8; t++) {
         xin[8 + t][0] = to_b(acc[t], 0, false);
         xin[8 + t][1] = to_b(acc[t], 1, false);
-        store_tile(a.x, 256, sample, t, h, xin[8 + t], live);
+        store_tile(a.x, a.ld_act, sample, t, h, xin[8 + t], live);
     }
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
         const uint4 q = __builtin_bit_cast(uint4, xin[8][0]);
-        a.raw[sample] = __uint_as_float(q.x << 16);
+        const float rawv = __uint_as_float(q.x << 16);
+        // head: F.softplus (beta 1, threshold 20) of the bf16-rounded linear output, in fp32 like autocast runs it
+        const float z = rawv + a.density_bias;
+        a.raw[sample] = !a.head ? rawv : (z > 20.0f ? z : log1pf(__expf(z)));
     }
     // ---- colour layer 0: x -> h1
 #pragma unroll
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     for (int t = 0; t < 8; t++) {
         xin[t][0] = to_b(acc[t], 0, true);
         xin[t][1] = to_b(acc[t], 1, true);
-        store_tile(a.h1, 256, sample, t, h, xin[t], live);
+        store_tile(a.h1, a.ld_act, sample, t, h, xin[t], live);
     }
     if (live) {
         uint32_t mk[4];
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     for (int t = 0; t < 8; t++) {
         h2[t][0] = to_b(acc[t], 0, true);
         h2[t][1] = to_b(acc[t], 1, true);
-        store_tile(a.h2, 256, sample, t, h, h2[t], live);
+        store_tile(a.h2, a.ld_act, sample, t, h, h2[t], live);
     }
     if (live) {
         uint32_t mk[4];
@@ -216,9 +233,12 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     load_acc(a.bias_rgb + h * 16, yo[0]);
     layer<1, 8, G4>(ws, yo, h2);
     if (live && h == 0) {
-        a.y[(size_t)sample * 3 + 0] = yo[0][0];
-        a.y[(size_t)sample * 3 + 1] = yo[0][1];
-        a.y[(size_t)sample * 3 + 2] = yo[0][2];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            float v = yo[0][e];
+            if (a.head) v = fmaf(1.0f / (1.0f + __expf(-fmaf(a.rgb_premult, v, a.rgb_bias))), 1.0f + 2.0f * a.rgb_padding, -a.rgb_padding);
+            a.y[(size_t)sample * 3 + e] = v;
+        }
     }
 }
 
@@ -227,12 +247,16 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
 //   d1 = (Wr^T gy) * m2          [256]      gx  = W1x^T d1 + W0x^T d0 (+ g_raw on feature 0)   [256]
 //   d0 = (W1h^T d1) * m1         [256]      gh0 = (Wd1^T gx) * m0 [64],   gfeat = Wd0^T gh0    [F] fp32
 struct TrainBwdArgs {
-    const uint16_t *gy;       // [M, 3] bf16
-    const uint16_t *graw;     // [M] bf16 or NULL
+    const void *gy;           // [M, 3] bf16 logit gradients, or (head) fp32 gradients of rgb
+    const void *graw;         // [M] bf16 gradient of raw, or (head) fp32 gradient of density; or NULL
+    int head;                 // 1: the activation derivatives are applied here from the saved outputs density / rgb
+    const float *density, *rgb;
+    float rgb_premult, rgb_padding;
     const uint4 *w;           // fragments: Wr^T (8x1x2), W1h^T (8x8x2), [W1x^T | W0x^T] (8x16x2), Wd1^T (2x8x2), Wd0^T (1x2x2)
     const uint32_t *m0;
     const uint4 *m1, *m2;
     uint16_t *d1, *d0, *gx, *gh0;     // bf16 [M,256] x3, [M,64]
+    uint16_t *dy;                     // bf16 [M,4] | NULL: the colour-logit gradient this kernel consumed (columns 0..2; 3 = 0)
     float *gfeat;                     // [M, F]
     uint32_t M, F;
 };
@@ -259,9 +283,21 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (h == 0) {
 #pragma unroll
-            for (int e = 0; e < 3; e++) v[e] = __uint_as_float((uint32_t)a.gy[(size_t)sample * 3 + e] << 16);
+            for (int e = 0; e < 3; e++) {
+                if (a.head) {
+                    const float k = 1.0f + 2.0f * a.rgb_padding;
+                    const float sg = (a.rgb[(size_t)sample * 3 + e] + a.rgb_padding) / k;
+                    v[e] = reinterpret_cast<const float *>(a.gy)[(size_t)sample * 3 + e] * k * a.rgb_premult * sg * (1.0f - sg);
+                } else {
+                    v[e] = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.gy)[(size_t)sample * 3 + e] << 16);
+                }
+            }
         }
         gin[0][0] = pack8(v);
+        if (a.dy && live && h == 0) {
+            const uint4 q = __builtin_bit_cast(uint4, gin[0][0]);
+            *reinterpret_cast<uint2 *>(a.dy + (size_t)sample * 4) = make_uint2(q.x, q.y);
+        }
         const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         gin[0][1] = pack8(z);
     }
@@ -302,7 +338,12 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; t++) zero_acc(acc[t]);
     layer<8, 16, 144>(ws, acc, din);
-    if (a.graw && h == 0) acc[0][0] += __uint_as_float((uint32_t)a.graw[sample] << 16);
+    if (a.graw && h == 0) {
+        // head: d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z)), from the saved density; rounded to bf16 like the
+        // gradient the per-layer path hands to the bottleneck's GEMM
+        if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (1.0f - __expf(-a.density[sample])));
+        else acc[0][0] += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+    }
     bf8 gxb[8][2];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -352,31 +393,39 @@ extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kChunks * k
 
 extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                              const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
-                             void *h1, void *h2, float *raw, float *y, uint32_t *m0, void *m1, void *m2, ucn_stream_t stream) {
+                             void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16, const float *head,
+                             float *raw, float *y, uint32_t *m0, void *m1, void *m2, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y && m0 && m1 && m2,
                 "train_fwd: null pointer argument");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
+    UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 4 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 4)", act_ld);
+    UCN_REQUIRE(!ray_cols || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
+    UCN_REQUIRE(!feat_bf16 || F % 8 == 0, "train_fwd: the bf16 feature copy needs F %% 8 == 0, got %u", F);
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
-                   (uint16_t *)h2, raw, y, m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
+                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, head != nullptr,
+                   head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
+                   m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
     if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_train_fwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
 }
 
-extern "C" int ucn_train_bwd(const void *gy, const void *graw, const void *packed_t, const uint32_t *m0, const void *m1, const void *m2,
-                             uint32_t N, uint32_t S, uint32_t F, void *d1, void *d0, void *gx, void *gh0, float *gfeat,
-                             ucn_stream_t stream) {
+extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
+                             const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S, uint32_t F,
+                             void *d1, void *d0, void *gx, void *gh0, void *dy, float *gfeat, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gx && gh0 && gfeat, "train_bwd: null pointer argument");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_bwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");
-    TrainBwdArgs a{(const uint16_t *)gy, (const uint16_t *)graw, (const uint4 *)packed_t, m0, (const uint4 *)m1, (const uint4 *)m2,
-                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, gfeat, (uint32_t)M, F};
+    UCN_REQUIRE(!head || (density && rgb), "train_bwd: head mode needs the forward's density and rgb");
+    TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
+                   (const uint4 *)m1, (const uint4 *)m2,
+                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, gfeat, (uint32_t)M, F};
     if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");

@@ -342,7 +342,42 @@ __global__ __launch_bounds__(256) void k_relu_bwd_reduce(const T *__restrict__ g
     }
 }
 
+// nan_to_num_ (nan -> 0, +-inf -> +-FLT_MAX) on up to kManyMax small fp32 tensors in one launch: blockIdx.y = tensor
+constexpr int kManyMax = 48;
+struct ManyTensors {
+    float *ptr[kManyMax];
+    uint32_t n[kManyMax];
+};
+__global__ __launch_bounds__(256) void k_nan_to_num_many(ManyTensors t) {
+    float *p = t.ptr[blockIdx.y];
+    const uint32_t n = t.n[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float v = p[i];
+        if (!(fabsf(v) <= 3.4028234663852886e38f)) p[i] = v != v ? 0.0f : (v > 0.0f ? 3.4028234663852886e38f : -3.4028234663852886e38f);
+    }
+}
+
 }  // namespace
+
+extern "C" int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *numel_host, uint32_t count, ucn_stream_t stream) {
+    UCN_REQUIRE(count == 0 || (tensors_host && numel_host), "nan_to_num_many: null pointer argument");
+    for (uint32_t base = 0; base < count; base += kManyMax) {
+        ManyTensors t{};
+        const uint32_t m = count - base < (uint32_t)kManyMax ? count - base : (uint32_t)kManyMax;
+        uint64_t biggest = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            UCN_REQUIRE(numel_host[base + i] < 0xFFFFFFFFull, "nan_to_num_many: tensor %u too large", base + i);
+            t.ptr[i] = tensors_host[base + i];
+            t.n[i] = (uint32_t)numel_host[base + i];
+            biggest = numel_host[base + i] > biggest ? numel_host[base + i] : biggest;
+        }
+        if (biggest == 0) continue;
+        const uint32_t bx = (uint32_t)(ucn_div_up(biggest, 1024) < 256 ? ucn_div_up(biggest, 1024) : 256);
+        hipLaunchKernelGGL(k_nan_to_num_many, dim3(bx ? bx : 1, m), dim3(256), 0, (hipStream_t)stream, t);
+        UCN_LAUNCH_CHECK("nan_to_num_many");
+    }
+    return 0;
+}
 
 extern "C" int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
                              float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream) {

@@ -348,6 +348,12 @@ class Model(nn.Module):
     #                                      evaluates every sample (models.py:221-243).  0 = off: on a field whose samples all
     #                                      carry weight (random initialisation) the extra density pass is pure overhead
 
+    sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background
+    #                                      weight 1 - sum(weights of the last level) reaches this value; the others get
+    #                                      sky_rgbs = 0 (their pixel moves by < sky_min_background * |A_sky| through
+    #                                      models.py:352-354).  The reference evaluates the sky for every ray
+    #                                      (models.py:326-337) and RETURNS sky_rgbs, so 0 = off is the default
+
     def __init__(self, config=None, **kwargs):
         super().__init__()
         set_kwargs(self, kwargs)
@@ -567,7 +573,18 @@ class Model(nn.Module):
                 r['ray_rgbs'] = final[:, None, :].expand(r['ray_rgbs'].shape)
 
         if getattr(cfg, 'model_sky', False):                           # ref models.py:326-337
-            sky = self.skynerf.render(o, d, cam, far)
+            if self.sky_min_background > 0 and not rand:
+                bgw = 1 - renderings[-1]['weights'].reshape(N, -1).sum(dim=-1)
+                keep = torch.nonzero(bgw >= self.sky_min_background).reshape(-1)      # host sync, like far[0] in render()
+                sky = torch.zeros(N, 3, device=dev)
+                if keep.numel() == N:
+                    sky = self.skynerf.render(o, d, cam, far)
+                elif keep.numel():
+                    # far0 = 1.5 * far[0] of the FULL batch (models.py:329), not of the kept rays
+                    sky[keep] = self.skynerf.render(o[keep], d[keep], cam[keep], far[keep], far0=far.reshape(-1)[:1])
+                self._sky_kept = (int(keep.numel()), N)
+            else:
+                sky = self.skynerf.render(o, d, cam, far)
             for r in renderings:
                 r['sky_rgbs'] = sky
         if getattr(cfg, 'brightness_correction', False):               # ref models.py:339-363

@@ -67,14 +67,15 @@ class NeRF(nn.Module):
         return d
 
     @torch.no_grad()
-    def render(self, origins, directions, cam_dirs, far):
-        """models.py:326-337: near = batch.far, far = 1.5 * near[0] -> rgb_map [N,3]."""
+    def render(self, origins, directions, cam_dirs, far, far0=None):
+        """models.py:326-337: near = batch.far, far = 1.5 * near[0] -> rgb_map [N,3].  `far0`: the tensor whose first
+        element stands for near[0] when `far` is a subset of the batch (Model.sky_min_background)."""
         lib = _lib.load()
         N = origins.shape[0]
         dev = origins.device
         d = self._descriptor()
         far = far.reshape(N).contiguous()
-        far0 = float(far[0].detach().cpu().item()) * 1.5          # the reference's host sync (models.py:329)
+        far0 = float((far if far0 is None else far0.reshape(-1))[0].detach().cpu().item()) * 1.5   # the reference's host sync (models.py:329)
         ws = torch.empty(lib.ucn_sky_workspace_floats(N), device=dev)
         out = torch.empty(N, 3, device=dev)
         _lib.check(lib.ucn_sky_render(ctypes.byref(d), origins.data_ptr(), directions.data_ptr(), cam_dirs.data_ptr(),

@@ -310,73 +310,164 @@ def _acc_vec(v, width, device):
     return pad[..., _acc_order(width, device)].contiguous()
 
 
+# Column layout of the one activation buffer ucn_train_fwd writes per sample (bf16 [M, ACT_LD]): adjacent blocks are the
+# concatenated inputs of the reference's layers, so each layer's whole weight gradient -- per-sample blocks, the per-ray
+# direction block AND the bias (the constant-1 column of `aux`) -- is ONE split-K GEMM on a strided view:
+#   [ h2 | h1 | x | aux = (dir_enc(27), 1, 0, 0, 0, 0) | h0 ]
+#     d1^T [h1 | x | aux] = [gW1h | gW1x | gW1e | gb1]  (models.py:620-640: lin_second_stage_1 over cat([h1, x, enc]))
+#     d0^T [x | aux]      = [gW0x | gW0e | gb0],      gx^T [aux | h0] -> gb_d1 (column 27), gW_d1 (columns 32..95)
+_ACT_H2, _ACT_H1, _ACT_X, _ACT_AUX, _ACT_H0, ACT_LD = 0, 256, 512, 768, 800, 864
+
+
+def _head_gather_index(F_in, NB, NW, E, total, device):
+    """ONE gather index over the flat bf16 copy of (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br, 0) that yields, in this
+    order: the forward fragment stream, the dgrad (transposed) fragment stream, the direction blocks of W0 / W1 with
+    rows in accumulator order [2 NW, E], their biases [2 NW], and bd0 / bd1 / br in accumulator order (64 + NB + 32).
+    A logical matrix is a list of column blocks (base, row_stride, col_stride, ncols) of the flat source."""
+    key = ("heads", F_in, NB, NW, E, total, str(device))
+    hit = _FRAG_CACHE.get(key)
+    if hit is not None:
+        return hit
+    k0, k1 = NB + E, NW + NB + E
+    oWd0 = 0
+    oWd1 = oWd0 + 64 * F_in
+    oW0 = oWd1 + NB * 64
+    oW1 = oW0 + NW * k0
+    oWr = oW1 + NW * k1
+    obd0 = oWr + 3 * NW
+    obd1, ob0, ob1, obr = obd0 + 64, obd0 + 64 + NB, obd0 + 64 + NB + NW, obd0 + 64 + NB + 2 * NW
+    zero = obr + 3
+
+    def stream(mats):
+        parts = []
+        for rows, blocks, nat in mats:
+            cols = sum(b[3] for b in blocks)
+            r, c = _fragment_index(rows, cols, nat)
+            off = torch.full_like(r, -1)
+            start = 0
+            for base, rs, cs, nc in blocks:
+                inside = (r >= 0) & (c >= start) & (c < start + nc)
+                off = torch.where(inside, base + r * rs + (c - start) * cs, off)
+                start += nc
+            parts.append(off)
+        flat = torch.cat(parts)
+        assert flat.numel() <= total * 512
+        return torch.cat([flat, flat.new_full((total * 512 - flat.numel(),), -1)])
+
+    fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oW0, k0, 1, NB)], False),
+                  (NW, [(oW1, k1, 1, NW + NB)], False), (3, [(oWr, NW, 1, NW)], False)])
+    bwd = stream([(NW, [(oWr, 1, NW, 3)], True), (NW, [(oW1, 1, k1, NW)], False),
+                  (NB, [(oW1 + NW, 1, k1, NW), (oW0, 1, k0, NW)], False), (64, [(oWd1, 1, 64, NB)], False),
+                  (F_in, [(oWd0, 1, F_in, 64)], False)])
+    acc_w, acc_b, acc_64 = _acc_order(NW, "cpu"), _acc_order(NB, "cpu"), _acc_order(64, "cpu")
+    e = torch.arange(E)
+    we = torch.cat([(oW0 + acc_w[:, None] * k0 + NB + e[None, :]).reshape(-1),
+                    (oW1 + acc_w[:, None] * k1 + NW + NB + e[None, :]).reshape(-1)])
+    be = torch.cat([ob0 + acc_w, ob1 + acc_w])
+    a32 = _acc_order(32, "cpu")
+    bv = torch.cat([obd0 + acc_64, obd1 + acc_b, torch.where(a32 < 3, obr + a32, torch.full_like(a32, -1))])
+    idx = torch.cat([fwd, bwd, we, be, bv])
+    hit = (torch.where(idx >= 0, idx, torch.full_like(idx, zero)).to(device), zero + 1)
+    _FRAG_CACHE[key] = hit
+    return hit
+
+
+def _wgrad_cols(gy, act, lo, hi):
+    """gy^T @ act[:, lo:hi] as float32 [gy columns, hi - lo]: split-K batched GEMM over 8192-row chunks on a strided
+    column view of the activation buffer (no copy; see _TallLinear for why the reduction is cut)."""
+    m, c = gy.shape[0], _TallLinear.CHUNK
+    if m >= 4 * c and m % c == 0:
+        return torch.bmm(gy.reshape(m // c, c, -1).transpose(1, 2), act.reshape(m // c, c, -1)[:, :, lo:hi]).float().sum(0)
+    return (gy.t() @ act[:, lo:hi]).float()
+
+
 class _FusedHeads(torch.autograd.Function):
-    """Density MLP + colour MLP + rgb layer of the NeRF field (models.py:507-674, the reference's topology and widths)
-    under bf16 autocast: the forward is ONE HIP kernel (`ucn_train_fwd`: activations stay in registers from the
-    feature row to the colour logits, each hidden activation and its ReLU mask is stored once); the backward's dgrad
-    chain is ONE HIP kernel too (`ucn_train_bwd`: transposed weight fragments, the forward's masks), and the weight
-    gradients are split-K library GEMMs on the pre-activation gradients it stores."""
+    """Density MLP + colour MLP + rgb layer + output activations of the NeRF field (models.py:507-674, the reference's
+    topology and widths) under bf16 autocast: the forward is ONE HIP kernel (`ucn_train_fwd`: activations stay in
+    registers from the feature row to density / rgb, each hidden activation and its ReLU mask is stored once, into one
+    [M, 864] buffer); the backward's dgrad chain is ONE HIP kernel too (`ucn_train_bwd`: transposed weight fragments, the
+    forward's masks, the activation derivatives from the saved outputs), and every layer's weight + bias gradient is one
+    split-K library GEMM on the pre-activation gradients it stores (column layout above).  All weight preparation (bf16
+    copies, both fragment streams, accumulator-order biases) is one cat + one cast + one gather per step."""
 
     @staticmethod
-    def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S):
+    def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S, head):
         lib = _lib.load()
         dev, dt = feat.device, torch.bfloat16
-        NB, NW = Wd1.shape[0], W0.shape[0]
+        NB, NW, F_in = Wd1.shape[0], W0.shape[0], Wd0.shape[1]
+        E = W0.shape[1] - NB
+        T = lib.ucn_train_fwd_fragments()
         with torch.autocast("cuda", enabled=False):
-            W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
-            W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
-            Wd0b, Wd1b, Wrb, eb = Wd0.to(dt), Wd1.to(dt), Wr.to(dt), enc.to(dt)
-            packed = _pack_fragments([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], dim=1), False), (Wrb, False)], dev,
-                                     total=lib.ucn_train_fwd_fragments())
-            assert packed.numel() == lib.ucn_train_fwd_fragments() * 512
-            pr0 = _acc_vec(torch.addmm(b0.to(dt), eb, W0e.t()).float(), NW, dev)         # what the bf16 GEMM + bias would hold
-            pr1 = _acc_vec(torch.addmm(b1.to(dt), eb, W1e.t()).float(), NW, dev)
-            bias0, bias1, biasr = (_acc_vec(b.to(dt).float(), w, dev) for b, w in ((bd0, 64), (bd1, NB), (br, 32)))
+            idx, n_src = _head_gather_index(F_in, NB, NW, E, T, dev)
+            zero = _FRAG_CACHE.get(("zero1", str(dev)))
+            if zero is None:
+                zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
+            src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br)] + [zero]).to(dt)
+            assert src.numel() == n_src
+            got = src[idx]
+            packed, packed_t = got[:T * 512], got[T * 512:2 * T * 512]
+            o = 2 * T * 512
+            We = got[o:o + 2 * NW * E].view(2 * NW, E)
+            be = got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]
+            bv = got[o + 2 * NW * E + 2 * NW:].float()
+            bias0, bias1, biasr = bv[:64], bv[64:64 + NB], bv[64 + NB:]
+            eb = enc.to(dt)
+            pr0 = torch.addmm(be[:NW], eb, We[:NW].t()).float()          # what the bf16 GEMM + bias would hold, acc order
+            pr1 = torch.addmm(be[NW:], eb, We[NW:].t()).float()
             M = N * S
             f = feat.float().contiguous()
-            h0 = torch.empty(M, 64, device=dev, dtype=dt)
-            x, h1, h2 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
-            raw, y = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+            act = torch.empty(M, ACT_LD, device=dev, dtype=dt)
+            aux = torch.zeros(N, 32, device=dev, dtype=dt)
+            aux[:, :E] = eb
+            aux[:, E] = 1.0
+            fb = torch.empty(M, F_in, device=dev, dtype=dt) if F_in % 8 == 0 else None
+            density, rgb = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
             m0 = torch.empty(M, 2, device=dev, dtype=torch.int32)
             m1, m2 = (torch.empty(M, 2, 4, device=dev, dtype=torch.int32) for _ in range(2))
-            _lib.check(lib.ucn_train_fwd(f.data_ptr(), f.shape[1], packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
-                                         biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, h0.data_ptr(), x.data_ptr(),
-                                         h1.data_ptr(), h2.data_ptr(), raw.data_ptr(), y.data_ptr(), m0.data_ptr(), m1.data_ptr(),
-                                         m2.data_ptr(), _lib.stream()))
-            # the dgrad chain's weights: the transposes, same fragment format (first matrix: gy arrives in natural order)
-            packed_t = _pack_fragments([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], dim=1), False),
-                                        (Wd1b.t(), False), (Wd0b.t(), False)], dev, total=lib.ucn_train_fwd_fragments())
-        ctx.save_for_backward(f.to(dt), eb, h0, x, h1, h2, m0, m1, m2, packed_t)
-        ctx.meta = (N, S, NB, NW, feat.dtype, Wd0.dtype, bd0.dtype)
-        return raw.to(dt), y.to(dt)
+            hd = (ctypes.c_float * 4)(*[float(v) for v in head])
+            base = act.data_ptr()
+            _lib.check(lib.ucn_train_fwd(f.data_ptr(), F_in, packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
+                                         biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, base + 2 * _ACT_X,
+                                         base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX, _lib.ptr(fb), hd, density.data_ptr(),
+                                         rgb.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), _lib.stream()))
+            if fb is None:
+                fb = f.to(dt)
+        ctx.save_for_backward(fb, act, m0, m1, m2, packed_t, density, rgb)
+        ctx.meta = (N, S, NB, NW, E, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head))
+        return density, rgb
 
     @staticmethod
-    def backward(ctx, g_raw, g_y):
+    def backward(ctx, g_density, g_rgb):
         lib = _lib.load()
-        fb, eb, h0, x, h1, h2, m0, m1, m2, packed_t = ctx.saved_tensors
-        N, S, NB, NW, f_dt, w_dt, b_dt = ctx.meta
+        fb, act, m0, m1, m2, packed_t, density, rgb = ctx.saved_tensors
+        N, S, NB, NW, E, f_dt, w_dt, b_dt, head = ctx.meta
         dt, dev, M = torch.bfloat16, fb.device, fb.shape[0]
         with torch.autocast("cuda", enabled=False):
-            gy = g_y.to(dt).contiguous()
-            gr = None if g_raw is None else g_raw.reshape(-1).to(dt).contiguous()
+            g_rgb = torch.zeros(M, 3, device=dev) if g_rgb is None else g_rgb.reshape(M, 3).float().contiguous()
+            g_density = None if g_density is None else g_density.reshape(-1).float().contiguous()
             d1, d0, gx = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
+            dy = torch.empty(M, 4, device=dev, dtype=dt)
             gfeat = torch.empty(M, fb.shape[1], device=dev)
-            _lib.check(lib.ucn_train_bwd(gy.data_ptr(), _lib.ptr(gr), packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(),
-                                         N, S, fb.shape[1], d1.data_ptr(), d0.data_ptr(), gx.data_ptr(), gh0.data_ptr(),
-                                         gfeat.data_ptr(), _lib.stream()))
-            # weight gradients: split-K GEMMs on the stored pre-activation gradients; the direction blocks and biases
-            # reduce over rays first
-            r1 = d1.reshape(N, S, NW).sum(1)
-            r0 = d0.reshape(N, S, NW).sum(1)
-            gWr, gbr = _wgrad(gy, h2), _colsum(gy)
-            gW0 = torch.cat([_wgrad(d0, x), (r0.t() @ eb).float()], dim=1)
-            gW1 = torch.cat([_wgrad(d1, h1), _wgrad(d1, x), (r1.t() @ eb).float()], dim=1)
-            gb0, gb1 = r0.float().sum(0), r1.float().sum(0)
-            gWd1, gbd1 = _wgrad(gx, h0), _colsum(gx)
+            hd = (ctypes.c_float * 4)(*head)
+            _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
+                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, fb.shape[1],
+                                         d1.data_ptr(), d0.data_ptr(), gx.data_ptr(), gh0.data_ptr(), dy.data_ptr(), gfeat.data_ptr(),
+                                         _lib.stream()))
+            # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
+            # 302 + 119 us, tools/wgrad_bench.py); the 288-column GEMM of layer 0 is fine (255 us)
+            G1a, G1b = _wgrad_cols(d1, act, _ACT_H1, _ACT_AUX), _wgrad_cols(d1, act, _ACT_AUX, _ACT_AUX + 32)
+            G1 = torch.cat([G1a, G1b], dim=1)
+            G0 = _wgrad_cols(d0, act, _ACT_X, _ACT_AUX + 32)                  # [NW, NB + 32]
+            Gd1 = _wgrad_cols(gx, act, _ACT_AUX, ACT_LD)                      # [NB, 32 + 64]
+            Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)                  # [4, NW]
+            gW1, gb1 = G1[:, :NW + NB + E], G1[:, NW + NB + E]
+            gW0, gb0 = G0[:, :NB + E], G0[:, NB + E]
+            gWd1, gbd1 = Gd1[:, 32:], Gd1[:, E]
+            gWr, gbr = Gr[:3], _colsum(dy)[:3]
             gWd0, gbd0 = _wgrad(gh0, fb), _colsum(gh0)
         return (gfeat.to(f_dt), None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
-                gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None)
+                gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None)
 
 
 def _fusable_heads(mlp, feat):
@@ -396,11 +487,10 @@ def field_heads(mlp, feat, viewdirs, N, S):
     bias / direction-weight gradients reduce over rays instead of samples."""
     if _fusable_heads(mlp, feat) and os.environ.get("UCN_FUSED_HEADS", "1") == "1":
         d0, d1, l0, l1, lr = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1, mlp.rgb_layer
-        raw, y = _FusedHeads.apply(feat, view_encoding(viewdirs, mlp.deg_view), d0.weight, d0.bias, d1.weight, d1.bias, l0.weight,
-                                   l0.bias, l1.weight, l1.bias, lr.weight, lr.bias, N, S)
-        density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
-        rgb = torch.sigmoid(mlp.rgb_premultiplier * y.reshape(N, S, 3) + mlp.rgb_bias)
-        return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
+        density, rgb = _FusedHeads.apply(feat, view_encoding(viewdirs, mlp.deg_view), d0.weight, d0.bias, d1.weight, d1.bias,
+                                         l0.weight, l0.bias, l1.weight, l1.bias, lr.weight, lr.bias, N, S,
+                                         (mlp.density_bias, mlp.rgb_premultiplier, mlp.rgb_bias, mlp.rgb_padding))
+        return density.reshape(N, S), rgb.reshape(N, S, 3)
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
     if mlp.disable_rgb:
         return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)

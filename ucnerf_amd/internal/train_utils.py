@@ -113,29 +113,59 @@ class _InterLevel(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ losses (train.py:173-216)
+class LazyStats(dict):
+    """The stats dict of compute_data_loss with its device values fetched on first READ.  The reference converts every
+    level's mse with `.item()` inside the loss function (train_utils.py:187) -- a host sync in the middle of the step,
+    before the remaining losses and the whole backward are even queued; its loop first reads the stats after the
+    optimiser step (train.py:226).  Same keys, same numpy values, one transfer at that point instead."""
+
+    def _fetch(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, torch.Tensor):
+            v = v.detach().float().cpu().numpy()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def __getitem__(self, k):
+        return self._fetch(k)
+
+    def get(self, k, default=None):
+        return self._fetch(k) if k in self else default
+
+    def items(self):
+        return [(k, self._fetch(k)) for k in self.keys()]
+
+    def values(self):
+        return [self._fetch(k) for k in self.keys()]
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
+
 def compute_data_loss(batch, renderings, config):
-    """ref train_utils.py:171-230 ('mse' and 'charb')."""
-    stats = collections.defaultdict(list)
+    """ref train_utils.py:171-230 ('mse' and 'charb').  All levels in one set of elementwise / reduce launches (the
+    levels' rgb stacked), the per-level mse statistics handed back as LazyStats."""
     target = batch['rgb'][..., :3]
     lossmult = torch.broadcast_to(batch['lossmult'], target.shape)
     if getattr(config, 'disable_multiscale_loss', False):
         lossmult = torch.ones_like(lossmult)
     denom = lossmult.sum()
-    per_level = []
-    for r in renderings:
-        resid_sq = (r['rgb'] - target) ** 2
-        stats['mses'].append(((lossmult * resid_sq).sum() / denom).item())
-        kind = getattr(config, 'data_loss_type', 'charb')
-        if kind == 'mse':
-            term = resid_sq
-        elif kind == 'charb':
-            term = torch.sqrt(resid_sq + getattr(config, 'charb_padding', 0.001) ** 2)
-        else:
-            raise NotImplementedError(f"data_loss_type={kind!r}")
-        per_level.append((lossmult * term).sum() / denom)
-    loss = (getattr(config, 'data_coarse_loss_mult', 0.) * sum(per_level[:-1])
-            + getattr(config, 'data_loss_mult', 1.0) * per_level[-1])
-    return loss, {k: np.array(v) for k, v in stats.items()}
+    kind = getattr(config, 'data_loss_type', 'charb')
+    if kind not in ('mse', 'charb'):
+        raise NotImplementedError(f"data_loss_type={kind!r}")
+    n_lvl = len(renderings)
+    dims = tuple(range(1, target.dim() + 1))
+    resid_sq = (torch.stack([r['rgb'] for r in renderings]) - target) ** 2                # [levels, ...]
+    mses = (lossmult * resid_sq).sum(dim=dims) / denom
+    if kind == 'mse':
+        per_level = mses
+    else:
+        per_level = (lossmult * torch.sqrt(resid_sq + getattr(config, 'charb_padding', 0.001) ** 2)).sum(dim=dims) / denom
+    coarse = getattr(config, 'data_coarse_loss_mult', 0.)
+    loss = getattr(config, 'data_loss_mult', 1.0) * per_level[-1]
+    if coarse != 0 and n_lvl > 1:
+        loss = loss + coarse * per_level[:-1].sum()
+    return loss, LazyStats(mses=mses.detach())
 
 
 def anti_interlevel_loss(ray_history, config):
@@ -215,6 +245,7 @@ class FusedAdam(torch.optim.Adam):
         for group in self.param_groups:
             for p in group['params']:
                 if self._fusable(group, p):
+                    p._ucn_sanitised_by_optimizer = True         # sanitize_gradients may skip it from now on
                     held.append((group, p, p.grad))
                     p.grad = None                                # the parent skips parameters without a gradient
         try:
@@ -244,9 +275,30 @@ def clip_gradients(model, accelerator, config):
         accelerator.clip_grad_norm_(model.parameters(), config.grad_max_norm)
     if getattr(config, 'grad_max_val', 0) > 0 and accelerator.sync_gradients:
         accelerator.clip_grad_value_(model.parameters(), config.grad_max_val)
-    for param in model.parameters():
-        if param.grad is not None:
-            param.grad.nan_to_num_()
+    sanitize_gradients(model.parameters())
+
+
+def sanitize_gradients(params):
+    """`param.grad.nan_to_num_()` for every parameter (train_utils.py:342-344): the contiguous fp32 device gradients in ONE
+    launch (`ucn_nan_to_num_many`) instead of one per parameter; the tables a FusedAdam owns are skipped, its kernel
+    sanitises them in the same pass that steps them.  Anything else takes torch's op."""
+    import ctypes
+    small = []
+    for p in params:
+        g = p.grad
+        if g is None:
+            continue
+        if getattr(p, '_ucn_sanitised_by_optimizer', False) and g.is_cuda:
+            continue
+        if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.numel() < (1 << 31):
+            small.append(g)
+        else:
+            g.nan_to_num_()
+    if small:
+        lib = _lib.load()
+        ptrs = (ctypes.c_void_p * len(small))(*[g.data_ptr() for g in small])
+        cnts = (ctypes.c_uint64 * len(small))(*[g.numel() for g in small])
+        _lib.check(lib.ucn_nan_to_num_many(ptrs, cnts, len(small), _lib.stream()))
 
 
 def learning_rate_decay(step, lr_init, lr_final, max_steps, lr_delay_steps=0, lr_delay_mult=1):
