@@ -303,6 +303,20 @@ int ucn_train_bwd(const void *gy, const void *graw, const float *head, const flo
                   uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M,4] bf16 | NULL: the colour-logit
                   gradient consumed, for the rgb layer's weight gradient*/, float *gfeat, ucn_stream_t stream);
 
+/* The PROPOSAL field's dense part in training (models.py:507-516 with disable_rgb: Linear(F,64) + ReLU, Linear(64,1),
+ * softplus(raw + density_bias)), forward and backward, as VALU kernels (prop_train.hip) instead of ~45 library launches.
+ * feat [M,F] fp32 (F <= 16), W0 [64,F], b0 [64], w1 [64], b1 [1] = the module's fp32 parameters.  round_bf16 != 0: operands
+ * and layer outputs rounded to bf16 with fp32 accumulation (what accelerator.autocast() makes of these layers); 0: fp32.
+ * bwd: density = the forward's output, g_density its gradient; gfeat [M,F] | NULL; gW0 / gb0 / gw1 / gb1 fp32, summed in a
+ * fixed order (deterministic); workspace of ucn_prop_train_bwd_ws_floats(F, M) floats. */
+int ucn_prop_train_fwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,
+                       const float *b1, float density_bias, int round_bf16, uint64_t M, float *density, ucn_stream_t stream);
+uint64_t ucn_prop_train_bwd_ws_floats(uint32_t F, uint64_t M);
+int ucn_prop_train_bwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,
+                       const float *b1, float density_bias, int round_bf16, uint64_t M, const float *density,
+                       const float *g_density, float *gfeat, float *gW0, float *gb0, float *gw1, float *gb1, float *workspace,
+                       ucn_stream_t stream);
+
 /* ------------------------------------------------- ray generation
  * ref: camera_utils.py:448-557 pixels_to_rays (perspective pinhole, no distortion, no NDC) + :560-608
  * cast_ray_batch + datasets.py:421-447,476 (_make_ray_batch: cam_dirs, near/far/lossmult/cam_idx columns, the

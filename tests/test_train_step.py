@@ -608,3 +608,65 @@ def test_sanitize_gradients_is_nan_to_num_on_every_gradient():
     for p, w in zip(params[:-1], want):
         assert torch.equal(p.grad, w)
     assert params[-1].grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F_in,M", [(12, 64 * 128), (12, 1000), (5, 4097), (16, 2048)])
+def test_proposal_field_train_kernels(F_in, M, monkeypatch):
+    """ucn_prop_train_fwd / _bwd (the proposal field's Linear-ReLU-Linear-softplus of models.py:507-516 as VALU kernels)
+    against torch autograd on the same parameters: fp32 mode to accumulation-order rounding; bf16 mode against the same
+    formula with every operand / layer output rounded to bf16 (what autocast's GEMMs do), in float64 on the host."""
+    import torch.nn.functional as F
+    from ucnerf_amd.internal import train_graph as tg
+    g = torch.Generator().manual_seed(F_in * 1000 + M)
+    feat = torch.randn(M, F_in, generator=g)
+    W0, b0 = torch.randn(64, F_in, generator=g) * 0.4, torch.randn(64, generator=g) * 0.2
+    W1, b1 = torch.randn(1, 64, generator=g) * 0.3, torch.randn(1, generator=g) * 0.2
+    cd = torch.randn(M, generator=g)
+    bias = -0.7
+
+    def r16(t, on):
+        return t.to(torch.bfloat16).to(t.dtype) if on else t
+
+    for bf16 in (False, True):
+        # ---- reference: float64 autograd; the bf16 roundings as straight-through (round in forward, identity backward)
+        P = [t.double().requires_grad_(True) for t in (feat, W0, b0, W1, b1)]
+        f_, W0_, b0_, W1_, b1_ = P
+        rt = lambda t: t + (r16(t.detach().float(), bf16).double() - t.detach())
+        pre = rt(rt(f_) @ rt(W0_).t() + rt(b0_))
+        h = F.relu(pre)
+        raw = rt(h @ rt(W1_).t() + rt(b1_))
+        dens = F.softplus(raw[:, 0] + bias)
+        (dens * cd.double()).sum().backward()
+        # ---- HIP
+        Q = [t.cuda().requires_grad_(True) for t in (feat, W0, b0, W1, b1)]
+        d_gpu = tg._PropHeads.apply(Q[0], Q[1], Q[2], Q[3], Q[4], bias, bf16)
+        (d_gpu * cd.cuda()).sum().backward()
+        tol = 3e-2 if bf16 else 2e-5
+        assert float((d_gpu.detach().cpu().double() - dens.detach()).abs().max()) <= tol * max(1.0, float(dens.abs().max()))
+        for got, want, what in zip(Q, P, ("feat", "W0", "b0", "W1", "b1")):
+            gg, ww = got.grad.cpu().double().reshape(-1), want.grad.reshape(-1)
+            # a bias gradient is ONE sum of M signed terms (cancellation): its error is measured against the terms' norm
+            scale = float(ww.norm()) if what != "b1" else float((cd.double() * (1 - torch.exp(-dens.detach()))).norm())
+            rel = float((gg - ww).norm() / (scale + 1e-30))
+            # bf16: the backward's own roundings (g_raw, g_h, d feat to bf16) are not in the straight-through reference
+            assert rel <= (2e-2 if bf16 else 2e-5), (bf16, what, rel)
+    # the training graph takes this path for the proposal field
+    spec = rm.make_spec("tiny")
+    model, _ = hip_model_for(spec, rm.init_state(spec, seed=9))
+    mlp = model.prop_mlp_0
+    Fp = mlp.encoder.num_levels * mlp.encoder.level_dim
+    fp = torch.randn(4 * 64, Fp, device="cuda").requires_grad_(True)
+    assert tg._fusable_prop(mlp, fp)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("UCN_FUSED_HEADS", fused)
+        mlp.zero_grad(set_to_none=True)
+        fp.grad = None
+        d, _ = tg.field_heads(mlp, fp, None, 4, 64)
+        d.square().sum().backward()
+        outs[fused] = (d.detach().clone(), fp.grad.clone(), [p.grad.clone() for n, p in mlp.named_parameters() if "encoder" not in n])
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 1e-5
+    assert float((outs["1"][1] - outs["0"][1]).abs().max()) <= 1e-5 * max(1.0, float(outs["0"][1].abs().max()))
+    for a, b in zip(outs["1"][2], outs["0"][2]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

@@ -17,6 +17,7 @@ for f in sorted(glob.glob(os.environ.get("PMC_GLOB", "gpurun_out/pmc_*/p_counter
             dur[n][0] += 1
             dur[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 want = sys.argv[1:] or sorted({k for k in dur if k.startswith(("k_march_features<", "k_field_mlp_h", "k_field_mlp<"))})
+want = [k for w in want for k in sorted(dur) if k == w or k.startswith(w + "<")]
 for k in want:
     if dur[k][0] == 0:
         continue

@@ -81,6 +81,10 @@ SIGNATURES = {
     "ucn_bias_relu": [c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_relu_backward_reduce": [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_nan_to_num_many": [c_vp, c_vp, c_u32, c_vp],
+    "ucn_prop_train_fwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_vp],
+    "ucn_prop_train_bwd_ws_floats": [c_u32, c_u64],
+    "ucn_prop_train_bwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                           c_vp, c_vp],
     "ucn_train_fwd_fragments": [],
     "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp,
                       ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -95,7 +99,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
-             "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64}
+             "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64,
+             "ucn_prop_train_bwd_ws_floats": c_u64}
 
 _lib = None
 

@@ -470,6 +470,47 @@ class _FusedHeads(torch.autograd.Function):
                 gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None)
 
 
+class _PropHeads(torch.autograd.Function):
+    """The proposal field's dense part (models.py:507-516, disable_rgb: Linear(F,64) + ReLU, Linear(64,1), softplus) as
+    three HIP launches forward + backward (`ucn_prop_train_fwd / _bwd`, prop_train.hip) instead of ~45 library ones.
+    Under autocast the kernels round operands and layer outputs to bf16 like the library GEMMs would."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feat, W0, b0, W1, b1, density_bias, bf16):
+        lib = _lib.load()
+        feat, W0, b0, W1, b1 = (t.contiguous() for t in (feat, W0, b0, W1, b1))
+        M, F_in = feat.shape
+        density = torch.empty(M, device=feat.device)
+        _lib.check(lib.ucn_prop_train_fwd(feat.data_ptr(), F_in, W0.shape[0], W0.data_ptr(), b0.data_ptr(), W1.data_ptr(), b1.data_ptr(),
+                                          float(density_bias), int(bf16), M, density.data_ptr(), _lib.stream()))
+        ctx.save_for_backward(feat, W0, b0, W1, b1, density)
+        ctx.consts = (float(density_bias), int(bf16))
+        return density
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_density):
+        lib = _lib.load()
+        feat, W0, b0, W1, b1, density = ctx.saved_tensors
+        M, F_in = feat.shape
+        g = g_density.reshape(-1).float().contiguous()
+        gfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        gW0, gb0, gW1, gb1 = torch.empty_like(W0), torch.empty_like(b0), torch.empty_like(W1), torch.empty_like(b1)
+        ws = torch.empty(lib.ucn_prop_train_bwd_ws_floats(F_in, M), device=feat.device)
+        _lib.check(lib.ucn_prop_train_bwd(feat.data_ptr(), F_in, W0.shape[0], W0.data_ptr(), b0.data_ptr(), W1.data_ptr(), b1.data_ptr(),
+                                          *ctx.consts, M, density.data_ptr(), g.data_ptr(), _lib.ptr(gfeat), gW0.data_ptr(),
+                                          gb0.data_ptr(), gW1.data_ptr(), gb1.data_ptr(), ws.data_ptr(), _lib.stream()))
+        return gfeat, gW0, gb0, gW1, gb1, None, None
+
+
+def _fusable_prop(mlp, feat):
+    l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
+    return (mlp.disable_rgb and len(mlp.density_layer) == 3 and feat.is_cuda and feat.shape[1] <= 16 and l0.out_features == 64
+            and l1.out_features == 1 and l0.bias is not None and l1.bias is not None
+            and (not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") == torch.bfloat16))
+
+
 def _fusable_heads(mlp, feat):
     return (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 and not mlp.disable_rgb
             and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and feat.shape[1] <= 64
@@ -491,6 +532,10 @@ def field_heads(mlp, feat, viewdirs, N, S):
                                          l0.weight, l0.bias, l1.weight, l1.bias, lr.weight, lr.bias, N, S,
                                          (mlp.density_bias, mlp.rgb_premultiplier, mlp.rgb_bias, mlp.rgb_padding))
         return density.reshape(N, S), rgb.reshape(N, S, 3)
+    if _fusable_prop(mlp, feat) and os.environ.get("UCN_FUSED_HEADS", "1") == "1":
+        l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
+        density = _PropHeads.apply(feat, l0.weight, l0.bias, l1.weight, l1.bias, mlp.density_bias, torch.is_autocast_enabled())
+        return density.reshape(N, S), torch.zeros(N, S, 3, device=feat.device)
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
     if mlp.disable_rgb:
         return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)
