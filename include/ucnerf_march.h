@@ -104,7 +104,9 @@ int ucn_field_pack(const ucn_field_t *f, ucn_stream_t stream);
 /* ref: stepfun.py:75-105 max_dilate_weights + models.py:168-191 (trim, anneal, logits) +
  * stepfun.py:251-294 sample_intervals.  n_prev == 0 selects the first level (sdist=[0,1], w=[1]).
  * u_table: DEVICE [S] = the linspace of stepfun.py:206 (eval) or :215 (train).
- * jitter : NULL (eval) or DEVICE [N, jitter_cols] U[0,1) draws (stepfun.py:216). */
+ * jitter : NULL (eval) or DEVICE [N, jitter_cols] U[0,1) draws (stepfun.py:216).
+ * dilation <= 0 selects the reference's use_dilation == False branch (models.py:167-168, both dilation knobs 0): the
+ * previous fenceposts / weights are resampled as they are (no envelope, no trim, no renormalisation). */
 int ucn_resample(const float *sdist_prev /*[N,n_prev+1]*/, const float *weights_prev /*[N,n_prev]*/,
                  uint32_t n_prev, float dilation, float anneal, float resample_padding,
                  const float *u_table, const float *jitter, uint32_t jitter_cols, float max_jitter,

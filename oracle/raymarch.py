@@ -395,7 +395,7 @@ def model_forward(spec: PathSpec, sd, batch, noise: List[LevelNoise], train_frac
         S = spec.num_prop_samples if is_prop else spec.num_nerf_samples
         dilation = spec.dilation_bias + spec.dilation_multiplier * 1.0 / prod       # :158-159
         prod *= S
-        if lvl > 0:
+        if lvl > 0 and (spec.dilation_bias > 0 or spec.dilation_multiplier > 0):               # :167-168 use_dilation
             sdist, weights = dilate_weights(sdist, weights, dilation, 0., 1.)
             sdist, weights = sdist[..., 1:-1], weights[..., 1:-1]
         anneal = (spec.anneal_slope * train_frac) / ((spec.anneal_slope - 1) * train_frac + 1)

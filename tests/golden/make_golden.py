@@ -18,6 +18,7 @@ Fixture index:
   model_sky.npz     G8 + sky NeRF + brightness correction (eval_camidx)
   model_train.npz   G7' Model.forward with rand=True (all draws captured), train_frac<1
   model_tiny64.npz  G7 Model.forward eval, BASELINE configs[0] architecture (64+64, 64-wide colour MLP)  [`cfg1` mode]
+  model_nodilate.npz G7 Model.forward eval with dilation_bias = dilation_multiplier = 0 (use_dilation False)  [`nodilate` mode]
   render_image.npz  G9 render_image on a 16x24 frame incl. a ragged last chunk
 """
 import os
@@ -317,6 +318,11 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cfg1':
         # G7 for BASELINE configs[0]'s architecture (64 + 64 samples, 64-wide colour MLP), small tables
         save('model_tiny64.npz', **npify(run_model(ref, rm.make_spec('tiny64'), 61, 48, 62, False)))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'nodilate':
+        # G7 with both dilation knobs 0: the reference's use_dilation == False branch (models.py:167-168)
+        save('model_nodilate.npz', **npify(run_model(ref, rm.make_spec('tiny', dilation_bias=0., dilation_multiplier=0.),
+                                                     63, 48, 64, False)))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         gen_train_step(ref, 'train_step.npz', rm.make_spec('tiny'), 71)

@@ -154,7 +154,8 @@ def build_reference_model(ref, spec, sd):
     try:
         model = m.Model(config=cfg, num_levels=spec.num_levels, num_prop_samples=spec.num_prop_samples,
                         num_nerf_samples=spec.num_nerf_samples, opaque_background=spec.opaque_background,
-                        prop_desired_grid_size=list(spec.prop_desired_grid_size))
+                        prop_desired_grid_size=list(spec.prop_desired_grid_size),
+                        dilation_bias=spec.dilation_bias, dilation_multiplier=spec.dilation_multiplier)
     finally:
         for (cls, k), v in saved.items():
             setattr(cls, k, v)

@@ -74,7 +74,8 @@ def hip_model(spec, sd, device="cuda", **model_kw):
     with models.bindings(NerfMLP=fkw(spec.nerf), PropMLP=fkw(spec.props[0])):
         model = models.Model(config=cfg, num_levels=spec.num_levels, num_prop_samples=spec.num_prop_samples,
                              num_nerf_samples=spec.num_nerf_samples, opaque_background=spec.opaque_background,
-                             prop_desired_grid_size=list(spec.prop_desired_grid_size), **model_kw)
+                             prop_desired_grid_size=list(spec.prop_desired_grid_size),
+                             dilation_bias=spec.dilation_bias, dilation_multiplier=spec.dilation_multiplier, **model_kw)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     assert all(k.endswith(".idx") for k in missing), missing

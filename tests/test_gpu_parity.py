@@ -323,6 +323,7 @@ def test_field_vs_golden():
     ("model_tiny64.npz", "tiny64", {}),                       # BASELINE configs[0] architecture: 64-wide colour MLP
     ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
     ("model_train.npz", "tiny", {}),
+    ("model_nodilate.npz", "tiny", dict(dilation_bias=0., dilation_multiplier=0.)),   # models.py:167 use_dilation False
 ])
 def test_model_forward_vs_golden(name, kind, over):
     fx = H.load(name)

@@ -84,6 +84,7 @@ def test_g6_alpha_and_composite():
     ("model_tiny64.npz", "tiny64", {}),
     ("model_sky.npz", "tiny", dict(model_sky=True, brightness_correction=True)),
     ("model_train.npz", "tiny", {}),
+    ("model_nodilate.npz", "tiny", dict(dilation_bias=0., dilation_multiplier=0.)),
 ])
 def test_g7_g8_model_forward(name, kind, over):
     fx = H.load(name)

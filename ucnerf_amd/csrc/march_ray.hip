@@ -77,7 +77,14 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
     const float *sd;                                     // fenceposts actually resampled (after the [1:-1] trim)
     const float *w;
     uint32_t nw;
-    {
+    if (!(dilation > 0.0f)) {
+        // models.py:167-168 use_dilation == False (both dilation knobs 0): the previous level's fenceposts and weights
+        // are resampled as they are -- no envelope, no [1:-1] trim, no renormalisation
+        for (uint32_t i = lane; i <= n; i += 64) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
+        for (uint32_t i = lane; i < n; i += 64) wt[i] = w_prev[(size_t)ray * n + i];
+        sd = t; w = wt; nw = n;
+        __syncthreads();
+    } else {
         for (uint32_t i = lane; i <= n; i += 64) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
         __syncthreads();
         for (uint32_t i = lane; i < n; i += 64)

@@ -435,6 +435,8 @@ class Model(nn.Module):
             if is_prop and S * L * C < nerf_row:
                 chunk = max(nerf_chunk, min(nerf_chunk * nerf_row // (S * L * C) // 256 * 256, 1 << 16))
             dilation = self.dilation_bias + self.dilation_multiplier * 1.0 / prod_num_samples
+            if not (self.dilation_bias > 0 or self.dilation_multiplier > 0):
+                dilation = 0.0                                           # ref :167 use_dilation False: resample undilated
             prod_num_samples *= S
             # ---- random draws, in the reference's order (stepfun.py:216, render.py:123,124,140)
             jitter = flip = spin = None

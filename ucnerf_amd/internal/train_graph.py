@@ -695,6 +695,8 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         S = model.num_prop_samples if is_prop else model.num_nerf_samples
         mlp = model.get_submodule(f'prop_mlp_{i_level}') if is_prop else model.nerf_mlp
         dilation = model.dilation_bias + model.dilation_multiplier * 1.0 / prod
+        if not (model.dilation_bias > 0 or model.dilation_multiplier > 0):
+            dilation = 0.0                                               # ref models.py:167 use_dilation False
         prod *= S
         jitter = flip = spin = None
         u_tab, max_jitter = _u_table(S, bool(rand), dev)
