@@ -330,6 +330,9 @@ def main():
                     help="Model.compact_min_weight: early-termination sample compaction (colour layers only for samples whose "
                          "compositing weight reaches this value; 4e-8 bounds the pixel error by 5e-6).  Default off: on the random-init "
                          "field AND on a fitted one every sample carries weight (tools/fit_scene.py, DESIGN.md)")
+    ap.add_argument("--ray-tile", type=int, default=8,
+                    help="config.render_ray_tile: render_image marches the frame in tile-major order (T x T pixel blocks per "
+                         "wave; 1 = the frame's row-major order)")
     ap.add_argument("--sky-skip", type=float, default=0.0,
                     help="Model.sky_min_background (with --cfg5): sky layer only for rays whose background weight reaches this "
                          "value.  Default off: the reference returns sky_rgbs for every ray, and on the random-init field "
@@ -381,6 +384,7 @@ def main():
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     model.compact_min_weight = args.compact
     model.sky_min_background = args.sky_skip
+    cfg.render_ray_tile = args.ray_tile
     batch = frame_rays(device, args.cameras, virtual=args.cfg5)
     n_rays = args.cameras * H_IMG * W_IMG
     g = torch.Generator().manual_seed(1)
@@ -474,7 +478,7 @@ def main():
             "config": {"workload": workload, "rays_per_step": n_rays, "cameras": args.cameras,
                        "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
                                  else "random-init weights, tables U(-1,1) (BASELINE configs)"),
-                       "compact_min_weight": args.compact,
+                       "compact_min_weight": args.compact, "ray_tile": args.ray_tile,
                        **({"sky_min_background": args.sky_skip,
                            "sky_rays_kept": getattr(model, "_sky_kept", None)} if args.cfg5 else {}),
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",

@@ -630,6 +630,15 @@ def test_render_image_vs_golden_and_invariants():
     assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
     assert H.maxdiff(w.sum(-1).cpu(), out["acc"].cpu()) <= 1e-5
     assert (out["rgb"] >= -0.001 - 1e-5).all() and (out["rgb"] <= 1.001 + 1e-5).all()
+    # the marching order of the frame's rays (config.render_ray_tile: T x T pixel blocks per wave; the 16 x 24 frame has
+    # ragged blocks for T = 5) is pure scheduling: every per-pixel output is bit-identical to the row-major march
+    ref = dict(out)
+    for T in (1, 5, 16):
+        cfg.render_ray_tile = T
+        again = models.render_image(model, OneProc(), batch, False, 1.0, cfg, verbose=False)
+        for k in ("rgb", "depth", "acc", "weights", "distance_mean", "distance_median"):
+            assert torch.equal(again[k], ref[k]), (T, k)
+    cfg.render_ray_tile = 8
 
 
 def test_product_raises_without_device_tensors():

@@ -251,3 +251,17 @@ def test_data_loss_levels_and_lazy_stats():
             assert isinstance(dict.__getitem__(stats, 'mses'), torch.Tensor)         # not fetched yet
             assert isinstance(stats['mses'], np.ndarray) and np.allclose(stats['mses'], mses, atol=1e-6)
             assert isinstance(dict.__getitem__(stats, 'mses'), np.ndarray) and list(stats.keys()) == ['mses']
+
+
+def test_tile_order_is_a_permutation_of_the_frame_in_blocks():
+    """models._tile_order: every pixel once, T x T blocks contiguous (ragged at the edges), inverse undoes it."""
+    from ucnerf_amd.internal import models
+    for Hh, Ww, T in ((16, 24, 8), (7, 13, 4), (8, 8, 8), (3, 50, 8)):
+        perm, inv = models._tile_order(Hh, Ww, T, "cpu")
+        assert sorted(perm.tolist()) == list(range(Hh * Ww))
+        assert torch.equal(perm[inv], torch.arange(Hh * Ww)) and torch.equal(inv[perm], torch.arange(Hh * Ww))
+        r, c = perm // Ww, perm % Ww
+        block = (r // T) * ((Ww + T - 1) // T) + c // T
+        assert bool((block[1:] >= block[:-1]).all())                      # blocks are contiguous runs
+        first = perm[:min(T, Ww)]
+        assert first.tolist() == list(range(min(T, Ww)))                 # row-major inside the first block

@@ -16,3 +16,4 @@ class Config:
     render_chunk_size: int = 15000          # waymo.gin:8 (kept for API parity; the HIP path sizes its own passes)
     near: float = 0.                        # waymo.gin:2
     far: float = 8.                         # waymo.gin:3
+    render_ray_tile: int = 8                # not in the reference: render_image marches T x T pixel blocks per wave (1 = row order)

@@ -655,6 +655,28 @@ def unwrap_model(model):
     return model
 
 
+_TILE_ORDER = {}
+
+
+def _tile_order(height, width, tile, device):
+    """(perm, inv) int64 [H*W]: the frame's pixels in tile-major order (tile x tile pixel blocks, row-major inside a block
+    and over the blocks; ragged blocks at the right / bottom edge) and the inverse permutation."""
+    key = (height, width, tile, str(device))
+    hit = _TILE_ORDER.get(key)
+    if hit is None:
+        r = torch.arange(height).reshape(-1, 1).expand(height, width)
+        c = torch.arange(width).reshape(1, -1).expand(height, width)
+        block = (r // tile) * ((width + tile - 1) // tile) + c // tile
+        inside = (r % tile) * tile + c % tile
+        perm = torch.argsort((block * (tile * tile) + inside).reshape(-1), stable=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        if len(_TILE_ORDER) > 8:
+            _TILE_ORDER.clear()
+        hit = _TILE_ORDER[key] = (perm.to(device), inv.to(device))
+    return hit
+
+
 def render_image(model, accelerator, batch, rand, train_frac, config, verbose=True, return_weights=False,
                  eval_camidx=0):
     """ref models.py:907-1007: render every pixel of an [H, W, .] ray batch.
@@ -674,6 +696,15 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     height, width = batch['origins'].shape[:2]
     num_rays = height * width
     flat = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None and torch.is_tensor(v)}
+    # Rays are marched in TILE-major order (8 x 8 pixel blocks): a wave's 64 lanes are then the rays of one block, whose
+    # samples at one depth index sit within ~8 pixel footprints of each other in BOTH image directions -- on the hash
+    # grid's coarse and middle levels they share lattice cells, i.e. cache lines, and the gather's requests coalesce
+    # (a 64 x 1 pixel row spreads 8x further).  Pixels do not depend on the order; the outputs are put back below.
+    tile = int(getattr(config, 'render_ray_tile', 8))
+    perm = inv = None
+    if tile > 1 and height > 1 and width > 1 and flat['origins'].is_cuda:
+        perm, inv = _tile_order(height, width, tile, flat['origins'].device)
+        flat = {k: v.index_select(0, perm) for k, v in flat.items()}
     world = getattr(accelerator, 'num_processes', 1)
     rank = getattr(accelerator, 'process_index', 0)
     lo, hi = udist.shard_bounds(num_rays, world, rank)
@@ -696,6 +727,8 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
         shapes['weights'] = tuple(history[-1]['weights'].shape[1:])
         shapes['coord'] = tuple(history[-1]['coord'].shape[1:])
     gathered = udist.all_gather_rows(local, num_rays, world, rank)
+    if inv is not None:
+        gathered = {k: v.index_select(0, inv) for k, v in gathered.items()}
     rendering = {k: gathered[k].reshape((height, width) + shapes[k]) for k in gathered}
     # 'ray_*' bundles: vis_num_rays rays per level, drawn like the reference's final randperm subset
     bundle_keys = [k for k in last if k.startswith('ray_')]
