@@ -263,6 +263,9 @@ extern "C" int ucn_field_mlp(const ucn_field_t *f, const float *features, uint32
     a.dir_bias = dir_bias; a.density = density_out; a.rgb = rgb_out; a.bott = bottleneck_out;
     UCN_REQUIRE(!(rays_fastest & 1) || B % samples_per_ray == 0, "field_mlp: B must be rays x samples_per_ray");
     a.B = B; a.spr = samples_per_ray; a.C = f->level_dim; a.F = pl.F;
+    a.cshift = 0xFFu;
+    if ((a.C == 1 || a.C == 2 || a.C == 4 || a.C == 8) && (uint64_t)B * a.C * (pl.F / a.C + 2) < (1ull << 30))
+        a.cshift = a.C == 1 ? 0u : a.C == 2 ? 1u : a.C == 4 ? 2u : 3u;
     a.n_rays = B / samples_per_ray; a.rays_fastest = (rays_fastest & 1) ? 1u : 0u;
     a.small_ring = (rays_fastest & UCN_LAUNCH_CORESIDENT) ? 1u : 0u;
     a.idx = g_mlp_idx; a.count = g_mlp_count;

@@ -313,13 +313,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
 
     // ---- the wave's only global loads: its feature values and the ray's direction tile
     float fv[kKS][8];
-#pragma unroll
-    for (int s = 0; s < kKS; s++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t k = 16u * s + 8u * h + e, l = k / a.C, c = k - l * a.C;
-            fv[s][e] = k < a.F ? a.feat[((size_t)l * a.B + b) * a.C + c] : 0.0f;
-        }
+    load_features<kKS>(a, b, h, fv);
     f32x16 ev;
     if constexpr (RGB) {
         const float4 *ep = reinterpret_cast<const float4 *>(a.dir_bias + (size_t)ray_index(a, b) * 32 + 4 * h);
@@ -498,13 +492,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void k_field_mlp_h8(MlpArgs a) {
     constexpr int NG = GB + NP * PB;
 
     float fv[kKS][8];
-#pragma unroll
-    for (int s = 0; s < kKS; s++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t k = 16u * s + 8u * h + e, l = k / a.C, c = k - l * a.C;
-            fv[s][e] = k < a.F ? a.feat[((size_t)l * a.B + b) * a.C + c] : 0.0f;
-        }
+    load_features<kKS>(a, b, h, fv);
     f32x16 ev;
     {
         const float4 *ep = reinterpret_cast<const float4 *>(a.dir_bias + (size_t)ray_index(a, b) * 32 + 4 * h);

@@ -69,12 +69,45 @@ struct MlpArgs {
     const float *dir_bias;    // mode 0: [rays][2][NW] per-ray biases; mode 1: [rays][32] direction encoding + 1.0
     float *density, *rgb, *bott;
     uint32_t B, spr, C, F, n_chunks;
+    uint32_t cshift;                 // log2(C) when C is 1, 2, 4 or 8 and the features span < 4 GiB (load_features), else 0xFF
     uint32_t n_rays, rays_fastest;   // rays_fastest: feature index b = s*n_rays + ray (else ray*spr + s)
     uint32_t small_ring;             // mode 1: 64 KiB weight ring (co-resident launches)
     const uint32_t *idx, *count;     // compacted colour pass: tile slot i evaluates sample idx[i], i < *count (else NULL)
     uint64_t p0, pstream, phead;
     float density_bias, rgb_premult, rgb_bias, rgb_padding;
 };
+
+// The wave's feature values from feat [L][B][C]: lane (j, h) supplies k = 16 s + 8 h + e of its sample b.  For C in
+// {1, 2, 4, 8} (8 % C == 0) the (level, channel) of k splits into a wave-uniform part -- s, e: scalar arithmetic, a scalar
+// base pointer per element -- and ONE per-lane byte offset shared by all elements: no vector integer work per load.
+// (The general form below divides k by C per element: 35 u32 divisions, ~650 of the 2860 VALU instructions a tile of the
+// NeRF-level kernel issued.  Removing them did not move the kernel time -- 167-171 ms per frame before and after: the
+// prologue of one workgroup runs under the MFMA phase of the other one on the CU -- so this is tidiness, not speed.)
+template <int KS>
+__device__ __forceinline__ void load_features(const MlpArgs &a, uint32_t b, int h, float (&fv)[KS][8]) {
+    if (a.cshift != 0xFFu) {
+        const uint32_t BC = a.B * a.C, cm = a.C - 1u;
+        const uint32_t mine = b * a.C + (uint32_t)h * ((8u >> a.cshift) * BC);          // elements; < 2^30 (host check)
+        const bool whole = (a.F & 15u) == 0u;                                            // then k < F is wave-uniform
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t kk = 16u * s + e;
+                const float *row = a.feat + ((size_t)(kk >> a.cshift) * BC + (kk & cm));     // uniform
+                const bool ok = whole ? kk < a.F : kk + 8u * h < a.F;
+                fv[s][e] = ok ? row[mine] : 0.0f;
+            }
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; s++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t k = 16u * s + 8u * h + e, l = k / a.C, c = k - l * a.C;
+            fv[s][e] = k < a.F ? a.feat[((size_t)l * a.B + b) * a.C + c] : 0.0f;
+        }
+}
 
 // feature index b -> ray and -> position in the [N,S]-shaped outputs
 __device__ __forceinline__ uint32_t ray_index(const MlpArgs &a, uint32_t b) {
