@@ -66,12 +66,22 @@ __device__ __forceinline__ f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 // hi = f16(v), lo = f16(v - hi): |v - hi - lo| <= 2^-22 |v| while lo is a normal f16 (|v| >= 2^-3); the packers'
 // power-of-two scaling (field_mlp_h.hip) keeps the operands in that window and below the f16 maximum.
 __device__ __forceinline__ void rsplit8(const float (&v)[8], h8 &hi, h8 &lo) {
+    // three VALU instructions per PAIR of values instead of six: hi pair = v_cvt_pk_f16_f32; each lo = f16(v - hi) is
+    // ONE v_fma_mix{lo,hi}_f16 (f16 source hi, f32 constant -1, f32 source v: the exact difference rounded once, into its
+    // half of the pair) -- no conversion of hi back to f32, no separate subtraction, no second pack
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    uint32_t hw[4], lw[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(v[e] - (float)h);
+    for (int p = 0; p < 4; p++) {
+        h2 hp;
+        hp[0] = (_Float16)v[2 * p];
+        hp[1] = (_Float16)v[2 * p + 1];
+        hw[p] = __builtin_bit_cast(uint32_t, hp);
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lw[p]) : "v"(hw[p]), "v"(v[2 * p]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw[p]) : "v"(hw[p]), "v"(v[2 * p + 1]));
     }
+    hi = __builtin_bit_cast(h8, hw);
+    lo = __builtin_bit_cast(h8, lw);
 }
 // ReLU as ONE v_max_i32 on the bit pattern: negative floats (and -0) are negative integers.  fmaxf costs two VALU
 // instructions here (IEEE mode canonicalises the MFMA result first).  A negative NaN becomes 0, a positive one stays.
