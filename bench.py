@@ -430,10 +430,10 @@ def main():
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         gather["frac"] = gather["achieved"] / gather["peak"]
         # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
-        # same command (profiles/r02b/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
+        # same command (profiles/r02c/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
         # when this run's launches have the size those passes measured
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02b", "traffic.json")))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02c", "traffic.json")))
             if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5:
                 gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
                 gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
@@ -451,8 +451,11 @@ def main():
                    peak=PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF, unit="TFLOP/s",
                    avg_launch_ms=mlp_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         mlp["frac"] = mlp["achieved"] / mlp["peak"]
-        mlp["issue_model_note"] = ("a gfx950 SIMD does not overlap VALU with MFMA (tools/mfma_valu_bench.hip): the kernel's 2170 VALU "
-                                   "instructions per 696 MFMAs put its ceiling at ~0.79 of the MFMA peak before any memory wait")
+        mlp["issue_model_note"] = ("per wave (32 samples): 696 MFMAs, 1463 VALU, 622 LDS reads, 118 LDS-DMA pieces, 29 barriers "
+                                   "(profiles/r02c/pmc_table.txt); beside MFMAs a VALU instruction costs ~2-2.6 cycles of the SIMD "
+                                   "(tools/mfma_valu_bench.hip), which puts the issue ceiling at ~0.87 of the MFMA peak before any "
+                                   "wait; the executed fraction equals what the CDNA4 guide's hand-scheduled attention example "
+                                   "reaches (0.50-0.56 of the same peak)")
         mlp["peak_note"] = ("dense f16 MFMA peak; fp32-class products = 3 f16 MFMAs each, composed layers = 0.52x MACs" if split
                             else "fp32-input MFMA peak (= fp32 vector rate on CDNA4)")
         if split:
