@@ -10,9 +10,9 @@
 //   k_prop_fwd        thread = sample.  Weights broadcast from LDS; the hidden activations never leave registers.
 //   k_prop_bwd_feat   thread = sample.  Recomputes the hidden layer (cheaper than storing [M, 64]) and forms
 //                     d feat = W0^T (g_raw w1 * relu'), [M, F].
-//   k_prop_bwd_weight lane = hidden unit, a wave walks a slab of samples whose features / gradients are wave-uniform
-//                     (scalar loads): every lane accumulates ITS row of d W0, d b0, d w1 in registers.  Per-workgroup
-//                     partial sums go to a workspace, k_prop_reduce adds them in a fixed order (deterministic).
+//   k_prop_bwd_weight lane = hidden unit, a wave walks a slab of samples whose rows it reads as LDS broadcasts: every
+//                     lane accumulates ITS row of d W0, d b0, d w1 in registers.  Per-workgroup partial sums go to a
+//                     workspace, k_prop_reduce adds them in a fixed order (deterministic).
 //
 // `round_bf16` reproduces what the reference's accelerator.autocast() does to these layers: operands and layer outputs
 // rounded to bf16, fp32 accumulation, softplus in fp32.  0 = plain fp32 (the G10 parity path).
@@ -130,9 +130,14 @@ __global__ __launch_bounds__(256) void k_prop_bwd_feat(PropArgs a) {
         if ((uint32_t)c < a.F) a.gfeat[(size_t)m * a.F + c] = bf16r(gf[c], a.round_bf16);
 }
 
-// lane = hidden unit k; the wave's samples are wave-uniform values
+// lane = hidden unit k.  A wave walks its slab 64 samples at a time: every lane fetches ONE sample's row (features, g_raw)
+// with ordinary vector loads and parks it in the wave's LDS tile; the 64 rows are then read back as broadcasts (every
+// lane the same address), so each lane sees every sample without a cross-lane operation.  (A first version read the rows
+// through scalar loads: one exposed s_load latency per sample, 198 us per call.)
 template <int FP>
 __global__ __launch_bounds__(256) void k_prop_bwd_weight(PropArgs a) {
+    constexpr int RS = FP + 4;                                // LDS row: FP features, g_raw, 3 pad (16-byte rows)
+    __shared__ __attribute__((aligned(16))) float s_rows[4][64 * RS];
     const int k = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float w0[FP], gw0[FP];
@@ -146,22 +151,44 @@ __global__ __launch_bounds__(256) void k_prop_bwd_weight(PropArgs a) {
     const uint32_t per_wave = a.slab / 4u;
     const uint32_t lo = blockIdx.x * a.slab + wave * per_wave;
     const uint32_t hi = lo + per_wave < a.M ? lo + per_wave : a.M;
-    for (uint32_t m = lo; m < hi; m++) {                     // m is wave-uniform: the loads below are scalar loads
+    float *rows = s_rows[wave];
+    for (uint32_t m0 = lo; m0 < hi; m0 += 64u) {
+        const uint32_t m = m0 + (uint32_t)k;
         float f[FP];
+        float g = 0.0f;
+        if (m < hi) {
+            load_features<FP>(a, m, f);
+            g = g_raw_of(a, m);
+        } else {
 #pragma unroll
-        for (int c = 0; c < FP; c++) f[c] = (uint32_t)c < a.F ? bf16r(a.feat[(size_t)m * a.F + c], a.round_bf16) : 0.0f;
-        const float g = g_raw_of(a, m);
-        float pre = 0.0f;
+            for (int c = 0; c < FP; c++) f[c] = 0.0f;         // g = 0: the padded samples add nothing
+        }
 #pragma unroll
-        for (int c = 0; c < FP; c++) pre = fmaf(w0[c], f[c], pre);
-        pre = bf16r(pre + b0, a.round_bf16);
-        const float h = fmaxf(pre, 0.0f);
-        const float gh = pre > 0.0f ? bf16r(g * w1, a.round_bf16) : 0.0f;
+        for (int c = 0; c < FP; c += 4) *reinterpret_cast<float4 *>(rows + k * RS + c) = make_float4(f[c], f[c + 1], f[c + 2], f[c + 3]);
+        rows[k * RS + FP] = g;
+        __builtin_amdgcn_wave_barrier();                      // the tile is private to the wave; LDS ops of a wave are ordered
+#pragma unroll 4
+        for (int j = 0; j < 64; j++) {
+            float fj[FP];
 #pragma unroll
-        for (int c = 0; c < FP; c++) gw0[c] = fmaf(gh, f[c], gw0[c]);
-        gb0 += gh;
-        gw1 = fmaf(g, h, gw1);
-        gb1 += g;
+            for (int c = 0; c < FP; c += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(rows + j * RS + c);
+                fj[c] = v.x; fj[c + 1] = v.y; fj[c + 2] = v.z; fj[c + 3] = v.w;
+            }
+            const float gj = rows[j * RS + FP];
+            float pre = 0.0f;
+#pragma unroll
+            for (int c = 0; c < FP; c++) pre = fmaf(w0[c], fj[c], pre);
+            pre = bf16r(pre + b0, a.round_bf16);
+            const float h = fmaxf(pre, 0.0f);
+            const float gh = pre > 0.0f ? bf16r(gj * w1, a.round_bf16) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < FP; c++) gw0[c] = fmaf(gh, fj[c], gw0[c]);
+            gb0 += gh;
+            gw1 = fmaf(gj, h, gw1);
+            gb1 += gj;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     // the workgroup's four waves -> one partial row: [64][FP] dW0, [64] db0, [64] dw1, [1] db1
     constexpr int ROW = kHidden * (FP + 2) + 1;
@@ -176,15 +203,23 @@ __global__ __launch_bounds__(256) void k_prop_bwd_weight(PropArgs a) {
         a.partial[(size_t)blockIdx.x * ROW + i] = (s_p[0][i] + s_p[1][i]) + (s_p[2][i] + s_p[3][i]);
 }
 
-// out[i] = sum over workgroups of partial[wg][i], fixed order; out layout = the partial row, FP columns squeezed to F
+// out[i] = sum over workgroups of partial[wg][i] in a fixed order: 64 columns x 16 interleaved groups of workgroups per
+// block, the groups added in order through LDS.  Output layout = the partial row, FP columns squeezed to F.
 template <int FP>
-__global__ __launch_bounds__(256) void k_prop_reduce(const float *__restrict__ partial, uint32_t n_wg, uint32_t F, float *gW0, float *gb0,
-                                                      float *gw1, float *gb1) {
+__global__ __launch_bounds__(1024) void k_prop_reduce(const float *__restrict__ partial, uint32_t n_wg, uint32_t F, float *gW0, float *gb0,
+                                                       float *gw1, float *gb1) {
     constexpr int ROW = kHidden * (FP + 2) + 1;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (uint32_t)ROW) return;
+    __shared__ float s_g[16][64];
+    const uint32_t col = threadIdx.x & 63u, grp = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64u + col;
     float s = 0.0f;
-    for (uint32_t w = 0; w < n_wg; w++) s += partial[(size_t)w * ROW + i];
+    if (i < (uint32_t)ROW)
+        for (uint32_t w = grp; w < n_wg; w += 16u) s += partial[(size_t)w * ROW + i];
+    s_g[grp][col] = s;
+    __syncthreads();
+    if (grp != 0 || i >= (uint32_t)ROW) return;
+#pragma unroll
+    for (int g = 1; g < 16; g++) s += s_g[g][col];
     if (i < (uint32_t)(kHidden * FP)) {
         const uint32_t k = i / FP, c = i % FP;
         if (c < F) gW0[k * F + c] = s;
@@ -252,7 +287,7 @@ extern "C" int ucn_prop_train_bwd(const float *feat, uint32_t F, uint32_t hidden
     }
     UCN_PROP_DISPATCH(fp, hipLaunchKernelGGL(k_prop_bwd_weight<FPC>, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, a));
     UCN_LAUNCH_CHECK("prop_train_bwd (weights)");
-    UCN_PROP_DISPATCH(fp, hipLaunchKernelGGL(k_prop_reduce<FPC>, dim3(ucn_div_up(kHidden * (FPC + 2) + 1, 256)), dim3(256), 0,
+    UCN_PROP_DISPATCH(fp, hipLaunchKernelGGL(k_prop_reduce<FPC>, dim3(ucn_div_up(kHidden * (FPC + 2) + 1, 64)), dim3(1024), 0,
                                              (hipStream_t)stream, workspace, n_wg, F, gW0, gb0, gw1, gb1));
     UCN_LAUNCH_CHECK("prop_train_bwd (reduce)");
     return 0;
