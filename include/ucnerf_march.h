@@ -237,6 +237,12 @@ int ucn_composite_backward(const float *density, const float *rgbs, const float 
  * ray; g_loss [N] -> out [N,S] = d(sum_n g_loss[n] loss[n]) / d w (t carries no gradient). */
 int ucn_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, uint64_t n, float lr, float beta1,
                   float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream);
+/* ref: models.py:297-306 (hash decay: mean over levels and channels of the per-level mean of embeddings^2).
+ * embeddings DEVICE [rows, C]; offsets_host HOST int32 [L+1] (first row of each level, offsets[L] = rows).
+ * g_dev NULL: forward -- out DEVICE [1] = the loss, workspace DEVICE [1024] floats.
+ * g_dev DEVICE [1] (gradient of the loss): backward -- out DEVICE [rows, C] = g * d loss / d embeddings. */
+int ucn_hash_decay(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, const float *g_dev,
+                   float *out, float *workspace, ucn_stream_t stream);
 /* ref: train_utils.py:342-344 `param.grad.nan_to_num_()` for every parameter: `count` fp32 DEVICE tensors (HOST arrays of
  * their pointers and element counts) sanitised in place by one launch per 48 tensors. */
 int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *numel_host, uint32_t count, ucn_stream_t stream);

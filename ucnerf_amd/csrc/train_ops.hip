@@ -342,6 +342,60 @@ __global__ __launch_bounds__(256) void k_relu_bwd_reduce(const T *__restrict__ g
     }
 }
 
+// Hash decay (models.py:297-306): mean over levels and channels of the per-level mean of embeddings^2 = sum over rows of
+// w_level * sum_c e^2 with w_level = 1 / (rows_of_level * L * C).  One pass over the table forward (block partials, added
+// in a fixed order by k_decay_finish), one pass backward (grad = 2 g w_level e).  As torch ops: pow + per-row sum + dot
+// over a 57 MB table and a [rows] weight vector, 110 us forward + 40 us backward per table and step.
+constexpr int kDecayBlocks = 1024, kDecayLevels = 32;
+struct DecayLevels {
+    uint32_t n;
+    uint32_t off[kDecayLevels + 1];      // first row of each level, off[n] = rows
+    float w[kDecayLevels];
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_hash_decay(const float *__restrict__ emb, uint32_t C, DecayLevels lv, const float *__restrict__ g,
+                                                    float *__restrict__ out) {
+    const uint64_t total = (uint64_t)lv.off[lv.n] * C;                     // floats
+    const uint64_t per = ((total + kDecayBlocks - 1) / kDecayBlocks + 3) & ~3ull;
+    const uint64_t e0 = (uint64_t)blockIdx.x * per, e1 = e0 + per < total ? e0 + per : total;
+    float acc = 0.0f;
+    const float g2 = BWD ? 2.0f * g[0] : 0.0f;
+    for (uint32_t l = 0; l < lv.n; l++) {                                  // wave-uniform: the levels this block's range meets
+        const uint64_t lo = (uint64_t)lv.off[l] * C > e0 ? (uint64_t)lv.off[l] * C : e0;
+        const uint64_t hi = (uint64_t)lv.off[l + 1] * C < e1 ? (uint64_t)lv.off[l + 1] * C : e1;
+        if (lo >= hi) continue;
+        const float w = lv.w[l];
+        float part = 0.0f;
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += 256u) {
+            const float e = emb[i];
+            if (BWD) out[i] = e * (g2 * w);
+            else part = fmaf(e, e, part);
+        }
+        acc = fmaf(w, part, acc);
+    }
+    if (BWD) return;
+    __shared__ float s_p[256];
+    s_p[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = s_p[0];
+}
+__global__ __launch_bounds__(256) void k_decay_finish(const float *__restrict__ partial, float *__restrict__ out) {
+    __shared__ float s_p[256];
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < kDecayBlocks; i += 256) a += partial[i];
+    s_p[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s_p[0];
+}
+
 // nan_to_num_ (nan -> 0, +-inf -> +-FLT_MAX) on up to kManyMax small fp32 tensors in one launch: blockIdx.y = tensor
 constexpr int kManyMax = 48;
 struct ManyTensors {
@@ -358,6 +412,30 @@ __global__ __launch_bounds__(256) void k_nan_to_num_many(ManyTensors t) {
 }
 
 }  // namespace
+
+extern "C" int ucn_hash_decay(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, const float *g_dev,
+                              float *out, float *workspace, ucn_stream_t stream) {
+    UCN_REQUIRE(embeddings && offsets_host && out, "hash_decay: null pointer argument");
+    UCN_REQUIRE(L >= 1 && L <= (uint32_t)kDecayLevels && C >= 1, "hash_decay: 1..32 levels, got %u", L);
+    UCN_REQUIRE(g_dev || workspace, "hash_decay: the forward needs a workspace of 1024 floats");
+    DecayLevels lv{};
+    lv.n = L;
+    for (uint32_t l = 0; l <= L; l++) lv.off[l] = (uint32_t)offsets_host[l];
+    for (uint32_t l = 0; l < L; l++) {
+        UCN_REQUIRE(offsets_host[l + 1] > offsets_host[l], "hash_decay: level %u is empty", l);
+        lv.w[l] = (float)(1.0 / ((double)(offsets_host[l + 1] - offsets_host[l]) * (double)L * (double)C));
+    }
+    if (g_dev) {
+        hipLaunchKernelGGL(k_hash_decay<true>, dim3(kDecayBlocks), dim3(256), 0, (hipStream_t)stream, embeddings, C, lv, g_dev, out);
+        UCN_LAUNCH_CHECK("hash_decay (backward)");
+        return 0;
+    }
+    hipLaunchKernelGGL(k_hash_decay<false>, dim3(kDecayBlocks), dim3(256), 0, (hipStream_t)stream, embeddings, C, lv, (const float *)nullptr,
+                       workspace);
+    hipLaunchKernelGGL(k_decay_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, out);
+    UCN_LAUNCH_CHECK("hash_decay");
+    return 0;
+}
 
 extern "C" int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *numel_host, uint32_t count, ucn_stream_t stream) {
     UCN_REQUIRE(count == 0 || (tensors_host && numel_host), "nan_to_num_many: null pointer argument");

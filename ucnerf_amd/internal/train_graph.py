@@ -605,20 +605,34 @@ class _Composite(torch.autograd.Function):
 
 
 class _HashDecay(torch.autograd.Function):
-    """sum_rows sum_c emb[r, c]^2 * w[r]: one pass over the table forward, one backward (the per-level slices of
-    the reference's formulation cost 16 full-table zero-fills and adds in autograd)."""
+    """models.py:297-306 as one pass over the table forward and one backward (`ucn_hash_decay`); the per-level slices of
+    the reference's formulation cost 16 full-table zero-fills and adds in autograd, the torch form of the weighted sum
+    (pow, per-row sum, dot with a [rows] weight vector) 150 us per table and step."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, emb, w):
-        ctx.save_for_backward(emb, w)
-        return torch.dot(emb.square().sum(dim=1), w)
+    def forward(ctx, emb, offsets_np):
+        lib = _lib.load()
+        emb = emb.contiguous()
+        out = torch.empty(1, device=emb.device)
+        ws = torch.empty(1024, device=emb.device)
+        off = np.ascontiguousarray(offsets_np, dtype=np.int32)
+        _lib.check(lib.ucn_hash_decay(emb.data_ptr(), off.ctypes.data, len(off) - 1, emb.shape[1], None, out.data_ptr(), ws.data_ptr(),
+                                      _lib.stream()))
+        ctx.save_for_backward(emb)
+        ctx.off = off
+        return out[0]
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        emb, w = ctx.saved_tensors
-        return emb * (w * (2.0 * g))[:, None], None
+        lib = _lib.load()
+        (emb,) = ctx.saved_tensors
+        grad = torch.empty_like(emb)
+        g = g.reshape(1).float().contiguous()
+        _lib.check(lib.ucn_hash_decay(emb.data_ptr(), ctx.off.ctypes.data, len(ctx.off) - 1, emb.shape[1], g.data_ptr(), grad.data_ptr(),
+                                      None, _lib.stream()))
+        return grad, None
 
 
 def hash_decay(mlp):
@@ -626,13 +640,9 @@ def hash_decay(mlp):
     (torch_scatter.segment_coo(reduce='mean') over the sorted level index), restated as one weighted sum with
     w[row] = 1 / (rows_of_its_level * L * C)."""
     enc = mlp.encoder
-    w = getattr(enc, "_decay_w", None)
-    if w is None or w.device != enc.embeddings.device:
-        off = enc._offsets_np
-        n = torch.tensor([int(off[i + 1]) - int(off[i]) for i in range(len(off) - 1)], device=enc.embeddings.device)
-        w = torch.repeat_interleave(1.0 / (n.double() * len(n) * enc.embeddings.shape[1]), n).float()
-        enc._decay_w = w
-    return _HashDecay.apply(enc.embeddings, w)
+    if not enc.embeddings.is_cuda:
+        raise RuntimeError("hash_decay: embeddings must be a CUDA tensor")
+    return _HashDecay.apply(enc.embeddings, enc._offsets_np)
 
 
 def sky_forward(net, origins, directions, cam_dirs, far):
