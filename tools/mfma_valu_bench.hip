@@ -65,8 +65,8 @@ void run(float *d, const char *name) {
     float ms, cyc;
     hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(&cyc, d, 4, hipMemcpyDeviceToHost);
-    printf("%d waves/SIMD  %-24s K=%2d: %.2f ns per MFMA of one wave = %.2f ns per MFMA of the SIMD (pipe: ~15)\n", g_threads / 256, name, K,
-           ms * 1e6 / (20000.0 * 6), ms * 1e6 / (20000.0 * 6) / (g_threads / 256));
+    printf("%d waves/SIMD  %-24s K=%2d: %.2f ns per MFMA of one wave = %.2f ns per MFMA of the SIMD; %.1f s_memtime ticks per MFMA of one wave -> %.2f GHz if a tick is a shader cycle\n",
+           g_threads / 256, name, K, ms * 1e6 / (20000.0 * 6), ms * 1e6 / (20000.0 * 6) / (g_threads / 256), cyc, cyc / (ms * 1e6 / (20000.0 * 6)));
 }
 int main() {
     float *d;
