@@ -138,6 +138,86 @@ __device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float
     }
 }
 
+// Coarse levels (cells far larger than a sample's cone section): the six multisamples of a sample usually sit in ONE
+// lattice cell.  Then its 8 corner rows are derived and fetched once instead of six times; every point still forms its
+// own weights and accumulates in level_accumulate's order, so the result is bit-identical.  Lanes whose points straddle a
+// cell boundary take the general path (the branch diverges; the caller enables this only where straddling is rare).
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, const float *__restrict__ tab,
+                                                        const float (&u)[6][3], const float (&rs)[6], float (&acc)[C]) {
+    float fx[6], fy[6], fz[6];
+    uint32_t x0 = 0, y0 = 0, z0 = 0;
+    bool same = true, any = false;
+    uint32_t inside = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (in_unit_cube(u[j][0], u[j][1], u[j][2])) {
+            fx[j] = fmaf(u[j][0], lv.scale, 0.5f); fy[j] = fmaf(u[j][1], lv.scale, 0.5f); fz[j] = fmaf(u[j][2], lv.scale, 0.5f);
+            const uint32_t xj = (uint32_t)floorf(fx[j]), yj = (uint32_t)floorf(fy[j]), zj = (uint32_t)floorf(fz[j]);
+            fx[j] -= (float)xj; fy[j] -= (float)yj; fz[j] -= (float)zj;
+            if (!any) { x0 = xj; y0 = yj; z0 = zj; any = true; }
+            else same = same && xj == x0 && yj == y0 && zj == z0;
+            inside |= 1u << j;
+        }
+    }
+    if (!same) {
+        level_accumulate<C, HASHED, POW2>(lv, tab, u, rs, 6, acc);
+        return;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) acc[c] = 0.0f;
+    if (!any) return;
+    uint32_t ya, yb, za, zb, xa, xb;
+    if constexpr (HASHED) {
+        xa = x0; xb = x0 + 1u;
+        ya = y0 * kP1; yb = ya + kP1;
+        za = z0 * kP2; zb = za + kP2;
+    } else {
+        xa = x0 * lv.stride[0]; xb = xa + lv.stride[0];
+        ya = y0 * lv.stride[1]; yb = ya + lv.stride[1];
+        za = z0 * lv.stride[2]; zb = za + lv.stride[2];
+    }
+    float v[8][C];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t xv = (k & 1u) ? xb : xa, yv = (k & 2u) ? yb : ya, zv = (k & 4u) ? zb : za;
+        uint32_t idx;
+        if constexpr (HASHED) idx = xv ^ yv ^ zv;
+        else idx = xv + yv + zv;
+        uint32_t row;
+        if constexpr (POW2) row = idx & lv.mask;
+        else row = idx < lv.rows ? idx : idx % lv.rows;
+        const float *r = tab + (size_t)row * C;
+        if constexpr (C == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(r);
+            v[k][0] = t.x; v[k][1] = t.y;
+        } else if constexpr (C == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(r);
+            v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        if (inside & (1u << j)) {
+            float w[8];
+            corner_weights(fx[j], fy[j], fz[j], w);
+            float f[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) f[c] = 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) f[c] = fmaf(w[k], v[k][c], f[c]);
+            const float damp = erf_pos(rs[j] * lv.inv_gs);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) acc[c] += f[c] * damp;
+        }
+    }
+}
+
 // Fine hashed levels, C = 2, power-of-two table: the kernel is bound by the L2 request rate there (one
 // request per gathered corner, ~16 per clock per XCD), so corners that are adjacent in memory are fetched
 // together.  For an even lattice x the corners (x, y, z) and (x+1, y, z) hash to rows r and r^1 -- one
@@ -375,6 +455,11 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
     }
 }
 
+#ifndef UCN_SHARED_CELL_MAX_RES
+#define UCN_SHARED_CELL_MAX_RES 64
+#endif
+constexpr uint32_t kSharedCellMaxRes = UCN_SHARED_CELL_MAX_RES;     // dense levels up to this resolution use level_accumulate_shared
+
 // layout: 0 = [L][B][C] (b as given), 1 = [B][L*C]
 template <uint32_t C>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
@@ -386,7 +471,10 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
         const float *tab = table + (size_t)lv.first_row * C;
         float acc[C];
         // wave-uniform dispatch on the level's addressing mode (lv lives in SGPRs)
-        if (lv.hashed) {
+        if (lv.hashed && G == 6 && lv.resolution <= kSharedCellMaxRes) {
+            if (lv.mask) level_accumulate_shared<C, true, true>(lv, tab, u, rs, acc);
+            else level_accumulate_shared<C, true, false>(lv, tab, u, rs, acc);
+        } else if (lv.hashed) {
             if constexpr (C == 2) {
                 if (lv.mask && lv.resolution > 2048u && G == 6) level_accumulate_pairs(lv, tab, u, rs, acc);
                 else if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
@@ -395,6 +483,9 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__
                 if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
                 else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
             }
+        } else if (G == 6 && lv.resolution <= kSharedCellMaxRes) {
+            if (lv.mask) level_accumulate_shared<C, false, true>(lv, tab, u, rs, acc);
+            else level_accumulate_shared<C, false, false>(lv, tab, u, rs, acc);
         } else {
             if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
             else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);
