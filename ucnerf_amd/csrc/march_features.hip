@@ -590,9 +590,9 @@ __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPatter
             float ang = hx.ang[j] + spin2pi;
             if (!keep) ang = 5.235987663269043f - ang;
             // v_sin_f32 / v_cos_f32 (argument in revolutions, |error| ~1e-6 absolute): the angle only places a multisample
-            // on its circle of radius ~r t / sqrt(2) (render.py:126-136), so the position moves by < 1e-9; the precise
-            // cosf / sinf were ~100 VALU instructions per point, re-derived by every level group: half of the training
-            // forward (2.03 -> ms in profiles/r02c).
+            // on its circle of radius ~r t / sqrt(2) (render.py:126-136), so the position moves by < 1e-9.  The precise
+            // cosf / sinf were ~100 VALU instructions per point and level group; removing them did not change the training
+            // forward's time (2.02 ms before and after: random rays leave it bound by the gather, not by VALU).
             const float rev = ang * 0.15915494309189535f;
             cs = __builtin_amdgcn_cosf(rev); sn = __builtin_amdgcn_sinf(rev);
         } else {
