@@ -176,7 +176,11 @@ struct Ring {
         if constexpr (C < kChunks) {
             const float *g = wsrc + (size_t)(C * CHUNK + I * NWAVES) * 256;
             const uint32_t l = wlds + (uint32_t)(((C % SLOTS) * CHUNK + I * NWAVES) * 1024);
+#ifdef UCN_EXP_DMA_DWORD      // experiment: the same number of DMA instructions moving a quarter of the bytes (results garbage)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(l), "v"(voff), "s"(g) : "memory");
+#else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(l), "v"(voff), "s"(g) : "memory");
+#endif
         }
     }
     template <int C>
