@@ -117,7 +117,9 @@ def test_hip_train_graph_matches_reference_step(name, over):
     batch['rand_vec'] = batch['rand_vec'][:, None, None, :]
     rend, hist = model(True, batch, float(fx["train_frac"]), False, zero_glo=False)
     assert rend[-1]['rgb'].shape == fx["L1_rgb"].shape and rend[-1]['rgb'].requires_grad
-    losses, _ = losses_of(tu, batch, rend, hist, spec)
+    losses, stats = losses_of(tu, batch, rend, hist, spec)
+    assert stats.pending('mses')                           # no host sync inside the loss: fetched on first read
+    assert np.allclose(stats['mses'], fx["mse"].numpy(), rtol=1e-4) and not stats.pending('mses')
     for k, v in losses.items():
         # data / interlevel / distortion inherit the per-pixel noise floor of the fine NeRF grid
         assert abs(float(v) - float(fx["loss_" + k])) <= 2e-4 * max(1.0, abs(float(fx["loss_" + k]))), (k, float(v), float(fx["loss_" + k]))

@@ -11,6 +11,7 @@ tensors already resident in HBM; formulations differ where the reference is quad
 * anti-interlevel loss: `sorted_interp_quad` (math.py:110-133) uses O(n*m) masks; here a binary search.
 """
 import collections
+import collections.abc
 
 import numpy as np
 import torch
@@ -113,30 +114,38 @@ class _InterLevel(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ losses (train.py:173-216)
-class LazyStats(dict):
+class LazyStats(collections.abc.MutableMapping):
     """The stats dict of compute_data_loss with its device values fetched on first READ.  The reference converts every
     level's mse with `.item()` inside the loss function (train_utils.py:187) -- a host sync in the middle of the step,
     before the remaining losses and the whole backward are even queued; its loop first reads the stats after the
-    optimiser step (train.py:226).  Same keys, same numpy values, one transfer at that point instead."""
+    optimiser step (train.py:226).  Same keys, same numpy values, one transfer at that point instead.  A mutable mapping
+    (train.py adds 'loss', 'psnrs', ... to it); `dict(stats)`, iteration and `.items()` all go through the fetch."""
 
-    def _fetch(self, k):
-        v = dict.__getitem__(self, k)
-        if isinstance(v, torch.Tensor):
-            v = v.detach().float().cpu().numpy()
-            dict.__setitem__(self, k, v)
-        return v
+    def __init__(self, **device_values):
+        self._d = dict(device_values)
 
     def __getitem__(self, k):
-        return self._fetch(k)
+        v = self._d[k]
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            v = self._d[k] = v.detach().float().cpu().numpy()
+        return v
 
-    def get(self, k, default=None):
-        return self._fetch(k) if k in self else default
+    def __setitem__(self, k, v):
+        self._d[k] = v
 
-    def items(self):
-        return [(k, self._fetch(k)) for k in self.keys()]
+    def __delitem__(self, k):
+        del self._d[k]
 
-    def values(self):
-        return [self._fetch(k) for k in self.keys()]
+    def __iter__(self):
+        return iter(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def pending(self, k):
+        """True while the value of `k` has not been fetched from the device."""
+        v = self._d[k]
+        return isinstance(v, torch.Tensor) and v.is_cuda
 
     def __repr__(self):
         return repr(dict(self.items()))
