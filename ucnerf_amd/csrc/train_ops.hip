@@ -450,7 +450,7 @@ extern "C" int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *n
             biggest = numel_host[base + i] > biggest ? numel_host[base + i] : biggest;
         }
         if (biggest == 0) continue;
-        const uint32_t bx = (uint32_t)(ucn_div_up(biggest, 1024) < 256 ? ucn_div_up(biggest, 1024) : 256);
+        const uint32_t bx = (uint32_t)(ucn_div_up(biggest, 1024) < 2048 ? ucn_div_up(biggest, 1024) : 2048);
         hipLaunchKernelGGL(k_nan_to_num_many, dim3(bx ? bx : 1, m), dim3(256), 0, (hipStream_t)stream, t);
         UCN_LAUNCH_CHECK("nan_to_num_many");
     }

@@ -254,7 +254,6 @@ class FusedAdam(torch.optim.Adam):
         for group in self.param_groups:
             for p in group['params']:
                 if self._fusable(group, p):
-                    p._ucn_sanitised_by_optimizer = True         # sanitize_gradients may skip it from now on
                     held.append((group, p, p.grad))
                     p.grad = None                                # the parent skips parameters without a gradient
         try:
@@ -289,15 +288,13 @@ def clip_gradients(model, accelerator, config):
 
 def sanitize_gradients(params):
     """`param.grad.nan_to_num_()` for every parameter (train_utils.py:342-344): the contiguous fp32 device gradients in ONE
-    launch (`ucn_nan_to_num_many`) instead of one per parameter; the tables a FusedAdam owns are skipped, its kernel
-    sanitises them in the same pass that steps them.  Anything else takes torch's op."""
+    launch (`ucn_nan_to_num_many`, a read-only pass unless something is not finite) instead of one per parameter.
+    Anything else takes torch's op."""
     import ctypes
     small = []
     for p in params:
         g = p.grad
         if g is None:
-            continue
-        if getattr(p, '_ucn_sanitised_by_optimizer', False) and g.is_cuda:
             continue
         if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.numel() < (1 << 31):
             small.append(g)
