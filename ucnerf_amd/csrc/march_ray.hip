@@ -61,6 +61,40 @@ __device__ __forceinline__ uint32_t count_before(F f, uint32_t len, float x) {
     return lo;
 }
 
+// The same count, started from a guess: gallop away from `hint` in the direction the predicate at the guess points to,
+// then bisect the bracket.  The ranks of the 3-way merge and the window bounds of the max-pool are known to within a
+// few positions from the element's own index (the dilation is of the order of one interval), so 2-3 probes replace
+// the 7 of a cold binary search over 64 entries; the result is the exact count either way.
+template <bool STRICT, class F>
+__device__ __forceinline__ uint32_t count_from(F f, uint32_t len, float x, uint32_t hint) {
+    auto before = [&](uint32_t j) { const float v = f(j); return STRICT ? (v < x) : (v <= x); };
+    uint32_t lo = 0, hi = len;
+    uint32_t c = hint < len ? hint : len;
+    if (c < len && before(c)) {                  // the count exceeds c
+        lo = c + 1;
+        uint32_t step = 1;
+        while (lo < hi) {
+            const uint32_t probe = lo + step - 1 < hi - 1 ? lo + step - 1 : hi - 1;
+            if (before(probe)) { lo = probe + 1; step <<= 1; }
+            else { hi = probe; break; }
+        }
+    } else {                                     // the count is at most c
+        hi = c;
+        uint32_t step = 1;
+        while (lo < hi) {
+            const uint32_t probe = hi - lo > step ? hi - step : lo;
+            if (!before(probe)) { hi = probe; step <<= 1; }
+            else { lo = probe + 1; break; }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (before(mid)) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_prev, const float *__restrict__ w_prev,
                                                   uint32_t n_prev, float dilation, float anneal, float pad,
                                                   const float *__restrict__ u_table, const float *__restrict__ jitter,
@@ -93,30 +127,36 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         auto A = [&](uint32_t j) { return t[j]; };
         auto Bq = [&](uint32_t j) { return t[j] - dilation; };
         auto Cq = [&](uint32_t j) { return t[j + 1] + dilation; };
+        uint32_t *src = reinterpret_cast<uint32_t *>(cdf);     // which t[] index a knot came from (cdf[] is free until the softmax)
         for (uint32_t e = lane; e < m; e += 64) {
             float v;
-            uint32_t pos;
+            uint32_t pos, near;
             if (e <= n) {
                 v = A(e);
-                pos = e + count_before<false>(Bq, n, v) + count_before<true>(Cq, n, v);
+                near = e;
+                pos = e + count_from<false>(Bq, n, v, e + 1) + count_from<true>(Cq, n, v, e >= 1 ? e - 1 : 0);
             } else if (e <= 2 * n) {
                 const uint32_t i = e - (n + 1);
                 v = Bq(i);
-                pos = i + count_before<true>(A, n + 1, v) + count_before<true>(Cq, n, v);
+                near = i;
+                pos = i + count_from<true>(A, n + 1, v, i) + count_from<true>(Cq, n, v, i >= 1 ? i - 1 : 0);
             } else {
                 const uint32_t i = e - (2 * n + 1);
                 v = Cq(i);
-                pos = i + count_before<false>(A, n + 1, v) + count_before<false>(Bq, n, v);
+                near = i + 1;
+                pos = i + count_from<false>(A, n + 1, v, i + 2) + count_from<false>(Bq, n, v, i + 2);
             }
             kn[pos] = fminf(fmaxf(v, 0.0f), 1.0f);
+            src[pos] = near;
         }
         __syncthreads();
         // max-pool the pdf over the dilated intervals covering each knot interval, times its width
         double part = 0.0;
         for (uint32_t i = lane; i + 1 < m; i += 64) {
             const float k = kn[i];
-            const uint32_t jhi = count_before<false>(Bq, n, k);          // intervals with t0 - d <= k
-            const uint32_t jlo = count_before<false>(Cq, n, k);          // intervals with t1 + d <= k end before k
+            const uint32_t near = src[i];
+            const uint32_t jhi = count_from<false>(Bq, n, k, near + 1);                        // intervals with t0 - d <= k
+            const uint32_t jlo = count_from<false>(Cq, n, k, near >= 1 ? near - 1 : 0);        // intervals with t1 + d <= k end before k
             float env = 0.0f;
             for (uint32_t j = jlo; j < jhi; j++) env = fmaxf(env, p[j]);
             const float wv_ = env * (kn[i + 1] - kn[i]);                 // pdf_to_weight
