@@ -291,7 +291,9 @@ uint64_t ucn_train_fwd_fragments(void);
  * [M, act_ld] bf16 buffer (the caller passes the four column-offset pointers), so that the weight-gradient GEMMs can
  * take adjacent blocks as one operand ([h1 | x | per-ray columns] is the input of the reference's concatenated layer,
  * models.py:620-640).  ray_cols [N,32] bf16 | NULL: per-RAY columns (direction encoding, a constant 1 for the bias)
- * copied into every sample's row at ray_dst (a column-offset pointer into the same buffer).  feat_bf16 [M,F] | NULL: bf16 copy of the features (operand of the first layer's weight gradient;
+ * copied into every sample's row at ray_dst (a column-offset pointer into the same buffer).  Rows that start on 128-byte
+ * lines matter: act_ld = 864 (1728-byte rows) costs 15 % against 1024.  feat_bf16 | NULL (row stride act_ld when act_ld != 0,
+ * i.e. one more column block of the same buffer, else F): bf16 copy of the features (operand of the first layer's weight gradient;
  * F % 8 == 0).  head: HOST float[4] {density_bias, rgb_premultiplier, rgb_bias, rgb_padding} | NULL.  With head the
  * output activations (models.py:515 softplus, :667-672 sigmoid + padding) are applied in fp32 before the store:
  * raw := density, y := rgb. */

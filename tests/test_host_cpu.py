@@ -212,9 +212,15 @@ def test_fused_heads_weight_preparation_is_one_gather():
         W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
         W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
         Wd0b, Wd1b, Wrb = Wd0.to(dt), Wd1.to(dt), Wr.to(dt)
-        fwd = tg._pack_fragments([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], 1), False), (Wrb, False)], "cpu", total=T)
-        bwd = tg._pack_fragments([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], 1), False), (Wd1b.t(), False),
-                                  (Wd0b.t(), False)], "cpu", total=T)
+        def packed(mats, weave):
+            # per-matrix fragment streams of the per-matrix packer, the consumer layer's fragments woven behind each
+            # output-tile pair of its producer (field_train.hip), zero-padded to T fragments
+            parts = tg._weave([tg._pack_fragments([m], "cpu") for m in mats], *weave)
+            flat = torch.cat(parts)
+            return torch.cat([flat, flat.new_zeros(T * 512 - flat.numel())])
+        fwd = packed([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], 1), False), (Wrb, False)], (3, 4))
+        bwd = packed([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], 1), False), (Wd1b.t(), False),
+                      (Wd0b.t(), False)], (2, 3))
         assert torch.equal(got[:T * 512], fwd) and torch.equal(got[T * 512:2 * T * 512], bwd)
         o = 2 * T * 512
         We, be = got[o:o + 2 * NW * E].view(2 * NW, E), got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]

@@ -18,7 +18,7 @@
 // LDS in 64 KiB chunks shared by the workgroup's four waves (reading them per wave straight from L2 was 5x slower).
 #include <utility>
 
-#include "mfma_chain.h"
+#include "mlp_ring.h"
 
 namespace {
 
@@ -34,7 +34,7 @@ struct TrainFwdArgs {
     uint16_t *ray_dst;
     uint16_t *fb;             // [M, F] bf16 copy of the features (the density layer's weight-gradient operand) or NULL
     float *raw, *y;           // [M], [M, 3]: raw density and colour logits, or (head) density and rgb
-    uint32_t ld_h0, ld_act;
+    uint32_t ld_h0, ld_act, ld_fb;
     int head;                 // 1: raw := softplus(raw + density_bias), y := sigmoid(premult y + rgb_bias) (1 + 2 pad) - pad
     float density_bias, rgb_premult, rgb_bias, rgb_padding;
     uint32_t *m0;             // [M][2] : ReLU masks of h0, bit 16 t + r of wave half h  (2 tiles)
@@ -72,17 +72,62 @@ __device__ __forceinline__ bf8 to_b_masked(const f32x16 &a, int s, uint32_t bits
     for (int e = 0; e < 8; e++) v[e] = ((bits >> (8 * s + e)) & 1u) ? a[8 * s + e] : 0.0f;
     return pack8(v);
 }
-// store a tile of activations: lane (j, h) holds rows 32t + (r&3) + 8(r>>2) + 4h -> four 8-byte pieces per tile.
-// (Transposing through LDS to write whole 512-byte rows was measured: 1.13 -> 1.06 ms, not worth 66 KiB of LDS.)
+// store a tile of activations: lane (j, h) holds features 32t + (r&3) + 8(r>>2) + 4h of sample j -- four 8-byte pieces
+// {0-3, 8-11, 16-19, 24-27} + 4h.  The two lanes of a sample first trade pieces (v_permlane32_swap: lane j's pieces 2, 3
+// against lane j + 32's pieces 0, 1), after which lane (j, 0) holds features 0-15 and lane (j, 1) features 16-31 of the
+// tile contiguously: two 16-byte stores per lane instead of four 8-byte ones -- the kernels' 1.8 GB of activations leave
+// in half as many write transactions.  (Transposing whole rows through LDS: 1.13 -> 1.06 ms, not worth 66 KiB of LDS.)
 __device__ __forceinline__ void store_tile(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int t, int h, const bf8 (&b)[2],
                                            bool live) {
-    if (!live) return;
     const uint4 lo = __builtin_bit_cast(uint4, b[0]), hi = __builtin_bit_cast(uint4, b[1]);
-    uint2 *p = reinterpret_cast<uint2 *>(dst + (size_t)sample * width + 32 * t + 4 * h);
-    p[0] = make_uint2(lo.x, lo.y);      // r = 0..3   -> features +0
-    p[2] = make_uint2(lo.z, lo.w);      // r = 4..7   -> features +8
-    p[4] = make_uint2(hi.x, hi.y);      // r = 8..11  -> features +16
-    p[6] = make_uint2(hi.z, hi.w);      // r = 12..15 -> features +24
+    // (a, b) -> a keeps lanes 0-31 and takes b's lanes 0-31 into its lanes 32-63; b takes a's lanes 32-63 into its lanes 0-31
+    const auto s0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(lo.z, hi.z, false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(lo.w, hi.w, false, false);
+    if (!live) return;
+    uint4 *p = reinterpret_cast<uint4 *>(dst + (size_t)sample * width + 32 * t + 16 * h);
+    p[0] = make_uint4(s0[0], s1[0], s0[1], s1[1]);      // h = 0: features 0-3 (own), 4-7 (partner);  h = 1: 16-19, 20-23
+    p[1] = make_uint4(s2[0], s3[0], s2[1], s3[1]);      // h = 0: features 8-11, 12-15;                h = 1: 24-27, 28-31
+}
+// ... and for the two tiles of an output PAIR (64 adjacent features = 128 bytes of the row): the two lanes of a sample
+// trade whole tiles' worth of pieces, lane (j, 0) ends up with all 32 features of tile tp, lane (j, 1) with those of tile
+// tp + 1 -- every lane writes one full 64-byte sector (4 x 16 bytes), same instruction count as two store_tile calls.
+__device__ __forceinline__ void store_pair(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h,
+                                           const bf8 (&t0)[2], const bf8 (&t1)[2], bool live) {
+    const uint4 a0 = __builtin_bit_cast(uint4, t0[0]), a1 = __builtin_bit_cast(uint4, t0[1]);   // tile tp:     pieces 0,1 | 2,3
+    const uint4 b0 = __builtin_bit_cast(uint4, t1[0]), b1 = __builtin_bit_cast(uint4, t1[1]);   // tile tp + 1
+    // swap(a, b): lanes 0-31 end with (a, partner's a) = both halves of tile tp's piece, lanes 32-63 with (own b's partner, b)
+    const auto p0x = __builtin_amdgcn_permlane32_swap(a0.x, b0.x, false, false), p0y = __builtin_amdgcn_permlane32_swap(a0.y, b0.y, false, false);
+    const auto p1x = __builtin_amdgcn_permlane32_swap(a0.z, b0.z, false, false), p1y = __builtin_amdgcn_permlane32_swap(a0.w, b0.w, false, false);
+    const auto p2x = __builtin_amdgcn_permlane32_swap(a1.x, b1.x, false, false), p2y = __builtin_amdgcn_permlane32_swap(a1.y, b1.y, false, false);
+    const auto p3x = __builtin_amdgcn_permlane32_swap(a1.z, b1.z, false, false), p3y = __builtin_amdgcn_permlane32_swap(a1.w, b1.w, false, false);
+    if (!live) return;
+    uint4 *p = reinterpret_cast<uint4 *>(dst + (size_t)sample * width + 32 * (tp + h));
+    p[0] = make_uint4(p0x[0], p0y[0], p0x[1], p0y[1]);      // features 0-3 (lane j's piece 0), 4-7 (lane j + 32's piece 0)
+    p[1] = make_uint4(p1x[0], p1y[0], p1x[1], p1y[1]);      // 8-11, 12-15
+    p[2] = make_uint4(p2x[0], p2y[0], p2x[1], p2y[1]);      // 16-19, 20-23
+    p[3] = make_uint4(p3x[0], p3y[0], p3x[1], p3y[1]);      // 24-27, 28-31
+}
+#ifndef UCN_TRAIN_PAIR_FWD
+#define UCN_TRAIN_PAIR_FWD 1
+#endif
+#ifndef UCN_TRAIN_PAIR_BWD
+#define UCN_TRAIN_PAIR_BWD 0
+#endif
+template <bool PAIR>
+__device__ __forceinline__ void store_two(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h, const bf8 (&t0)[2],
+                                          const bf8 (&t1)[2], bool live) {
+    if constexpr (PAIR) {
+        store_pair(dst, width, sample, tp, h, t0, t1, live);
+    } else {
+        store_tile(dst, width, sample, tp, h, t0, live);
+        store_tile(dst, width, sample, tp + 1, h, t1, live);
+    }
+}
+__device__ __forceinline__ void zero_acc(f32x16 &a) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = 0.0f;
 }
 __device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &acc) {
 #pragma unroll
@@ -92,37 +137,45 @@ __device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &ac
     }
 }
 
-// Weight staging = the rendering engine's WeightStream (mfma_chain.h): two 64 KiB LDS buffers, the next chunk's 64
-// fragments arrive by global_load_lds DMA issued one piece per four MFMAs of the current chunk, one barrier per chunk.
-// (A first version staged 32 KiB chunks through registers one chunk ahead: the L2 latency of a chunk, ~1.5 us, is longer
-// than its 0.4 us of MFMAs, so every boundary waited -- 1.1 ms per call.)
+// Weight staging = the rendering engine's DMA ring (mlp_ring.h): a 64 KiB LDS ring of 4 x 16 KiB chunks filled by
+// global_load_lds two chunks ahead, one piece per four MFMAs, one barrier per chunk -- 64 KiB and <= 256 registers per
+// wave, so that TWO workgroups share a CU: at one wave per SIMD (the first version: two 64 KiB buffers, 456 registers)
+// both kernels spent 75 % of their wave-cycles waiting (profiles/r02c/pmc_table_train.txt).
 constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
-constexpr int kChunks = (kFragsMax + kChunkGroups - 1) / kChunkGroups;                     // 7 either way (stream zero-padded)
+constexpr int kTChunk = 16, kTSlots = 4, kTLead = 2;
+constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
+using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;
 
 template <int... Is, class F>
 __device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// acc[ot] += sum over NT_IN input tiles of A(frag) . in[it][s].  Output tiles go in PAIRS, the pair innermost
-// (fragment order [ot pair][it][s][o2], a single tile: [it][s]): two MFMAs that accumulate into the same registers do
-// not issue back to back (+43 cycles), alternating between two accumulators they do -- the first version, with all
-// of a tile's MFMAs in a row, ran at 40 % of this one's speed.
-template <int NT_OUT, int NT_IN, int G0>
-__device__ __forceinline__ void layer(WeightStream &ws, f32x16 (&acc)[NT_OUT], const bf8 (&in)[NT_IN][2]) {
-    static_assert(NT_OUT == 1 || NT_OUT % 2 == 0, "output tiles come in pairs");
-    sfor<NT_OUT * NT_IN * 2>([&](auto i) {
+// P output tiles (a PAIR, or one) from NT_IN input tiles: acc[o2] += A(frag) . in[it][s], fragments [it][s][o2] from
+// stream position G0.  The two tiles of a pair alternate (two MFMAs into the same accumulator do not issue back to
+// back); only the pair's 32 accumulator registers are live, the caller converts / stores it before the next pair.
+template <int P, int NT_IN, int G0>
+__device__ __forceinline__ void tile_pair(TRing &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
+    sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
-        constexpr int P = NT_OUT == 1 ? 1 : 2;                               // tiles per group
-        constexpr int o2 = I % P, s = (I / P) % 2, it = (I / (2 * P)) % NT_IN, ot = P * (I / (2 * P * NT_IN)) + o2;
-        if constexpr (G % kChunkGroups == 0 && G > 0) ws.sync();
-        if constexpr (G % 4 == 0 && G / kChunkGroups + 1 < kChunks) ws.piece_unchecked(G / kChunkGroups + 1, (G % kChunkGroups) / 4);
-        acc[ot] = mfma_bf(__builtin_bit_cast(bf8, ws.group(G)), in[it][s], acc[ot]);
+        constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
+        if constexpr (G % kTChunk == 0 && G / kTChunk >= 1) ring.template boundary<G / kTChunk>();
+        if constexpr (G % 4 == 0) ring.template piece<G / kTChunk + kTLead, (G % kTChunk) / 4>();
+        acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
+        // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     });
 }
+__device__ __forceinline__ void ring_start(TRing &ring) {
+    rstatic_for<kTLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
+}
 
+#ifndef UCN_TRAIN_FWD_WGS
+#define UCN_TRAIN_FWD_WGS 2
+#endif
 template <int NTF>   // feature tiles: F <= 32 * NTF
-__global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
+__global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
     const int j = lane & 31, h = lane >> 5;
@@ -130,9 +183,9 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
     const bool live = s0 < a.M;
     const uint32_t sample = live ? s0 : a.M - 1;
     const uint32_t ray = sample / a.S;
-    extern __shared__ __attribute__((aligned(16))) float s_w[];      // 2 x 64 KiB weight chunks
-    WeightStream ws{reinterpret_cast<const float *>(a.w), s_w, lane, wave, (uint32_t)kChunks};
-    ws.issue(0);
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
+    TRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
+    ring_start(ring);
 
     // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
     bf8 fin[NTF][2];
@@ -148,7 +201,7 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
             }
             fin[ft][s] = pack8(v);
             if (a.fb && live && a.F % 8 == 0 && 32u * ft + 16u * s + 8u * h < a.F)
-                *reinterpret_cast<uint4 *>(a.fb + (size_t)sample * a.F + 32u * ft + 16u * s + 8u * h) = __builtin_bit_cast(uint4, fin[ft][s]);
+                *reinterpret_cast<uint4 *>(a.fb + (size_t)sample * a.ld_fb + 32u * ft + 16u * s + 8u * h) = __builtin_bit_cast(uint4, fin[ft][s]);
         }
     if (a.ray_cols && live) {               // lane (j, h): columns 16 h .. 16 h + 15 of its sample's row
         const uint4 *src = reinterpret_cast<const uint4 *>(a.ray_cols + (size_t)ray * 32 + 16 * h);
@@ -156,33 +209,40 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         dst[0] = src[0];
         dst[1] = src[1];
     }
-    ws.sync();                              // chunk 0 and the feature loads above land together
+    ring.template boundary<0>();            // chunk 0 and the feature loads above land together
+    // stream positions: L0 | L1: 4 pairs x 8 | L2: 4 pairs x 32 | 4 x (L3 pair: 64, then the rgb layer's fragments for the
+    // two h2 tiles just finished: 4)
+    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 128;
     // ---- density layer 0
-    f32x16 a0[2];
-    load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
-    load_acc(a.bias_d0 + (1 * 2 + h) * 16, a0[1]);
-    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 128, G4 = G3 + 256;
-    layer<2, NTF, 0>(ws, a0, fin);
     bf8 h0[2][2];
+    {
+        f32x16 a0[2];
+        load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
+        load_acc(a.bias_d0 + (1 * 2 + h) * 16, a0[1]);
+        tile_pair<2, NTF, 0>(ring, a0, fin);
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        h0[t][0] = to_b(a0[t], 0, true);
-        h0[t][1] = to_b(a0[t], 1, true);
-        store_tile(a.h0, a.ld_h0, sample, t, h, h0[t], live);
+        for (int t = 0; t < 2; t++) {
+            h0[t][0] = to_b(a0[t], 0, true);
+            h0[t][1] = to_b(a0[t], 1, true);
+        }
+        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h0, a.ld_h0, sample, 0, h, h0[0], h0[1], live);
+        if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     }
-    if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) load_acc(a.bias_d1 + (t * 2 + h) * 16, acc[t]);
-    layer<8, 2, G1>(ws, acc, h0);
     bf8 xin[16][2];                         // tiles 0..7: h1 (filled below), 8..15: x  -- the order of W1 = [W1h | W1x]
+    sfor<4>([&](auto pp) {
+        constexpr int p = pp.value;
+        f32x16 acc[2];
+        load_acc(a.bias_d1 + ((2 * p) * 2 + h) * 16, acc[0]);
+        load_acc(a.bias_d1 + ((2 * p + 1) * 2 + h) * 16, acc[1]);
+        tile_pair<2, 2, G1 + 8 * p>(ring, acc, h0);
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        xin[8 + t][0] = to_b(acc[t], 0, false);
-        xin[8 + t][1] = to_b(acc[t], 1, false);
-        store_tile(a.x, a.ld_act, sample, t, h, xin[8 + t], live);
-    }
+        for (int o = 0; o < 2; o++) {
+            xin[8 + 2 * p + o][0] = to_b(acc[o], 0, false);
+            xin[8 + 2 * p + o][1] = to_b(acc[o], 1, false);
+        }
+        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xin[8 + 2 * p], xin[9 + 2 * p], live);
+    });
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
         const uint4 q = __builtin_bit_cast(uint4, xin[8][0]);
         const float rawv = __uint_as_float(q.x << 16);
@@ -191,51 +251,53 @@ __global__ __launch_bounds__(256) void k_train_fwd(TrainFwdArgs a) {
         a.raw[sample] = !a.head ? rawv : (z > 20.0f ? z : log1pf(__expf(z)));
     }
     // ---- colour layer 0: x -> h1
-#pragma unroll
-    for (int t = 0; t < 8; t++) load_acc(a.pr0 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
     {
-        bf8 xonly[8][2];
-#pragma unroll
-        for (int t = 0; t < 8; t++) { xonly[t][0] = xin[8 + t][0]; xonly[t][1] = xin[8 + t][1]; }
-        layer<8, 8, G2>(ws, acc, xonly);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        xin[t][0] = to_b(acc[t], 0, true);
-        xin[t][1] = to_b(acc[t], 1, true);
-        store_tile(a.h1, a.ld_act, sample, t, h, xin[t], live);
-    }
-    if (live) {
         uint32_t mk[4];
+        sfor<4>([&](auto pp) {
+            constexpr int p = pp.value;
+            f32x16 acc[2];
+            load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+            load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+            tile_pair<2, 8, G2 + 32 * p>(ring, acc, reinterpret_cast<const bf8(&)[8][2]>(xin[8]));
 #pragma unroll
-        for (int q = 0; q < 4; q++) mk[q] = mask16(acc[2 * q]) | (mask16(acc[2 * q + 1]) << 16);
-        a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+            for (int o = 0; o < 2; o++) {
+                xin[2 * p + o][0] = to_b(acc[o], 0, true);
+                xin[2 * p + o][1] = to_b(acc[o], 1, true);
+            }
+            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, xin[2 * p], xin[2 * p + 1], live);
+            mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
+        });
+        if (live) a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
-    // ---- colour layer 1: [h1, x] -> h2
-#pragma unroll
-    for (int t = 0; t < 8; t++) load_acc(a.pr1 + ((size_t)ray * 8 + t) * 32 + h * 16, acc[t]);
-    layer<8, 16, G3>(ws, acc, xin);
-    bf8 h2[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        h2[t][0] = to_b(acc[t], 0, true);
-        h2[t][1] = to_b(acc[t], 1, true);
-        store_tile(a.h2, a.ld_act, sample, t, h, h2[t], live);
-    }
-    if (live) {
+    // ---- colour layer 1: [h1, x] -> h2, and the rgb layer (3 rows of one padded output tile) on each finished pair
+    float y3[3] = {a.bias_rgb[h * 16 + 0], a.bias_rgb[h * 16 + 1], a.bias_rgb[h * 16 + 2]};   // rows 0..2 live in wave half 0
+    {
         uint32_t mk[4];
+        sfor<4>([&](auto pp) {
+            constexpr int p = pp.value;
+            f32x16 acc[2];
+            load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+            load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+            tile_pair<2, 16, G3 + 68 * p>(ring, acc, xin);
+            bf8 hp[2][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) mk[q] = mask16(acc[2 * q]) | (mask16(acc[2 * q + 1]) << 16);
-        a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+            for (int o = 0; o < 2; o++) {
+                hp[o][0] = to_b(acc[o], 0, true);
+                hp[o][1] = to_b(acc[o], 1, true);
+            }
+            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h2, a.ld_act, sample, 2 * p, h, hp[0], hp[1], live);
+            mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
+            f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
+            zero_acc(yo[0]);
+            tile_pair<1, 2, G3 + 68 * p + 64>(ring, yo, hp);
+            y3[0] += yo[0][0]; y3[1] += yo[0][1]; y3[2] += yo[0][2];
+        });
+        if (live) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
-    // ---- rgb layer (3 rows of one padded output tile)
-    f32x16 yo[1];
-    load_acc(a.bias_rgb + h * 16, yo[0]);
-    layer<1, 8, G4>(ws, yo, h2);
     if (live && h == 0) {
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            float v = yo[0][e];
+            float v = y3[e];
             if (a.head) v = fmaf(1.0f / (1.0f + __expf(-fmaf(a.rgb_premult, v, a.rgb_bias))), 1.0f + 2.0f * a.rgb_padding, -a.rgb_padding);
             a.y[(size_t)sample * 3 + e] = v;
         }
@@ -261,13 +323,9 @@ struct TrainBwdArgs {
     uint32_t M, F;
 };
 
-__device__ __forceinline__ void zero_acc(f32x16 &a) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) a[r] = 0.0f;
-}
 
 template <int NTF>
-__global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -275,8 +333,8 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
     const bool live = s0 < a.M;
     const uint32_t sample = live ? s0 : a.M - 1;
     extern __shared__ __attribute__((aligned(16))) float s_w[];
-    WeightStream ws{reinterpret_cast<const float *>(a.w), s_w, lane, wave, (uint32_t)kChunks};
-    ws.issue(0);
+    TRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
+    ring_start(ring);
     // ---- colour logit gradients: k = 0..2 of k-step 0, wave half 0
     bf8 gin[1][2];
     {
@@ -304,71 +362,83 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
     const uint4 mk2 = a.m2[(size_t)sample * 2 + h], mk1 = a.m1[(size_t)sample * 2 + h];
     const uint32_t mk0 = a.m0[(size_t)sample * 2 + h];
     const uint32_t m2w[4] = {mk2.x, mk2.y, mk2.z, mk2.w}, m1w[4] = {mk1.x, mk1.y, mk1.z, mk1.w};
-    ws.sync();
-    f32x16 acc[8];
+    ring.template boundary<0>();
+    // stream positions: Wr^T: 4 pairs x 4 | W1h^T: 4 pairs x 32 | 4 x ([W1x^T | W0x^T] pair: 64, then Wd1^T's fragments for the
+    // two gx tiles just finished: 8) | Wd0^T
+    constexpr int H1 = 16, H2 = H1 + 128, H4 = H2 + 4 * 72;
     bf8 din[16][2];                          // tiles 0..7: d1, 8..15: d0  (the order of [W1x^T | W0x^T])
     // ---- through the rgb layer and the second hidden layer's ReLU
+    sfor<4>([&](auto pp) {
+        constexpr int p = pp.value;
+        f32x16 acc[2];
+        zero_acc(acc[0]);
+        zero_acc(acc[1]);
+        tile_pair<2, 1, 4 * p>(ring, acc, gin);
 #pragma unroll
-    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
-    layer<8, 1, 0>(ws, acc, gin);
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const uint32_t bits = (m2w[t / 2] >> (16 * (t % 2))) & 0xFFFFu;
-        din[t][0] = to_b_masked(acc[t], 0, bits);
-        din[t][1] = to_b_masked(acc[t], 1, bits);
-        store_tile(a.d1, 256, sample, t, h, din[t], live);
-    }
+        for (int o = 0; o < 2; o++) {
+            const uint32_t bits = (m2w[p] >> (16 * o)) & 0xFFFFu;
+            din[2 * p + o][0] = to_b_masked(acc[o], 0, bits);
+            din[2 * p + o][1] = to_b_masked(acc[o], 1, bits);
+        }
+        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.d1, 256, sample, 2 * p, h, din[2 * p], din[2 * p + 1], live);
+    });
     // ---- through W1h and the first hidden layer's ReLU
+    sfor<4>([&](auto pp) {
+        constexpr int p = pp.value;
+        f32x16 acc[2];
+        zero_acc(acc[0]);
+        zero_acc(acc[1]);
+        tile_pair<2, 8, H1 + 32 * p>(ring, acc, reinterpret_cast<const bf8(&)[8][2]>(din[0]));
 #pragma unroll
-    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
-    {
-        bf8 d1only[8][2];
-#pragma unroll
-        for (int t = 0; t < 8; t++) { d1only[t][0] = din[t][0]; d1only[t][1] = din[t][1]; }
-        layer<8, 8, 16>(ws, acc, d1only);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const uint32_t bits = (m1w[t / 2] >> (16 * (t % 2))) & 0xFFFFu;
-        din[8 + t][0] = to_b_masked(acc[t], 0, bits);
-        din[8 + t][1] = to_b_masked(acc[t], 1, bits);
-        store_tile(a.d0, 256, sample, t, h, din[8 + t], live);
-    }
-    // ---- both paths into the bottleneck, plus the density head's column
-#pragma unroll
-    for (int t = 0; t < 8; t++) zero_acc(acc[t]);
-    layer<8, 16, 144>(ws, acc, din);
-    if (a.graw && h == 0) {
-        // head: d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z)), from the saved density; rounded to bf16 like the
-        // gradient the per-layer path hands to the bottleneck's GEMM
-        if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (1.0f - __expf(-a.density[sample])));
-        else acc[0][0] += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
-    }
-    bf8 gxb[8][2];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        gxb[t][0] = to_b(acc[t], 0, false);
-        gxb[t][1] = to_b(acc[t], 1, false);
-        store_tile(a.gx, 256, sample, t, h, gxb[t], live);
-    }
-    // ---- density layer 1 backwards, ReLU of h0
+        for (int o = 0; o < 2; o++) {
+            const uint32_t bits = (m1w[p] >> (16 * o)) & 0xFFFFu;
+            din[8 + 2 * p + o][0] = to_b_masked(acc[o], 0, bits);
+            din[8 + 2 * p + o][1] = to_b_masked(acc[o], 1, bits);
+        }
+        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.d0, 256, sample, 2 * p, h, din[8 + 2 * p], din[9 + 2 * p], live);
+    });
+    // ---- both paths into the bottleneck (plus the density head's column), and density layer 1 backwards on each
+    //      finished pair of gx tiles
     f32x16 a0[2];
     zero_acc(a0[0]);
     zero_acc(a0[1]);
-    layer<2, 8, 400>(ws, a0, gxb);
+    sfor<4>([&](auto pp) {
+        constexpr int p = pp.value;
+        f32x16 acc[2];
+        zero_acc(acc[0]);
+        zero_acc(acc[1]);
+        tile_pair<2, 16, H2 + 72 * p>(ring, acc, din);
+        if constexpr (p == 0) {
+            if (a.graw && h == 0) {
+                // head: d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z)), from the saved density; rounded to bf16 like
+                // the gradient the per-layer path hands to the bottleneck's GEMM
+                if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (1.0f - __expf(-a.density[sample])));
+                else acc[0][0] += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+            }
+        }
+        bf8 gp[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            gp[o][0] = to_b(acc[o], 0, false);
+            gp[o][1] = to_b(acc[o], 1, false);
+        }
+        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gx, 256, sample, 2 * p, h, gp[0], gp[1], live);
+        tile_pair<2, 2, H2 + 72 * p + 64>(ring, a0, gp);
+    });
+    // ---- ReLU of h0
     bf8 gh0[2][2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const uint32_t bits = (mk0 >> (16 * t)) & 0xFFFFu;
         gh0[t][0] = to_b_masked(a0[t], 0, bits);
         gh0[t][1] = to_b_masked(a0[t], 1, bits);
-        store_tile(a.gh0, 64, sample, t, h, gh0[t], live);
     }
+    store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gh0, 64, sample, 0, h, gh0[0], gh0[1], live);
     // ---- density layer 0 backwards: the feature gradient, fp32, natural feature order
     f32x16 gf[NTF];
 #pragma unroll
     for (int ft = 0; ft < NTF; ft++) zero_acc(gf[ft]);
-    layer<NTF, 2, 432>(ws, gf, gh0);
+    tile_pair<NTF, 2, H4>(ring, gf, gh0);
     if (live) {
 #pragma unroll
         for (int ft = 0; ft < NTF; ft++)
@@ -389,7 +459,7 @@ __global__ __launch_bounds__(256) void k_train_bwd(TrainBwdArgs a) {
 
 }  // namespace
 
-extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kChunks * kChunkGroups; }     // 436 used + zero padding
+extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kFragsPadded; }     // 436 / 440 used + zero padding
 
 extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                              const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
@@ -401,15 +471,15 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
                 "train_fwd: null pointer argument");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
-    UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 4 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 4)", act_ld);
+    UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 8 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 8)", act_ld);
     UCN_REQUIRE(!ray_cols || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
     UCN_REQUIRE(!feat_bf16 || F % 8 == 0, "train_fwd: the bf16 feature copy needs F %% 8 == 0, got %u", F);
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
-                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, head != nullptr,
+                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, head != nullptr,
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_fwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_fwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
 }
@@ -426,8 +496,8 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
                    (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, gfeat, (uint32_t)M, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), 2 * kChunkGroups * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }

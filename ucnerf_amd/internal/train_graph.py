@@ -313,10 +313,22 @@ def _acc_vec(v, width, device):
 # Column layout of the one activation buffer ucn_train_fwd writes per sample (bf16 [M, ACT_LD]): adjacent blocks are the
 # concatenated inputs of the reference's layers, so each layer's whole weight gradient -- per-sample blocks, the per-ray
 # direction block AND the bias (the constant-1 column of `aux`) -- is ONE split-K GEMM on a strided view:
-#   [ h2 | h1 | x | aux = (dir_enc(27), 1, 0, 0, 0, 0) | h0 ]
+#   [ h2 | h1 | x | aux = (dir_enc(27), 1, 0, 0, 0, 0) | h0 | bf16 copy of the features (<= 64) | pad ]     rows of 2 KiB:
+#   a row that does not start on a 128-byte line (864 columns) costs the forward kernel 15 %
 #     d1^T [h1 | x | aux] = [gW1h | gW1x | gW1e | gb1]  (models.py:620-640: lin_second_stage_1 over cat([h1, x, enc]))
 #     d0^T [x | aux]      = [gW0x | gW0e | gb0],      gx^T [aux | h0] -> gb_d1 (column 27), gW_d1 (columns 32..95)
-_ACT_H2, _ACT_H1, _ACT_X, _ACT_AUX, _ACT_H0, ACT_LD = 0, 256, 512, 768, 800, 864
+_ACT_H2, _ACT_H1, _ACT_X, _ACT_AUX, _ACT_H0, _ACT_FB, ACT_LD = 0, 256, 512, 768, 800, 864, 1024
+
+
+def _weave(parts, producer, consumer):
+    """Fragment lists of consecutive layers -> the same lists with parts[producer] (4 output-tile PAIRS) and
+    parts[consumer] (whose 8 input tiles are those output tiles) cut into quarters and alternated: pair 0 of the
+    producer, the consumer's fragments for input tiles 0-1, pair 1, input tiles 2-3, ..."""
+    a, b = parts[producer], parts[consumer]
+    assert a.numel() % 4 == 0 and b.numel() % 4 == 0 and consumer == producer + 1
+    qa, qb = a.reshape(4, -1), b.reshape(4, -1)
+    woven = torch.cat([torch.cat([qa[p], qb[p]]) for p in range(4)])
+    return parts[:producer] + [woven] + parts[consumer + 1:]
 
 
 def _head_gather_index(F_in, NB, NW, E, total, device):
@@ -338,7 +350,7 @@ def _head_gather_index(F_in, NB, NW, E, total, device):
     obd1, ob0, ob1, obr = obd0 + 64, obd0 + 64 + NB, obd0 + 64 + NB + NW, obd0 + 64 + NB + 2 * NW
     zero = obr + 3
 
-    def stream(mats):
+    def stream(mats, weave):
         parts = []
         for rows, blocks, nat in mats:
             cols = sum(b[3] for b in blocks)
@@ -350,15 +362,19 @@ def _head_gather_index(F_in, NB, NW, E, total, device):
                 off = torch.where(inside, base + r * rs + (c - start) * cs, off)
                 start += nc
             parts.append(off)
+        parts = _weave(parts, *weave)
         flat = torch.cat(parts)
         assert flat.numel() <= total * 512
         return torch.cat([flat, flat.new_full((total * 512 - flat.numel(),), -1)])
 
+    # forward: the rgb layer's fragments ride behind each pair of the last hidden layer's output tiles; backward: the
+    # density layer's behind each pair of bottleneck-gradient tiles (field_train.hip: the consumer layer runs on every
+    # finished pair, so that only one pair of accumulators is live and two workgroups fit a CU)
     fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oW0, k0, 1, NB)], False),
-                  (NW, [(oW1, k1, 1, NW + NB)], False), (3, [(oWr, NW, 1, NW)], False)])
+                  (NW, [(oW1, k1, 1, NW + NB)], False), (3, [(oWr, NW, 1, NW)], False)], weave=(3, 4))
     bwd = stream([(NW, [(oWr, 1, NW, 3)], True), (NW, [(oW1, 1, k1, NW)], False),
                   (NB, [(oW1 + NW, 1, k1, NW), (oW0, 1, k0, NW)], False), (64, [(oWd1, 1, 64, NB)], False),
-                  (F_in, [(oWd0, 1, F_in, 64)], False)])
+                  (F_in, [(oWd0, 1, F_in, 64)], False)], weave=(2, 3))
     acc_w, acc_b, acc_64 = _acc_order(NW, "cpu"), _acc_order(NB, "cpu"), _acc_order(64, "cpu")
     e = torch.arange(E)
     we = torch.cat([(oW0 + acc_w[:, None] * k0 + NB + e[None, :]).reshape(-1),
@@ -420,7 +436,7 @@ class _FusedHeads(torch.autograd.Function):
             aux = torch.zeros(N, 32, device=dev, dtype=dt)
             aux[:, :E] = eb
             aux[:, E] = 1.0
-            fb = torch.empty(M, F_in, device=dev, dtype=dt) if F_in % 8 == 0 else None
+            fb_in_act = F_in % 8 == 0                                   # the kernel writes the bf16 feature copy into the row
             density, rgb = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
             m0 = torch.empty(M, 2, device=dev, dtype=torch.int32)
             m1, m2 = (torch.empty(M, 2, 4, device=dev, dtype=torch.int32) for _ in range(2))
@@ -428,30 +444,31 @@ class _FusedHeads(torch.autograd.Function):
             base = act.data_ptr()
             _lib.check(lib.ucn_train_fwd(f.data_ptr(), F_in, packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
                                          biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, base + 2 * _ACT_X,
-                                         base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX, _lib.ptr(fb), hd, density.data_ptr(),
+                                         base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX,
+                                         base + 2 * _ACT_FB if fb_in_act else None, hd, density.data_ptr(),
                                          rgb.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), _lib.stream()))
-            if fb is None:
-                fb = f.to(dt)
-        ctx.save_for_backward(fb, act, m0, m1, m2, packed_t, density, rgb)
-        ctx.meta = (N, S, NB, NW, E, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head))
+            if not fb_in_act:
+                act[:, _ACT_FB:_ACT_FB + F_in] = f
+        ctx.save_for_backward(act, m0, m1, m2, packed_t, density, rgb)
+        ctx.meta = (N, S, NB, NW, E, F_in, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head))
         return density, rgb
 
     @staticmethod
     def backward(ctx, g_density, g_rgb):
         lib = _lib.load()
-        fb, act, m0, m1, m2, packed_t, density, rgb = ctx.saved_tensors
-        N, S, NB, NW, E, f_dt, w_dt, b_dt, head = ctx.meta
-        dt, dev, M = torch.bfloat16, fb.device, fb.shape[0]
+        act, m0, m1, m2, packed_t, density, rgb = ctx.saved_tensors
+        N, S, NB, NW, E, F_in, f_dt, w_dt, b_dt, head = ctx.meta
+        dt, dev, M = torch.bfloat16, act.device, act.shape[0]
         with torch.autocast("cuda", enabled=False):
             g_rgb = torch.zeros(M, 3, device=dev) if g_rgb is None else g_rgb.reshape(M, 3).float().contiguous()
             g_density = None if g_density is None else g_density.reshape(-1).float().contiguous()
             d1, d0, gx = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
             dy = torch.empty(M, 4, device=dev, dtype=dt)
-            gfeat = torch.empty(M, fb.shape[1], device=dev)
+            gfeat = torch.empty(M, F_in, device=dev)
             hd = (ctypes.c_float * 4)(*head)
             _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
-                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, fb.shape[1],
+                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in,
                                          d1.data_ptr(), d0.data_ptr(), gx.data_ptr(), gh0.data_ptr(), dy.data_ptr(), gfeat.data_ptr(),
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
@@ -459,13 +476,13 @@ class _FusedHeads(torch.autograd.Function):
             G1a, G1b = _wgrad_cols(d1, act, _ACT_H1, _ACT_AUX), _wgrad_cols(d1, act, _ACT_AUX, _ACT_AUX + 32)
             G1 = torch.cat([G1a, G1b], dim=1)
             G0 = _wgrad_cols(d0, act, _ACT_X, _ACT_AUX + 32)                  # [NW, NB + 32]
-            Gd1 = _wgrad_cols(gx, act, _ACT_AUX, ACT_LD)                      # [NB, 32 + 64]
+            Gd1 = _wgrad_cols(gx, act, _ACT_AUX, _ACT_FB)                     # [NB, 32 + 64]
             Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)                  # [4, NW]
             gW1, gb1 = G1[:, :NW + NB + E], G1[:, NW + NB + E]
             gW0, gb0 = G0[:, :NB + E], G0[:, NB + E]
             gWd1, gbd1 = Gd1[:, 32:], Gd1[:, E]
             gWr, gbr = Gr[:3], _colsum(dy)[:3]
-            gWd0, gbd0 = _wgrad(gh0, fb), _colsum(gh0)
+            gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
         return (gfeat.to(f_dt), None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
                 gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None)
 
