@@ -280,9 +280,11 @@ int ucn_relu_backward_reduce(const void *gy, const void *h, void *d_pre, void *d
  * accelerator.autocast(): bf16 operands, fp32 accumulation), writing every activation the backward needs once:
  * h0 [M,64], x [M,256] (bottleneck), h1, h2 [M,256] as bf16, raw [M] = x[:,0], y [M,3] = pre-sigmoid colour, M = N*S,
  * and the ReLU masks m0 / m1 / m2 (16 bits per 32-feature tile and wave half) for ucn_train_bwd.
- * packed = ucn_train_fwd_fragments() fragments of 64 lanes x 8 bf16 (1 KiB): the five weight matrices in MFMA
- * A-operand order [out tile][in tile][k-step], k permuted to the accumulator layout of the producing layer
- * (ucnerf_amd/internal/train_graph.py::_pack_fragments); biases / per-ray terms in accumulator order
+ * packed = ucn_train_fwd_fragments() fragments of 64 lanes x 8 bf16 (1 KiB), of which the forward reads the first 256:
+ * W_d0, W_d1, then the colour layers COMPOSED with the activation-free bottleneck -- (W0x W_d1) [256 x 64] and
+ * [W1h | W1x W_d1] [256 x 320] -- and W_rgb woven behind each output-tile pair of the last hidden layer, all in MFMA
+ * A-operand order [out tile pair][in tile][k-step][tile of the pair], k permuted to the accumulator layout of the
+ * producing layer (ucnerf_amd/internal/train_graph.py::_head_gather_index); pr0 / pr1 carry W0x b_d1 / W1x b_d1; biases / per-ray terms in accumulator order
  * [tile][wave half][16] (pr0, pr1: [N, 8, 2, 16] = direction block of the colour layer times the ray's encoding
  * plus its bias).  Widths are the reference's (64, 256, 256, 256, 3); feat [M,F] fp32 with F <= 64 (one feature tile up to 32, two above:
  * the first and last matrices then have 4 more fragments). */

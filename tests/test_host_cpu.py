@@ -193,9 +193,10 @@ def test_instance_keeps_its_bound_configuration_after_the_binding_block():
 
 
 def test_fused_heads_weight_preparation_is_one_gather():
-    """train_graph._head_gather_index: ONE gather over the flat bf16 copy of the NeRF field's dense parameters yields the
-    forward and the dgrad fragment streams, the direction blocks / biases in accumulator order -- element for element
-    what the per-matrix packers build from the sliced, transposed and concatenated matrices."""
+    """train_graph._head_gather_index: ONE gather over the flat bf16 copy of the NeRF field's dense parameters (the colour
+    layers composed with the activation-free bottleneck for the forward) yields the forward and the dgrad fragment
+    streams, the direction blocks / biases in accumulator order -- element for element what the per-matrix packers build
+    from the sliced, transposed, concatenated and woven matrices."""
     from ucnerf_amd.internal import train_graph as tg
     torch.manual_seed(0)
     dt = torch.bfloat16
@@ -205,28 +206,32 @@ def test_fused_heads_weight_preparation_is_one_gather():
         Wd0, Wd1, W0 = torch.randn(64, F_in), torch.randn(NB, 64), torch.randn(NW, NB + E)
         W1, Wr = torch.randn(NW, NW + NB + E), torch.randn(3, NW)
         bd0, bd1, b0, b1, br = torch.randn(64), torch.randn(NB), torch.randn(NW), torch.randn(NW), torch.randn(3)
+        Wc0, Wc1 = W0[:, :NB] @ Wd1, W1[:, NW:NW + NB] @ Wd1
+        b0c, b1c = b0 + W0[:, :NB] @ bd1, b1 + W1[:, NW:NW + NB] @ bd1
         idx, n = tg._head_gather_index(F_in, NB, NW, E, T, "cpu")
-        src = torch.cat([t.reshape(-1) for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br)] + [torch.zeros(1)]).to(dt)
+        src = torch.cat([t.reshape(-1) for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0c, b1c, br, Wc0, Wc1)] + [torch.zeros(1)]).to(dt)
         assert src.numel() == n
         got = src[idx]
         W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
         W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
         Wd0b, Wd1b, Wrb = Wd0.to(dt), Wd1.to(dt), Wr.to(dt)
+
         def packed(mats, weave):
             # per-matrix fragment streams of the per-matrix packer, the consumer layer's fragments woven behind each
             # output-tile pair of its producer (field_train.hip), zero-padded to T fragments
             parts = tg._weave([tg._pack_fragments([m], "cpu") for m in mats], *weave)
             flat = torch.cat(parts)
             return torch.cat([flat, flat.new_zeros(T * 512 - flat.numel())])
-        fwd = packed([(Wd0b, True), (Wd1b, False), (W0x, False), (torch.cat([W1h, W1x], 1), False), (Wrb, False)], (3, 4))
+        fwd = packed([(Wd0b, True), (Wd1b, False), (Wc0.to(dt), False), (torch.cat([W1h, Wc1.to(dt)], 1), False), (Wrb, False)], (3, 4))
         bwd = packed([(Wrb.t(), True), (W1h.t(), False), (torch.cat([W1x.t(), W0x.t()], 1), False), (Wd1b.t(), False),
                       (Wd0b.t(), False)], (2, 3))
         assert torch.equal(got[:T * 512], fwd) and torch.equal(got[T * 512:2 * T * 512], bwd)
+        assert int((fwd.reshape(T, 512) != 0).any(dim=1).sum()) <= 248          # what the forward kernel reads: 244 / 248 fragments
         o = 2 * T * 512
         We, be = got[o:o + 2 * NW * E].view(2 * NW, E), got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]
         bv = got[o + 2 * NW * E + 2 * NW:].float()
         eb = torch.randn(5, E).to(dt)
-        for half, (b, We_ref) in enumerate(((b0, W0e), (b1, W1e))):
+        for half, (b, We_ref) in enumerate(((b0c, W0e), (b1c, W1e))):
             pr = torch.addmm(be[half * NW:(half + 1) * NW], eb, We[half * NW:(half + 1) * NW].t()).float()
             assert torch.equal(pr, tg._acc_vec(torch.addmm(b.to(dt), eb, We_ref.t()).float(), NW, "cpu"))
         for got_v, (b, w) in zip((bv[:64], bv[64:64 + NB], bv[64 + NB:]), ((bd0, 64), (bd1, NB), (br, 32))):

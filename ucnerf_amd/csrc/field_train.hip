@@ -6,6 +6,7 @@
 //   x  = W_d1 h0 + b_d1                    [256]     bottleneck; x[0] = raw density
 //   h1 = relu(W0x x  + pr0[ray])           [256]     pr0 = W0e enc + b0, per RAY (computed by the caller, [N, 256])
 //   h2 = relu(W1h h1 + W1x x + pr1[ray])   [256]     the skip connection as a second block of the same GEMM
+//        (evaluated as (W0x W_d1) h0 and (W1x W_d1) h0 with W b_d1 inside pr0 / pr1: see k_train_fwd)
 //   y  = W_rgb h2 + b_rgb                  [3]       pre-sigmoid colour
 //
 // As library GEMMs these layers are HBM-bound on their activations (1 GB in + out per 256x256 product, plus the
@@ -144,7 +145,11 @@ __device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &ac
 constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
 constexpr int kTChunk = 16, kTSlots = 4, kTLead = 2;
 constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
-using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;
+using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;                            // the backward's stream
+// the forward's stream (composed colour layers, see k_train_fwd): 2 NTF 2 + 32 + 32 + 4 (40 + 4) = 244 / 248 fragments
+constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 32 + 4 * 44;
+constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 256
+using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
 
 template <int... Is, class F>
 __device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -154,8 +159,8 @@ __device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequen
 // P output tiles (a PAIR, or one) from NT_IN input tiles: acc[o2] += A(frag) . in[it][s], fragments [it][s][o2] from
 // stream position G0.  The two tiles of a pair alternate (two MFMAs into the same accumulator do not issue back to
 // back); only the pair's 32 accumulator registers are live, the caller converts / stores it before the next pair.
-template <int P, int NT_IN, int G0>
-__device__ __forceinline__ void tile_pair(TRing &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
+template <int P, int NT_IN, int G0, class RING>
+__device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
@@ -167,7 +172,8 @@ __device__ __forceinline__ void tile_pair(TRing &ring, f32x16 (&acc)[P], const b
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     });
 }
-__device__ __forceinline__ void ring_start(TRing &ring) {
+template <class RING>
+__device__ __forceinline__ void ring_start(RING &ring) {
     rstatic_for<kTLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
 }
 
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
     const uint32_t sample = live ? s0 : a.M - 1;
     const uint32_t ray = sample / a.S;
     extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
-    TRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
+    FRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
     ring_start(ring);
 
     // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
@@ -210,11 +216,17 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
         dst[1] = src[1];
     }
     ring.template boundary<0>();            // chunk 0 and the feature loads above land together
-    // stream positions: L0 | L1: 4 pairs x 8 | L2: 4 pairs x 32 | 4 x (L3 pair: 64, then the rgb layer's fragments for the
-    // two h2 tiles just finished: 4)
-    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 128;
+    // The bottleneck x = W_d1 h0 + b_d1 has NO activation behind it (models.py:508) and only linear maps consume it: the
+    // colour layers take it COMPOSED, (W0x W_d1) h0 and (W1x W_d1) h0 (the host forms the two 256 x 64 products and folds
+    // W b_d1 into the per-ray terms every step), exactly like the rendering kernel.  x itself is still computed -- the
+    // backward's weight gradients and the density head need it -- but only to be stored: 244 fragments instead of 436, and
+    // the 64 registers that held x as an operand are free, which is what lets two workgroups share a CU without spills.
+    // stream positions: L0 | L1: 4 pairs x 8 | L2': 4 pairs x 8 | 4 x (L3' pair: [h1 (8 tiles) | h0 (2 tiles)] = 40, then the
+    // rgb layer's fragments for the two h2 tiles just finished: 4)
+    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 32;
     // ---- density layer 0
-    bf8 h0[2][2];
+    bf8 hin[10][2];                        // tiles 0..7: h1 (filled below), 8..9: h0  -- the order of [W1h | W1x W_d1]
+    bf8 (&h0)[2][2] = reinterpret_cast<bf8(&)[2][2]>(hin[8]);
     {
         f32x16 a0[2];
         load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
@@ -229,22 +241,24 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
         if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     }
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
-    bf8 xin[16][2];                         // tiles 0..7: h1 (filled below), 8..15: x  -- the order of W1 = [W1h | W1x]
+    bf8 x0[2];                              // tile 0, k-step 0 of x: its first value is the raw density
     sfor<4>([&](auto pp) {
         constexpr int p = pp.value;
         f32x16 acc[2];
         load_acc(a.bias_d1 + ((2 * p) * 2 + h) * 16, acc[0]);
         load_acc(a.bias_d1 + ((2 * p + 1) * 2 + h) * 16, acc[1]);
         tile_pair<2, 2, G1 + 8 * p>(ring, acc, h0);
+        bf8 xp[2][2];
 #pragma unroll
         for (int o = 0; o < 2; o++) {
-            xin[8 + 2 * p + o][0] = to_b(acc[o], 0, false);
-            xin[8 + 2 * p + o][1] = to_b(acc[o], 1, false);
+            xp[o][0] = to_b(acc[o], 0, false);
+            xp[o][1] = to_b(acc[o], 1, false);
         }
-        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xin[8 + 2 * p], xin[9 + 2 * p], live);
+        if constexpr (p == 0) x0[0] = xp[0][0];
+        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);
     });
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
-        const uint4 q = __builtin_bit_cast(uint4, xin[8][0]);
+        const uint4 q = __builtin_bit_cast(uint4, x0[0]);
         const float rawv = __uint_as_float(q.x << 16);
         // head: F.softplus (beta 1, threshold 20) of the bf16-rounded linear output, in fp32 like autocast runs it
         const float z = rawv + a.density_bias;
@@ -258,13 +272,13 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             f32x16 acc[2];
             load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
             load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
-            tile_pair<2, 8, G2 + 32 * p>(ring, acc, reinterpret_cast<const bf8(&)[8][2]>(xin[8]));
+            tile_pair<2, 2, G2 + 8 * p>(ring, acc, h0);
 #pragma unroll
             for (int o = 0; o < 2; o++) {
-                xin[2 * p + o][0] = to_b(acc[o], 0, true);
-                xin[2 * p + o][1] = to_b(acc[o], 1, true);
+                hin[2 * p + o][0] = to_b(acc[o], 0, true);
+                hin[2 * p + o][1] = to_b(acc[o], 1, true);
             }
-            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, xin[2 * p], xin[2 * p + 1], live);
+            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, hin[2 * p], hin[2 * p + 1], live);
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
         });
         if (live) a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             f32x16 acc[2];
             load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
             load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
-            tile_pair<2, 16, G3 + 68 * p>(ring, acc, xin);
+            tile_pair<2, 10, G3 + 44 * p>(ring, acc, hin);
             bf8 hp[2][2];
 #pragma unroll
             for (int o = 0; o < 2; o++) {
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
             f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
             zero_acc(yo[0]);
-            tile_pair<1, 2, G3 + 68 * p + 64>(ring, yo, hp);
+            tile_pair<1, 2, G3 + 44 * p + 40>(ring, yo, hp);
             y3[0] += yo[0][0]; y3[1] += yo[0][1]; y3[2] += yo[0][2];
         });
         if (live) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -459,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
 
 }  // namespace
 
-extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kFragsPadded; }     // 436 / 440 used + zero padding
+extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kFragsPadded; }     // backward: 436 / 440 used; forward: 244 / 248
 
 extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                              const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,

@@ -332,7 +332,8 @@ def _weave(parts, producer, consumer):
 
 
 def _head_gather_index(F_in, NB, NW, E, total, device):
-    """ONE gather index over the flat bf16 copy of (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br, 0) that yields, in this
+    """ONE gather index over the flat bf16 copy of (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0', b1', br, W0x Wd1, W1x Wd1, 0) -- the
+    colour layers composed with the activation-free bottleneck and W bd1 folded into their biases -- that yields, in this
     order: the forward fragment stream, the dgrad (transposed) fragment stream, the direction blocks of W0 / W1 with
     rows in accumulator order [2 NW, E], their biases [2 NW], and bd0 / bd1 / br in accumulator order (64 + NB + 32).
     A logical matrix is a list of column blocks (base, row_stride, col_stride, ncols) of the flat source."""
@@ -348,7 +349,9 @@ def _head_gather_index(F_in, NB, NW, E, total, device):
     oWr = oW1 + NW * k1
     obd0 = oWr + 3 * NW
     obd1, ob0, ob1, obr = obd0 + 64, obd0 + 64 + NB, obd0 + 64 + NB + NW, obd0 + 64 + NB + 2 * NW
-    zero = obr + 3
+    oWc0 = obr + 3
+    oWc1 = oWc0 + NW * 64
+    zero = oWc1 + NW * 64
 
     def stream(mats, weave):
         parts = []
@@ -370,8 +373,8 @@ def _head_gather_index(F_in, NB, NW, E, total, device):
     # forward: the rgb layer's fragments ride behind each pair of the last hidden layer's output tiles; backward: the
     # density layer's behind each pair of bottleneck-gradient tiles (field_train.hip: the consumer layer runs on every
     # finished pair, so that only one pair of accumulators is live and two workgroups fit a CU)
-    fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oW0, k0, 1, NB)], False),
-                  (NW, [(oW1, k1, 1, NW + NB)], False), (3, [(oWr, NW, 1, NW)], False)], weave=(3, 4))
+    fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oWc0, 64, 1, 64)], False),
+                  (NW, [(oW1, k1, 1, NW), (oWc1, 64, 1, 64)], False), (3, [(oWr, NW, 1, NW)], False)], weave=(3, 4))
     bwd = stream([(NW, [(oWr, 1, NW, 3)], True), (NW, [(oW1, 1, k1, NW)], False),
                   (NB, [(oW1 + NW, 1, k1, NW), (oW0, 1, k0, NW)], False), (64, [(oWd1, 1, 64, NB)], False),
                   (F_in, [(oWd0, 1, F_in, 64)], False)], weave=(2, 3))
@@ -418,7 +421,12 @@ class _FusedHeads(torch.autograd.Function):
             zero = _FRAG_CACHE.get(("zero1", str(dev)))
             if zero is None:
                 zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
-            src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0, b1, br)] + [zero]).to(dt)
+            # the bottleneck has no activation (models.py:508): the forward kernel takes the colour layers composed with it,
+            # (W0x Wd1) h0 and (W1x Wd1) h0, like the rendering kernel; x is still computed and stored for the backward
+            W0x32, W1x32, Wd132, bd132 = W0.detach()[:, :NB].float(), W1.detach()[:, NW:NW + NB].float(), Wd1.detach().float(), bd1.detach().float()
+            Wc0, Wc1 = W0x32 @ Wd132, W1x32 @ Wd132
+            b0c, b1c = torch.addmv(b0.detach().float(), W0x32, bd132), torch.addmv(b1.detach().float(), W1x32, bd132)
+            src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0c, b1c, br, Wc0, Wc1)] + [zero]).to(dt)
             assert src.numel() == n_src
             got = src[idx]
             packed, packed_t = got[:T * 512], got[T * 512:2 * T * 512]
