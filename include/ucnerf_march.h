@@ -131,6 +131,10 @@ int ucn_tsdf_integrate(const float *voxel_world, uint32_t N, const float *w2c /*
  * (72 KiB in all), so that exactly one workgroup of each fits a CU (registers: 2 x 104 + 296 of 512 per SIMD lane).
  * Results do not depend on it. */
 #define UCN_LAUNCH_CORESIDENT 0x100
+/* OR-ed into ucn_march_features' layout argument: field->embeddings points to an IEEE half copy of the table ([rows, C]
+ * _Float16) -- what the reference gathers under autocast (gridencoder/grid.py:41-44: `embeddings.to(torch.half)` when
+ * autocast is on and C is even).  The interpolation arithmetic stays fp32. */
+#define UCN_TABLE_F16 0x200
 
 /* ref: render.py:94-152 cast_rays + coord.py:60-116 contraction + grid.py:158-174 /
  * gridencoder.cu:87-199 + models.py:494-496 (erf damping, mean over the 6 multisamples).

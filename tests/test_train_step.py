@@ -672,3 +672,32 @@ def test_proposal_field_train_kernels(F_in, M, monkeypatch):
     assert float((outs["1"][1] - outs["0"][1]).abs().max()) <= 1e-5 * max(1.0, float(outs["0"][1].abs().max()))
     for a, b in zip(outs["1"][2], outs["0"][2]):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_half_table_gather_equals_the_fp32_gather_of_the_rounded_table():
+    """Under autocast the training forward gathers a HALF copy of the tables, as the reference's _grid_encode does
+    (gridencoder/grid.py:41-44).  The kernel converts each row to fp32 and interpolates in fp32, so its features are
+    bit-identical to the fp32-table kernel run on the table rounded to half -- every level type (dense, hashed, pairs)."""
+    from ucnerf_amd.internal import train_graph as tg
+    spec = rm.make_spec("tiny")
+    model, _ = hip_model_for(spec, rm.init_state(spec, seed=41))
+    model.train()
+    N = 300
+    rays = H.to_dev(rm.synthetic_rays(N, seed=42))
+    g = torch.Generator(device="cuda").manual_seed(43)
+    for mlp, S in ((model.prop_mlp_0, 64), (model.nerf_mlp, 128)):
+        sdist = torch.sort(torch.rand(N, S + 1, device="cuda", generator=g), dim=-1).values.contiguous()
+        basis = torch.nn.functional.normalize(torch.randn(N, 2, 3, device="cuda", generator=g), dim=-1).reshape(N, 6).contiguous()
+        flip, spin = torch.rand(N, S, device="cuda", generator=g), torch.rand(N, S, device="cuda", generator=g)
+        f32 = lambda k: rays[k].reshape(N, -1).float().contiguous()
+        geom = (sdist, f32("near"), f32("far"), f32("origins"), f32("directions"), basis, f32("radii"), flip, spin)
+        emb = mlp.encoder.embeddings
+        with torch.no_grad():
+            half, c16, _ = tg._FieldFeatures.apply(emb, mlp, geom, N, S, 0.5, 0, True)
+            keep = emb.data.clone()
+            emb.data.copy_(keep.half().float())
+            full, c32, _ = tg._FieldFeatures.apply(emb, mlp, geom, N, S, 0.5, 0, False)
+            emb.data.copy_(keep)
+        assert torch.equal(half, full) and torch.equal(c16, c32)
+        assert float(half.abs().max()) > 0

@@ -11,7 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
 ABI_VERSION = 15
-LAUNCH_CORESIDENT = 0x100          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
+LAUNCH_CORESIDENT = 0x100
+TABLE_F16 = 0x200          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

@@ -94,9 +94,55 @@ __device__ __forceinline__ bool in_unit_cube(float px, float py, float pz) {
     return !(px < 0.0f || px > 1.0f || py < 0.0f || py > 1.0f || pz < 0.0f || pz > 1.0f);   // gridencoder.cu:110-135
 }
 
+// One table row -> C floats.  TT = float (the fp32 tables of rendering and of the fp32 training path) or _Float16: under
+// autocast the reference gathers a HALF copy of the table (grid.py:41-44: `embeddings.to(torch.half)` whenever autocast is on
+// and C is even) -- half the bytes per corner, and a 2 MiB level slice that fits an XCD's L2 beside the streaming traffic.
+// The interpolation arithmetic stays fp32 here (the reference's is half: this side is the more exact one).
+template <uint32_t C, typename TT>
+__device__ __forceinline__ void load_row(const TT *__restrict__ tab, uint32_t row, float (&v)[C]) {
+    const TT *r = tab + (size_t)row * C;
+    if constexpr (sizeof(TT) == 4) {
+        if constexpr (C == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(r);
+            v[0] = t.x; v[1] = t.y;
+        } else if constexpr (C == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(r);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) v[c] = (float)r[c];
+        }
+    } else {
+        typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 hx4 __attribute__((ext_vector_type(4)));
+        if constexpr (C == 2) {
+            const hx2 t = *reinterpret_cast<const hx2 *>(r);
+            v[0] = (float)t[0]; v[1] = (float)t[1];
+        } else if constexpr (C == 4) {
+            const hx4 t = *reinterpret_cast<const hx4 *>(r);
+            v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) v[c] = (float)r[c];
+        }
+    }
+}
+// rows r and r ^ 1 (an aligned pair, C = 2) in one request: out[0..1] = row (r & ~1), out[2..3] = row (r | 1)
+template <typename TT>
+__device__ __forceinline__ void load_row_pair(const TT *__restrict__ tab, uint32_t row_even, float (&o)[4]) {
+    if constexpr (sizeof(TT) == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(tab + (size_t)row_even * 2);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+        typedef _Float16 hx4 __attribute__((ext_vector_type(4)));
+        const hx4 t = *reinterpret_cast<const hx4 *>(tab + (size_t)row_even * 2);
+        o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3];
+    }
+}
+
 // sum_j damp_j * trilerp(point_j) for one level
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float *__restrict__ tab,
+template <uint32_t C, bool HASHED, bool POW2, typename TT>
+__device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const TT *__restrict__ tab,
                                                  const float (&u)[6][3], const float (&rs)[6], uint32_t G,
                                                  float (&acc)[C]) {
 #pragma unroll
@@ -109,19 +155,7 @@ __device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float
             corner_rows<HASHED, POW2>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
             float v[8][C];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const float *r = tab + (size_t)rows[k] * C;
-                if constexpr (C == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(r);
-                    v[k][0] = t.x; v[k][1] = t.y;
-                } else if constexpr (C == 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(r);
-                    v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
-                } else {
-#pragma unroll
-                    for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
-                }
-            }
+            for (uint32_t k = 0; k < 8; k++) load_row<C, TT>(tab, rows[k], v[k]);
             corner_weights(fx, fy, fz, w);
             float f[C];
 #pragma unroll
@@ -142,8 +176,8 @@ __device__ __forceinline__ void level_accumulate(const UcnLevel &lv, const float
 // lattice cell.  Then its 8 corner rows are derived and fetched once instead of six times; every point still forms its
 // own weights and accumulates in level_accumulate's order, so the result is bit-identical.  Lanes whose points straddle a
 // cell boundary take the general path (the branch diverges; the caller enables this only where straddling is rare).
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, const float *__restrict__ tab,
+template <uint32_t C, bool HASHED, bool POW2, typename TT>
+__device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, const TT *__restrict__ tab,
                                                         const float (&u)[6][3], const float (&rs)[6], float (&acc)[C]) {
     float fx[6], fy[6], fz[6];
     uint32_t x0 = 0, y0 = 0, z0 = 0;
@@ -161,7 +195,7 @@ __device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, cons
         }
     }
     if (!same) {
-        level_accumulate<C, HASHED, POW2>(lv, tab, u, rs, 6, acc);
+        level_accumulate<C, HASHED, POW2, TT>(lv, tab, u, rs, 6, acc);
         return;
     }
 #pragma unroll
@@ -187,17 +221,7 @@ __device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, cons
         uint32_t row;
         if constexpr (POW2) row = idx & lv.mask;
         else row = idx < lv.rows ? idx : idx % lv.rows;
-        const float *r = tab + (size_t)row * C;
-        if constexpr (C == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(r);
-            v[k][0] = t.x; v[k][1] = t.y;
-        } else if constexpr (C == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(r);
-            v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
-        } else {
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) v[k][c] = r[c];
-        }
+        load_row<C, TT>(tab, row, v[k]);
     }
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
@@ -223,7 +247,8 @@ __device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, cons
 // together.  For an even lattice x the corners (x, y, z) and (x+1, y, z) hash to rows r and r^1 -- one
 // aligned 16-byte pair; for an odd x they are unrelated and cost two requests.  6 requests per point on
 // average instead of 8.  Same values, same fmaf order as level_accumulate.
-__device__ __forceinline__ void level_accumulate_pairs(const UcnLevel &lv, const float *__restrict__ tab,
+template <typename TT>
+__device__ __forceinline__ void level_accumulate_pairs(const UcnLevel &lv, const TT *__restrict__ tab,
                                                        const float (&u)[6][3], const float (&rs)[6], float (&acc)[2]) {
     acc[0] = acc[1] = 0.0f;
 #pragma unroll
@@ -238,17 +263,15 @@ __device__ __forceinline__ void level_accumulate_pairs(const UcnLevel &lv, const
 #pragma unroll
                 for (uint32_t q = 0; q < 4; q++) {                  // (y, z) choice; corners 2q (x0) and 2q+1 (x0+1)
                     const uint32_t r0 = rows[2 * q];
-                    const float4 t = *reinterpret_cast<const float4 *>(tab + (size_t)(r0 & ~1u) * 2);
+                    float t[4];
+                    load_row_pair<TT>(tab, r0 & ~1u, t);
                     const bool hi = (r0 & 1u) != 0u;
-                    v[2 * q][0] = hi ? t.z : t.x; v[2 * q][1] = hi ? t.w : t.y;
-                    v[2 * q + 1][0] = hi ? t.x : t.z; v[2 * q + 1][1] = hi ? t.y : t.w;
+                    v[2 * q][0] = hi ? t[2] : t[0]; v[2 * q][1] = hi ? t[3] : t[1];
+                    v[2 * q + 1][0] = hi ? t[0] : t[2]; v[2 * q + 1][1] = hi ? t[1] : t[3];
                 }
             } else {
 #pragma unroll
-                for (uint32_t k = 0; k < 8; k++) {
-                    const float2 t = *reinterpret_cast<const float2 *>(tab + (size_t)rows[k] * 2);
-                    v[k][0] = t.x; v[k][1] = t.y;
-                }
+                for (uint32_t k = 0; k < 8; k++) load_row<2, TT>(tab, rows[k], v[k]);
             }
             corner_weights(fx, fy, fz, w);
             float f0 = 0.0f, f1 = 0.0f;
@@ -461,14 +484,14 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *_
 constexpr uint32_t kSharedCellMaxRes = UCN_SHARED_CELL_MAX_RES;     // dense levels up to this resolution use level_accumulate_shared
 
 // layout: 0 = [L][B][C] (b as given), 1 = [B][L*C]
-template <uint32_t C>
-__device__ __forceinline__ void featurise(const UcnLevels &lvls, const float *__restrict__ table, uint32_t lvl0,
+template <uint32_t C, typename TT>
+__device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__restrict__ table, uint32_t lvl0,
                                           uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
                                           size_t B, size_t b, float *__restrict__ out, bool sample_major) {
     const uint32_t F_out = lvls.L * C;
     for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
-        const float *tab = table + (size_t)lv.first_row * C;
+        const TT *tab = table + (size_t)lv.first_row * C;
         float acc[C];
         // wave-uniform dispatch on the level's addressing mode (lv lives in SGPRs)
         if (lv.hashed && G == 6 && lv.resolution <= kSharedCellMaxRes) {
@@ -639,8 +662,8 @@ static LevelGroups make_groups(const UcnLevels &lv, uint32_t levels_per_block) {
 }
 
 // layout: 0 = [L][N*S][C] with b = ray*S+s; 1 = [N*S][L*C]; 2 = [L][S*N][C] with b = s*N+ray
-template <uint32_t C, uint32_t TPB>
-__global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const float *__restrict__ table, RayInputs in,
+template <uint32_t C, uint32_t TPB, typename TT = float>
+__global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const TT *__restrict__ table, RayInputs in,
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
                                                         LevelGroups grp, int layout, float *__restrict__ features,
                                                         float *__restrict__ coord_out, float *__restrict__ tmean_out) {
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const fl
     float u[6][3], rs[6], csum[3], tsum;
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = grp.lo[blockIdx.y], lvl1 = grp.lo[blockIdx.y + 1];
-    featurise<C>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
+    featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
     if (blockIdx.y == 0) {
         const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
         if (coord_out) {
@@ -1120,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_points_features(UcnLevels lvls, const f
     }
     const uint32_t lvl0 = blockIdx.y * lpb;
     const uint32_t lvl1 = lvl0 + lpb < lvls.L ? lvl0 + lpb : lvls.L;
-    featurise<C>(lvls, table, lvl0, lvl1, u, rs, G, Bn, b, features, false);
+    featurise<C, float>(lvls, table, lvl0, lvl1, u, rs, G, Bn, b, features, false);
     if (blockIdx.y == 0 && coord_out) {
         coord_out[b * 3 + 0] = cs0 / (float)G; coord_out[b * 3 + 1] = cs1 / (float)G; coord_out[b * 3 + 2] = cs2 / (float)G;
     }
@@ -1162,7 +1185,9 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
                 "march_features: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
     const bool coresident = (layout & UCN_LAUNCH_CORESIDENT) != 0;
-    layout &= ~UCN_LAUNCH_CORESIDENT;
+    const bool half_table = (layout & UCN_TABLE_F16) != 0;
+    layout &= ~(UCN_LAUNCH_CORESIDENT | UCN_TABLE_F16);
+    UCN_REQUIRE(!(half_table && coresident), "march_features: the co-resident launch shape reads fp32 tables");
     UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
@@ -1183,7 +1208,11 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     const dim3 grid(ucn_div_up(B, tpb), grp.n);
 #define UCN_MF(CC)                                                                                                        \
     do {                                                                                                                  \
-        if (coresident)                                                                                                   \
+        if (half_table)                                                                                                   \
+            hipLaunchKernelGGL((k_march_features<CC, 256, _Float16>), grid, dim3(256), lds, st, lv,                       \
+                               reinterpret_cast<const _Float16 *>(f->embeddings), in, hx, std_scale, N, S, grp, layout,   \
+                               features_out, coord_out, tmean_out);                                                       \
+        else if (coresident)                                                                                              \
             hipLaunchKernelGGL((k_march_features<CC, 512>), grid, dim3(512), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
                                grp, layout, features_out, coord_out, tmean_out);                                          \
         else                                                                                                              \

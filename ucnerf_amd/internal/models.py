@@ -348,6 +348,8 @@ class Model(nn.Module):
     #                                      evaluates every sample (models.py:221-243).  0 = off: on a field whose samples all
     #                                      carry weight (random initialisation) the extra density pass is pure overhead
 
+    autocast_half_tables: bool = True     # training under autocast gathers a HALF copy of the tables, like the reference's
+    #                                      _grid_encode (grid.py:41-44); False keeps the fp32 tables (more exact, 2x the bytes)
     sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background
     #                                      weight 1 - sum(weights of the last level) reaches this value; the others get
     #                                      sky_rgbs = 0 (their pixel moves by < sky_min_background * |A_sky| through

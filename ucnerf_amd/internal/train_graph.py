@@ -32,15 +32,25 @@ class _FieldFeatures(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb):
+    def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb, half_table=False):
         lib = _lib.load()
         desc = mlp.grid_field()
         L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
+        layout = 1
+        if half_table:
+            # gridencoder/grid.py:41-44: under autocast (and C even) the reference gathers `embeddings.to(torch.half)`.
+            # Same here -- half the bytes per corner, a 2 MiB level slice per XCD L2 -- with fp32 interpolation arithmetic
+            # (the reference's is half); the table gradient stays fp32 (grid.py:77-89 converts it back as well)
+            emb16 = embeddings.detach().to(torch.half)
+            d16 = _lib.UcnField()
+            ctypes.memmove(ctypes.byref(d16), ctypes.byref(desc), ctypes.sizeof(_lib.UcnField))
+            d16.embeddings = emb16.data_ptr()
+            desc, layout = d16, 1 | _lib.TABLE_F16
         feat = torch.empty(N * S, L * C, device=embeddings.device)
         coord = torch.empty(N, S, 3, device=embeddings.device)
         tmean = torch.empty(N, S, device=embeddings.device)
         _lib.check(lib.ucn_march_features(ctypes.byref(desc), *[_lib.ptr(t) for t in geom], float(std_scale), N, S,
-                                          int(lpb), 1, feat.data_ptr(), coord.data_ptr(), tmean.data_ptr(), _lib.stream()))
+                                          int(lpb), layout, feat.data_ptr(), coord.data_ptr(), tmean.data_ptr(), _lib.stream()))
         ctx.mlp, ctx.geom, ctx.dims = mlp, geom, (N, S, float(std_scale), int(lpb))
         ctx.mark_non_differentiable(coord, tmean)
         return feat, coord, tmean
@@ -65,7 +75,7 @@ class _FieldFeatures(torch.autograd.Function):
         ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.grid_field()), N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.grid_field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
                                                    N, S, 0, layout, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
 class GradientScaler(torch.autograd.Function):
@@ -751,8 +761,9 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
                                     0 if jitter is None else jitter.shape[1], max_jitter, N, S, sdist.data_ptr(), st))
         _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
         geom = (sdist, near, far, o, d, basis, rad, flip, spin)
+        half_table = torch.is_autocast_enabled() and mlp.encoder.level_dim % 2 == 0 and getattr(model, 'autocast_half_tables', True)
         feat, coord, tmean = _FieldFeatures.apply(mlp.encoder.embeddings, mlp, geom, N, S, model.std_scale,
-                                                  model.levels_per_block)
+                                                  model.levels_per_block, half_table)
         density, rgbs = field_heads(mlp, feat, vd, N, S)
         if getattr(cfg, 'brightness_correction', False):              # models.py:233-235 (gated on this flag)
             rgbs, density = GradientScaler.apply(rgbs, density, tmean)
