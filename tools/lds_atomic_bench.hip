@@ -5,6 +5,7 @@
 //   pattern 5: like 4 but ONE 8-byte read-modify-write under "this wave owns the row" (non-atomic ceiling)
 //   pattern 6: like 4 but ONE 8-byte compare-and-swap loop (exact fp32 adds of both channels)
 //   pattern 7: like 6, 1 lane in 4 active      8: two ds_add_u64 per row (fixed-point alternative; 8192 rows)
+//   pattern 9 / 10: one ds_pk_add_f16 / ds_pk_add_bf16 per 4-byte row (both channels of a C = 2 row as a 16-bit pair)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -30,7 +31,12 @@ __global__ __launch_bounds__(1024) void k_lds(float *out) {
         if (PATTERN >= 4) w &= ~1u;
         if (PATTERN == 8) w &= ~3u;
         if (!act) continue;
-        if (PATTERN == 5) {
+        if (PATTERN == 9 || PATTERN == 10) {                      // one packed 2 x 16-bit float add per 4-byte row
+            const uint32_t addr = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)(s + w);
+            const uint32_t one2 = PATTERN == 9 ? 0x3C003C00u : 0x3F803F80u;     // (1, 1) as half2 / bf16x2
+            if (PATTERN == 9) asm volatile("ds_pk_add_f16 %0, %1" ::"v"(addr), "v"(one2) : "memory");
+            else asm volatile("ds_pk_add_bf16 %0, %1" ::"v"(addr), "v"(one2) : "memory");
+        } else if (PATTERN == 5) {
             float2 *p = reinterpret_cast<float2 *>(s + w);
             float2 v = *p; v.x += 1.0f; v.y += 1.0f; *p = v;
         } else if (PATTERN == 6 || PATTERN == 7) {
@@ -93,5 +99,7 @@ int main() {
     run<6, true>("random rows, float2 CAS loop");
     run<7, true>("random rows, float2 CAS loop, 1/4 lanes");
     run<8, true>("random rows, 2 x ds_add_u64");
+    run<9, true>("random rows of 4 B, ds_pk_add_f16");
+    run<10, true>("random rows of 4 B, ds_pk_add_bf16");
     return 0;
 }
