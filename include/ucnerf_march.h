@@ -250,6 +250,11 @@ int ucn_hash_decay(const float *embeddings, const int32_t *offsets_host, uint32_
 /* ref: train_utils.py:342-344 `param.grad.nan_to_num_()` for every parameter: `count` fp32 DEVICE tensors (HOST arrays of
  * their pointers and element counts) sanitised in place by one launch per 48 tensors. */
 int ucn_nan_to_num_many(float *const *tensors_host, const uint64_t *numel_host, uint32_t count, ucn_stream_t stream);
+/* ucn_adam_step on `count` small tensors that share the hyper-parameters and the step count (one parameter group) in
+ * one launch per 24 tensors: HOST arrays of DEVICE pointers / element counts. */
+int ucn_adam_step_many(float *const *params_host, float *const *grads_host, float *const *exp_avg_host,
+                       float *const *exp_avg_sq_host, const uint64_t *numel_host, uint32_t count, float lr, float beta1,
+                       float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream);
 int ucn_distortion_loss(const float *t /*[N,S+1]*/, const float *w /*[N,S]*/, uint32_t N, uint32_t S,
                         const float *g_loss, float *out, ucn_stream_t stream);
 /* ref: train_utils.py:247-270 anti_interlevel_loss for ONE proposal level (stepfun.py:395-403 blur_stepfun +

@@ -204,11 +204,11 @@ def test_composite_backward_matches_oracle_autograd(S, opaque):
 
 @pytest.mark.gpu
 def test_fused_adam_matches_torch_adam_and_shares_its_state():
-    """FusedAdam (ucn_adam_step on the large tensors, torch's own path on the rest) vs torch.optim.Adam on the host
+    """FusedAdam (ucn_adam_step on the large tensors, ucn_adam_step_many on the small ones) vs torch.optim.Adam on the host
     after clip_gradients' nan_to_num, three steps with a changing learning rate; gradients contain NaN / +-inf."""
     from ucnerf_amd.internal import train_utils as tu
     g = torch.Generator().manual_seed(5)
-    shapes = [((1 << 20) + 3,), (600000, 2), (64, 32), (3,)]                 # two fused (one with a ragged tail), two not
+    shapes = [((1 << 20) + 3,), (600000, 2), (64, 32), (3,)]                 # two with their own launch (one ragged), two batched
     ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
     dev = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
     o_ref = torch.optim.Adam(ref, lr=0.01, betas=(0.9, 0.99), eps=1e-8)

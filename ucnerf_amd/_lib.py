@@ -82,6 +82,7 @@ SIGNATURES = {
     "ucn_bias_relu": [c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_relu_backward_reduce": [c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp],
     "ucn_nan_to_num_many": [c_vp, c_vp, c_u32, c_vp],
+    "ucn_adam_step_many": [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_f32, c_f32, c_f32, c_f32, c_u32, c_i32, c_vp],
     "ucn_hash_decay": [c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_prop_train_fwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_vp],
     "ucn_prop_train_bwd_ws_floats": [c_u32, c_u64],

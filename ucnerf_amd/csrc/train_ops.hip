@@ -411,7 +411,58 @@ __global__ __launch_bounds__(256) void k_nan_to_num_many(ManyTensors t) {
     }
 }
 
+// The same Adam step (k_adam_step's arithmetic, element by element) on up to kAdamMany SMALL tensors of one parameter
+// group in one launch: blockIdx.y = tensor.  torch's foreach path takes seven launches (~105 us) for the 16 dense-layer
+// parameters of the two fields.
+constexpr int kAdamMany = 24;
+struct AdamMany {
+    float *p[kAdamMany], *g[kAdamMany], *m[kAdamMany], *v[kAdamMany];
+    uint32_t n[kAdamMany];
+};
+__global__ __launch_bounds__(256) void k_adam_step_many(AdamMany t, float w1, float beta2, float w2, float bc2_sqrt, float eps, float neg_step,
+                                                        int sanitize) {
+    float *__restrict__ p = t.p[blockIdx.y], *__restrict__ g = t.g[blockIdx.y], *__restrict__ m = t.m[blockIdx.y],
+                        *__restrict__ v = t.v[blockIdx.y];
+    const uint32_t n = t.n[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float gk = sanitize ? nan_to_num0(g[i]) : g[i];
+        if (sanitize) g[i] = gk;
+        const float a = fmaf(w1, gk - m[i], m[i]);
+        const float b = fmaf(w2 * gk, gk, v[i] * beta2);
+        m[i] = a;
+        v[i] = b;
+        p[i] = fmaf(neg_step, a / (sqrtf(b) / bc2_sqrt + eps), p[i]);
+    }
+}
+
 }  // namespace
+
+extern "C" int ucn_adam_step_many(float *const *params_host, float *const *grads_host, float *const *exp_avg_host,
+                                  float *const *exp_avg_sq_host, const uint64_t *numel_host, uint32_t count, float lr, float beta1,
+                                  float beta2, float eps, uint32_t step, int sanitize_grad, ucn_stream_t stream) {
+    UCN_REQUIRE(count == 0 || (params_host && grads_host && exp_avg_host && exp_avg_sq_host && numel_host),
+                "adam_step_many: null pointer argument");
+    UCN_REQUIRE(step >= 1, "adam_step_many: step counts from 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (uint32_t base = 0; base < count; base += kAdamMany) {
+        AdamMany t{};
+        const uint32_t k = count - base < (uint32_t)kAdamMany ? count - base : (uint32_t)kAdamMany;
+        uint64_t biggest = 0;
+        for (uint32_t i = 0; i < k; i++) {
+            UCN_REQUIRE(numel_host[base + i] < 0xFFFFFFFFull, "adam_step_many: tensor %u too large", base + i);
+            t.p[i] = params_host[base + i]; t.g[i] = grads_host[base + i];
+            t.m[i] = exp_avg_host[base + i]; t.v[i] = exp_avg_sq_host[base + i];
+            t.n[i] = (uint32_t)numel_host[base + i];
+            biggest = numel_host[base + i] > biggest ? numel_host[base + i] : biggest;
+        }
+        if (biggest == 0) continue;
+        const uint32_t bx = (uint32_t)(ucn_div_up(biggest, 256) < 512 ? ucn_div_up(biggest, 256) : 512);
+        hipLaunchKernelGGL(k_adam_step_many, dim3(bx, k), dim3(256), 0, (hipStream_t)stream, t, 1.0f - beta1, beta2, 1.0f - beta2,
+                           (float)sqrt(bc2), eps, (float)(-(double)lr / bc1), sanitize_grad);
+        UCN_LAUNCH_CHECK("adam_step_many");
+    }
+    return 0;
+}
 
 extern "C" int ucn_hash_decay(const float *embeddings, const int32_t *offsets_host, uint32_t L, uint32_t C, const float *g_dev,
                               float *out, float *workspace, ucn_stream_t stream) {

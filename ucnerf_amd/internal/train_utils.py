@@ -230,21 +230,25 @@ def transformIdentityLoss(renderings):
 
 # ------------------------------------------------------------------ optimiser (train_utils.py:335-366)
 class FusedAdam(torch.optim.Adam):
-    """torch.optim.Adam -- what `create_optimizer` builds (train_utils.py:347-366) -- whose large fp32 device tensors
-    (the hash tables: 7.1 M x 2 and 1.9 M x 2 parameters in config B) are stepped by ONE pass of `ucn_adam_step`
-    instead of ~12 elementwise passes, with the `grad.nan_to_num_()` of `clip_gradients` folded in.  State keys and
-    layout are torch's (`step`, `exp_avg`, `exp_avg_sq`), so state_dicts interchange with torch.optim.Adam.  Every other
-    parameter (and any group using amsgrad / weight_decay / maximize) goes through the parent class unchanged."""
-    MIN_NUMEL = 1 << 20
+    """torch.optim.Adam -- what `create_optimizer` builds (train_utils.py:347-366) -- whose fp32 device tensors are stepped
+    by this repo's kernels: the hash tables (7.1 M x 2 and 1.9 M x 2 parameters in config B) by ONE pass of
+    `ucn_adam_step` each instead of ~12 elementwise passes, the small dense-layer parameters of a group together by ONE
+    launch of `ucn_adam_step_many` instead of torch's seven foreach launches; the `grad.nan_to_num_()` of `clip_gradients`
+    is folded in.  State keys and layout are torch's (`step`, `exp_avg`, `exp_avg_sq`), so state_dicts interchange with
+    torch.optim.Adam.  Everything else (other dtypes / devices, groups using amsgrad / weight_decay / maximize) goes
+    through the parent class unchanged."""
+    MIN_NUMEL = 1 << 20                                          # from here on a tensor gets its own launch
 
     def _fusable(self, group, p):
-        return (p.grad is not None and p.is_cuda and p.dtype == torch.float32 and p.numel() >= self.MIN_NUMEL
+        return (p.grad is not None and p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32
                 and p.is_contiguous() and p.grad.is_contiguous() and not p.grad.is_sparse and not group.get('amsgrad', False)
                 and group.get('weight_decay', 0) == 0 and not group.get('maximize', False)
-                and not group.get('capturable', False) and not group.get('differentiable', False))
+                and not group.get('capturable', False) and not group.get('differentiable', False)
+                and not group.get('fused', False) and p.numel() < (1 << 31) * (4 if p.numel() >= self.MIN_NUMEL else 1))
 
     @torch.no_grad()
     def step(self, closure=None):
+        import ctypes
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -261,6 +265,7 @@ class FusedAdam(torch.optim.Adam):
         finally:
             for _, p, g in held:
                 p.grad = g
+        batches = {}                                             # (group, step count) -> small tensors stepped together
         for group, p, g in held:
             state = self.state[p]
             if len(state) == 0:                                  # torch/optim/adam.py _init_group
@@ -268,11 +273,22 @@ class FusedAdam(torch.optim.Adam):
                 state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             state['step'] += 1
-            lr = group['lr']
+            step = int(state['step'].item())
             beta1, beta2 = group['betas']
-            _lib.check(lib.ucn_adam_step(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
-                                         p.numel(), float(lr), float(beta1), float(beta2), float(group['eps']),
-                                         int(state['step'].item()), 1, _lib.stream()))
+            if p.numel() >= self.MIN_NUMEL and all(t.data_ptr() % 16 == 0 for t in (p, g, state['exp_avg'], state['exp_avg_sq'])):
+                _lib.check(lib.ucn_adam_step(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                                             p.numel(), float(group['lr']), float(beta1), float(beta2), float(group['eps']),
+                                             step, 1, _lib.stream()))
+            else:
+                batches.setdefault((id(group), step), (group, []))[1].append((p, g, state))
+        for (_, step), (group, items) in batches.items():
+            n = len(items)
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            beta1, beta2 = group['betas']
+            _lib.check(lib.ucn_adam_step_many(arr([p for p, _, _ in items]), arr([g for _, g, _ in items]),
+                                              arr([s['exp_avg'] for _, _, s in items]), arr([s['exp_avg_sq'] for _, _, s in items]),
+                                              (ctypes.c_uint64 * n)(*[p.numel() for p, _, _ in items]), n, float(group['lr']),
+                                              float(beta1), float(beta2), float(group['eps']), step, 1, _lib.stream()))
         return loss
 
 
