@@ -308,10 +308,12 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
             times.append((time.perf_counter() - t0) * 1e3)
     model.eval()
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
-                autocast="bf16 GEMMs, fp32 tables/compositing",
+                autocast="bf16 dense layers; forward gather from a half copy of the tables (the reference's autocast policy, "
+                         "gridencoder/grid.py:41-44) with fp32 interpolation; fp32 table gradients, compositing and losses",
                 graph="HIP resample, fused featurisation fwd / bwd (LDS row blocks, no global atomics), NeRF-field dense forward and "
-                      "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd), compositing fwd / bwd, distortion + interlevel "
-                      "losses, table Adam; weight gradients and PropMLP as library GEMMs")
+                      "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd, two workgroups per CU), proposal field as VALU "
+                      "kernels, compositing fwd / bwd, distortion + interlevel + hash-decay losses, Adam (tables and small "
+                      "parameters); one library GEMM per layer for weight + bias gradients")
 
 
 def main():
