@@ -335,6 +335,10 @@ def main():
     ap.add_argument("--ray-tile", type=int, default=8,
                     help="config.render_ray_tile: render_image marches the frame in tile-major order (T x T pixel blocks per "
                          "wave; 1 = the frame's row-major order)")
+    ap.add_argument("--autocast", action="store_true",
+                    help="render under torch.autocast(bf16) like the reference's render_image under `accelerate --mixed_precision "
+                         "bf16` (models.py:957): half tables in the gather, dense layers as bf16 MFMAs, fp32 compositing -- the "
+                         "'mixed bf16/fp32' of BASELINE configs[4]; NOT the fp32 headline")
     ap.add_argument("--sky-skip", type=float, default=0.0,
                     help="Model.sky_min_background (with --cfg5): sky layer only for rays whose background weight reaches this "
                          "value.  Default off: the reference returns sky_rgbs for every ray, and on the random-init field "
@@ -397,7 +401,8 @@ def main():
     eval_camidx = torch.tensor([7]) if args.cfg5 else 0
 
     def step():
-        return models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=eval_camidx)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.autocast):
+            return models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=eval_camidx)
 
     def fence():
         if world > 1:
@@ -479,7 +484,7 @@ def main():
         res = {
             "metric": "rays/sec (fwd render), 1280x1920 @ 64+128 samples", "value": n_rays * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 dense layers + f16 tables, f32 compositing (autocast)" if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": workload, "rays_per_step": n_rays, "cameras": args.cameras,
                        "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
                                  else "random-init weights, tables U(-1,1) (BASELINE configs)"),
@@ -488,7 +493,9 @@ def main():
                            "sky_rays_kept": getattr(model, "_sky_kept", None)} if args.cfg5 else {}),
                        "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
                        "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
-                       "mlp_mode": {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]},
+                       "mlp_mode": ("bf16 MFMA, composed colour layers (the training forward kernel without its stores)" if args.autocast else
+                                    {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]),
+                       **({"autocast": "bf16"} if args.autocast else {})},
             "roofline": dominant, "roofline_secondary": other,
             "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / args.steps, "mlp_prop": mlp_ms[0] / args.steps,
                                          "features_nerf": feat_ms[1] / args.steps, "mlp_nerf": mlp_ms[1] / args.steps},

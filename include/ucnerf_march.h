@@ -304,7 +304,8 @@ uint64_t ucn_train_fwd_fragments(void);
  * models.py:620-640).  ray_cols [N,32] bf16 | NULL: per-RAY columns (direction encoding, a constant 1 for the bias)
  * copied into every sample's row at ray_dst (a column-offset pointer into the same buffer).  Rows that start on 128-byte
  * lines matter: act_ld = 864 (1728-byte rows) costs 15 % against 1024.  feat_bf16 | NULL (row stride act_ld when act_ld != 0,
- * i.e. one more column block of the same buffer, else F): bf16 copy of the features (operand of the first layer's weight gradient;
+ * i.e. one more column block of the same buffer, else F).  h0 / x / h1 / h2 / m0 / m1 / m2 all NULL = INFERENCE: nothing but
+ * raw / y (density / rgb with head) is written -- the mixed-precision render path (render_image under autocast): bf16 copy of the features (operand of the first layer's weight gradient;
  * F % 8 == 0).  head: HOST float[4] {density_bias, rgb_premultiplier, rgb_bias, rgb_padding} | NULL.  With head the
  * output activations (models.py:515 softplus, :667-672 sigmoid + padding) are applied in fp32 before the store:
  * raw := density, y := rgb. */
@@ -312,6 +313,8 @@ int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
                   void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16,
                   const float *head, float *raw, float *y, uint32_t *m0 /*[M,2]*/, void *m1 /*[M,2] x 16 B*/, void *m2,
+                  uint32_t feat_level_dim /*0: feat [M,F]; C (inference): feat = ucn_march_features' layout 2, [L][B][C]
+                  with b = s N + ray -- a wave's lanes are then neighbouring rays, outputs stay [ray][sample]*/,
                   ucn_stream_t stream);
 /* The same chain backwards (dgrad): gy [M,3] bf16 (gradient of y), graw [M] bf16|NULL (gradient of raw), packed_t =
  * the TRANSPOSED weights in the same fragment format (Wr^T, W1h^T, [W1x^T | W0x^T], Wd1^T, Wd0^T), m0/m1/m2 = the ReLU
@@ -331,7 +334,10 @@ int ucn_train_bwd(const void *gy, const void *graw, const float *head, const flo
  * bwd: density = the forward's output, g_density its gradient; gfeat [M,F] | NULL; gW0 / gb0 / gw1 / gb1 fp32, summed in a
  * fixed order (deterministic); workspace of ucn_prop_train_bwd_ws_floats(F, M) floats. */
 int ucn_prop_train_fwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,
-                       const float *b1, float density_bias, int round_bf16, uint64_t M, float *density, ucn_stream_t stream);
+                       const float *b1, float density_bias, int round_bf16, uint64_t M, float *density,
+                       uint32_t n_rays, uint32_t feat_level_dim /*0: feat [M,F], density [M]; C (inference): feat =
+                       ucn_march_features' layout 2 ([L][B][C], b = s n_rays + ray), density [ray][sample]*/,
+                       ucn_stream_t stream);
 uint64_t ucn_prop_train_bwd_ws_floats(uint32_t F, uint64_t M);
 int ucn_prop_train_bwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,
                        const float *b1, float density_bias, int round_bf16, uint64_t M, const float *density,

@@ -871,3 +871,40 @@ def test_sky_is_skipped_for_rays_without_background_weight():
     everything = march(1e-30)                                  # threshold below every background weight: nothing skipped
     assert torch.equal(everything["rgb"], full["rgb"])
     model.sky_min_background = 0.0
+
+
+# ------------------------------------------------------------------ mixed precision: render_image under autocast
+def test_render_under_autocast_runs_the_mixed_precision_path():
+    """The reference wraps the model call of render_image in accelerator.autocast() (models.py:957): with mixed precision
+    on, its grid op gathers half tables (grid.py:41-44) and its Linear layers run in bf16.  Here the same context switches
+    the inference march to the half-table gather + the bf16 MFMA kernels of the training forward (no stores), fp32
+    compositing.  Checked: the path is taken for both levels, the frame agrees with the fp32-class frame to bf16 accuracy
+    (stated: 8 mantissa bits through three 256-wide layers -> a few 1e-3 per pixel, 3e-2 worst case), geometry outputs
+    that do not depend on the colour layers stay close, and the knob switches it off bit-exactly."""
+    from ucnerf_amd.internal import models
+    import bench
+    model, cfg, _ = bench.build_model(torch.device("cuda", 0))           # config B: the 256-wide field the bf16 kernels cover
+    n = 4096
+    rays = H.to_dev(rm.synthetic_rays(n, seed=5))
+    rays["rand_vec"] = torch.randn(n, 6, generator=torch.Generator().manual_seed(6)).cuda()
+
+    def march(autocast):
+        model._mixed_levels = 0
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            r, _ = model._march(False, rays, 1.0, True, None, want_history=False)
+        torch.cuda.synchronize()
+        return {k: r[-1][k].float().clone() for k in ("rgb", "acc", "depth", "weights")}, model._mixed_levels
+
+    full, used0 = march(False)
+    mixed, used1 = march(True)
+    assert used0 == 0 and used1 == 2
+    assert torch.isfinite(mixed["rgb"]).all()
+    d = (mixed["rgb"] - full["rgb"]).abs()
+    assert float(d.max()) <= 3e-2 and float(d.mean()) <= 3e-3, (float(d.max()), float(d.mean()))
+    assert float((mixed["acc"] - full["acc"]).abs().max()) <= 3e-2
+    model.autocast_render = False
+    off, used2 = march(True)
+    model.autocast_render = True
+    assert used2 == 0
+    for k in full:
+        assert torch.equal(off[k], full[k]), k

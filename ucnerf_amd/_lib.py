@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
@@ -84,13 +84,13 @@ SIGNATURES = {
     "ucn_nan_to_num_many": [c_vp, c_vp, c_u32, c_vp],
     "ucn_adam_step_many": [c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_f32, c_f32, c_f32, c_f32, c_u32, c_i32, c_vp],
     "ucn_hash_decay": [c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
-    "ucn_prop_train_fwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_vp],
+    "ucn_prop_train_fwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_u32, c_u32, c_vp],
     "ucn_prop_train_bwd_ws_floats": [c_u32, c_u64],
     "ucn_prop_train_bwd": [c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                            c_vp, c_vp],
     "ucn_train_fwd_fragments": [],
     "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp,
-                      ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+                      ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp],
     "ucn_train_bwd": [c_vp, c_vp, ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
                       c_vp, c_vp, c_vp, c_vp],
     "ucn_sky_packed_floats": [],

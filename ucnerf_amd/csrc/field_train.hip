@@ -36,6 +36,9 @@ struct TrainFwdArgs {
     uint16_t *fb;             // [M, F] bf16 copy of the features (the density layer's weight-gradient operand) or NULL
     float *raw, *y;           // [M], [M, 3]: raw density and colour logits, or (head) density and rgb
     uint32_t ld_h0, ld_act, ld_fb;
+    int store;                // 0: inference -- no activation / mask stores (h0, x, h1, h2, m0, m1, m2 are NULL)
+    uint32_t n_rays, level_dim;   // level_dim != 0 (inference only): feat is the rendering gather's [L][B][C] with b = s * n_rays + ray
+    //                              (rays fastest) and the wave's 32 lanes are 32 consecutive b; outputs stay [ray][sample]
     int head;                 // 1: raw := softplus(raw + density_bias), y := sigmoid(premult y + rgb_bias) (1 + 2 pad) - pad
     float density_bias, rgb_premult, rgb_bias, rgb_padding;
     uint32_t *m0;             // [M][2] : ReLU masks of h0, bit 16 t + r of wave half h  (2 tiles)
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
     const int j = lane & 31, h = lane >> 5;
     const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
     const bool live = s0 < a.M;
-    const uint32_t sample = live ? s0 : a.M - 1;
-    const uint32_t ray = sample / a.S;
+    const uint32_t bq = live ? s0 : a.M - 1;             // position in the feature buffer
+    const uint32_t ray = a.level_dim ? bq % a.n_rays : bq / a.S;
+    const uint32_t sample = a.level_dim ? ray * a.S + bq / a.n_rays : bq;   // position in the [ray][sample] outputs
     extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
     FRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
     ring_start(ring);
@@ -203,7 +207,18 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint32_t k = 32u * ft + 16u * s + 8u * h + e;
-                v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
+                if (a.level_dim == 2u) {                       // one 8-byte load per level
+                    if (e % 2 == 0) {
+                        const float2 t = k < a.F ? *reinterpret_cast<const float2 *>(a.feat + ((size_t)(k >> 1) * a.M + bq) * 2) : make_float2(0.0f, 0.0f);
+                        v[e] = t.x;
+                        v[e + 1] = t.y;
+                    }
+                } else if (a.level_dim) {
+                    const uint32_t l = k / a.level_dim, c = k - l * a.level_dim;
+                    v[e] = k < a.F ? a.feat[((size_t)l * a.M + bq) * a.level_dim + c] : 0.0f;
+                } else {
+                    v[e] = k < a.F ? a.feat[(size_t)sample * a.F + k] : 0.0f;
+                }
             }
             fin[ft][s] = pack8(v);
             if (a.fb && live && a.F % 8 == 0 && 32u * ft + 16u * s + 8u * h < a.F)
@@ -237,8 +252,8 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             h0[t][0] = to_b(a0[t], 0, true);
             h0[t][1] = to_b(a0[t], 1, true);
         }
-        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h0, a.ld_h0, sample, 0, h, h0[0], h0[1], live);
-        if (live) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
+        if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h0, a.ld_h0, sample, 0, h, h0[0], h0[1], live);
+        if (live && a.store) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     }
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
     bf8 x0[2];                              // tile 0, k-step 0 of x: its first value is the raw density
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             xp[o][1] = to_b(acc[o], 1, false);
         }
         if constexpr (p == 0) x0[0] = xp[0][0];
-        store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);
+        if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);
     });
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
         const uint4 q = __builtin_bit_cast(uint4, x0[0]);
@@ -278,10 +293,10 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
                 hin[2 * p + o][0] = to_b(acc[o], 0, true);
                 hin[2 * p + o][1] = to_b(acc[o], 1, true);
             }
-            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, hin[2 * p], hin[2 * p + 1], live);
+            if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, hin[2 * p], hin[2 * p + 1], live);
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
         });
-        if (live) a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+        if (live && a.store) a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
     // ---- colour layer 1: [h1, x] -> h2, and the rgb layer (3 rows of one padded output tile) on each finished pair
     float y3[3] = {a.bias_rgb[h * 16 + 0], a.bias_rgb[h * 16 + 1], a.bias_rgb[h * 16 + 2]};   // rows 0..2 live in wave half 0
@@ -299,14 +314,14 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
                 hp[o][0] = to_b(acc[o], 0, true);
                 hp[o][1] = to_b(acc[o], 1, true);
             }
-            store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h2, a.ld_act, sample, 2 * p, h, hp[0], hp[1], live);
+            if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h2, a.ld_act, sample, 2 * p, h, hp[0], hp[1], live);
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
             f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
             zero_acc(yo[0]);
             tile_pair<1, 2, G3 + 44 * p + 40>(ring, yo, hp);
             y3[0] += yo[0][0]; y3[1] += yo[0][1]; y3[2] += yo[0][2];
         });
-        if (live) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+        if (live && a.store) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
     if (live && h == 0) {
 #pragma unroll
@@ -478,18 +493,21 @@ extern "C" uint64_t ucn_train_fwd_fragments(void) { return (uint64_t)kFragsPadde
 extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                              const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
                              void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16, const float *head,
-                             float *raw, float *y, uint32_t *m0, void *m1, void *m2, ucn_stream_t stream) {
+                             float *raw, float *y, uint32_t *m0, void *m1, void *m2, uint32_t feat_level_dim, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
-    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && h0 && x && h1 && h2 && raw && y && m0 && m1 && m2,
-                "train_fwd: null pointer argument");
+    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && raw && y, "train_fwd: null pointer argument");
+    const bool store = h0 || x || h1 || h2 || m0 || m1 || m2;
+    UCN_REQUIRE(!store || (h0 && x && h1 && h2 && m0 && m1 && m2), "train_fwd: the activation / mask outputs come together (all, or none = inference)");
+    UCN_REQUIRE(feat_level_dim == 0 || (!store && !feat_bf16 && !ray_cols && F % feat_level_dim == 0),
+                "train_fwd: level-major rays-fastest features are an inference layout (no stores), F a multiple of the level dim");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
     UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 8 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 8)", act_ld);
     UCN_REQUIRE(!ray_cols || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
     UCN_REQUIRE(!feat_bf16 || F % 8 == 0, "train_fwd: the bf16 feature copy needs F %% 8 == 0, got %u", F);
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
-                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, head != nullptr,
+                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, store ? 1 : 0, N, feat_level_dim, head != nullptr,
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
     if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);

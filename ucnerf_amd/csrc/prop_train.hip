@@ -42,6 +42,8 @@ struct PropArgs {
     float *gfeat;             // [M, F]
     float *partial;           // [n_wg][64 * (FP + 2) + 1]
     uint32_t slab;            // samples per workgroup of k_prop_bwd_weight
+    uint32_t n_rays, level_dim;   // level_dim != 0 (forward / inference only): feat is the rendering gather's [L][B][C] with
+    //                              b = s * n_rays + ray; thread m = b, the density goes to [ray][sample]
 };
 
 // weights into LDS, rounded like the GEMM operands: W0 padded to FP columns
@@ -62,7 +64,11 @@ __device__ __forceinline__ void stage_weights(const PropArgs &a, float *s_w0, fl
 template <int FP>
 __device__ __forceinline__ void load_features(const PropArgs &a, uint32_t m, float (&f)[FP]) {
 #pragma unroll
-    for (int c = 0; c < FP; c++) f[c] = (uint32_t)c < a.F ? bf16r(a.feat[(size_t)m * a.F + c], a.round_bf16) : 0.0f;
+    for (int c = 0; c < FP; c++) {
+        size_t at = (size_t)m * a.F + c;
+        if (a.level_dim) at = ((size_t)((uint32_t)c / a.level_dim) * a.M + m) * a.level_dim + (uint32_t)c % a.level_dim;
+        f[c] = (uint32_t)c < a.F ? bf16r(a.feat[at], a.round_bf16) : 0.0f;
+    }
 }
 
 template <int FP>
@@ -93,7 +99,9 @@ __global__ __launch_bounds__(256) void k_prop_fwd(PropArgs a) {
         raw = fmaf(s_w1[k], h, raw);
     }
     const float z = bf16r(raw + b1, a.round_bf16) + a.density_bias;
-    a.density[m] = z > 20.0f ? z : log1pf(__expf(z));                                 // F.softplus, beta 1, threshold 20
+    const uint32_t spr = a.M / (a.n_rays ? a.n_rays : 1u);
+    const uint32_t o = a.level_dim ? (m % a.n_rays) * spr + m / a.n_rays : m;
+    a.density[o] = z > 20.0f ? z : log1pf(__expf(z));                                 // F.softplus, beta 1, threshold 20
 }
 
 // d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z))
@@ -249,11 +257,13 @@ int check_shapes(uint32_t F, uint32_t hidden, uint64_t M) {
 
 extern "C" int ucn_prop_train_fwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,
                                   const float *b1, float density_bias, int round_bf16, uint64_t M, float *density,
-                                  ucn_stream_t stream) {
+                                  uint32_t n_rays, uint32_t feat_level_dim, ucn_stream_t stream) {
     if (int rc = check_shapes(F, hidden, M)) return rc;
     if (M == 0) return 0;
     UCN_REQUIRE(feat && W0 && b0 && w1 && b1 && density, "prop_train_fwd: null pointer argument");
-    PropArgs a{feat, W0, b0, w1, b1, density_bias, round_bf16, (uint32_t)M, F, density, nullptr, nullptr, nullptr, 0};
+    UCN_REQUIRE(feat_level_dim == 0 || (n_rays && M % n_rays == 0 && F % feat_level_dim == 0),
+                "prop_train_fwd: level-major rays-fastest features need n_rays | M and level_dim | F");
+    PropArgs a{feat, W0, b0, w1, b1, density_bias, round_bf16, (uint32_t)M, F, density, nullptr, nullptr, nullptr, 0, n_rays, feat_level_dim};
     const uint32_t fp = (F + 3u) & ~3u;
     UCN_PROP_DISPATCH(fp, hipLaunchKernelGGL(k_prop_fwd<FPC>, dim3(ucn_div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, a));
     UCN_LAUNCH_CHECK("prop_train_fwd");
@@ -279,7 +289,7 @@ extern "C" int ucn_prop_train_bwd(const float *feat, uint32_t F, uint32_t hidden
         return 0;
     }
     UCN_REQUIRE(feat && W0 && b0 && w1 && b1 && density && g_density && workspace, "prop_train_bwd: null pointer argument");
-    PropArgs a{feat, W0, b0, w1, b1, density_bias, round_bf16, (uint32_t)M, F, const_cast<float *>(density), g_density, gfeat, workspace, kSlab};
+    PropArgs a{feat, W0, b0, w1, b1, density_bias, round_bf16, (uint32_t)M, F, const_cast<float *>(density), g_density, gfeat, workspace, kSlab, 0, 0};
     const uint32_t fp = (F + 3u) & ~3u, n_wg = (uint32_t)ucn_div_up(M, kSlab);
     if (gfeat) {
         UCN_PROP_DISPATCH(fp, hipLaunchKernelGGL(k_prop_bwd_feat<FPC>, dim3(ucn_div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, a));

@@ -350,6 +350,10 @@ class Model(nn.Module):
 
     autocast_half_tables: bool = True     # training under autocast gathers a HALF copy of the tables, like the reference's
     #                                      _grid_encode (grid.py:41-44); False keeps the fp32 tables (more exact, 2x the bytes)
+    autocast_render: bool = True          # inference marches called under bf16 autocast (the reference's render_image wraps the
+    #                                      model call in accelerator.autocast(), models.py:957) run in the reference's mixed
+    #                                      precision: half tables in the gather, dense layers as bf16 MFMAs (the training
+    #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
     sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background
     #                                      weight 1 - sum(weights of the last level) reaches this value; the others get
     #                                      sky_rgbs = 0 (their pixel moves by < sky_min_background * |A_sky| through
@@ -388,6 +392,41 @@ class Model(nn.Module):
             from . import train_graph
             return train_graph.march_train(self, rand, batch, train_frac, compute_extras, eval_camidx)
         return self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
+
+    def _mixed_level(self, mlp, is_prop, F_in):
+        """Mixed-precision inference of one level (see `autocast_render`): None = the fp32-class path, else what the bf16
+        kernels need -- the half table behind a copy of the grid descriptor and the packed / rounded dense parameters."""
+        if not (self.autocast_render and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+            return None
+        from . import train_graph as tg
+        emb = mlp.encoder.embeddings
+        probe = torch.empty(1, F_in, device=emb.device)
+        if is_prop:
+            if not tg._fusable_prop(mlp, probe):
+                return None
+        elif not tg._fusable_heads(mlp, probe):
+            return None
+        out = {}
+        half = mlp.encoder.level_dim % 2 == 0                      # grid.py:41-44: half tables when C is even
+        d16 = _lib.UcnField()
+        ctypes.memmove(ctypes.byref(d16), ctypes.byref(mlp.grid_field()), ctypes.sizeof(_lib.UcnField))
+        if half:
+            out['table'] = emb.detach().to(torch.half)
+            d16.embeddings = out['table'].data_ptr()
+        out['desc'], out['table_flag'] = d16, (_lib.TABLE_F16 if half else 0)
+        with torch.autocast('cuda', enabled=False):
+            if is_prop:
+                l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
+                out['prop'] = tuple(t.detach().float().contiguous() for t in (l0.weight, l0.bias, l1.weight, l1.bias))
+            else:
+                d0, d1, c0, c1, lr = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1, mlp.rgb_layer
+                packed, _, We, be, bias0, bias1, biasr = tg.prepare_heads(d0.weight, d0.bias, d1.weight, d1.bias, c0.weight, c0.bias,
+                                                                         c1.weight, c1.bias, lr.weight, lr.bias)
+                out.update(packed=packed, We=We, be=be, bias0=bias0, bias1=bias1, biasr=biasr, NW=c0.weight.shape[0],
+                           head=(ctypes.c_float * 4)(float(mlp.density_bias), float(mlp.rgb_premultiplier), float(mlp.rgb_bias),
+                                                     float(mlp.rgb_padding)),
+                           enc=lambda v: tg.view_encoding(v.float(), mlp.deg_view).to(torch.bfloat16))
+        return out
 
     def _march(self, rand, batch, train_frac, compute_extras, eval_camidx, want_history):
         lib = _lib.load()
@@ -464,6 +503,10 @@ class Model(nn.Module):
             basis = torch.empty(N, 6, device=dev)
             nc = min(chunk, N)
             feat = torch.empty(L * nc * S * C, device=dev)
+            mixed = self._mixed_level(mlp, is_prop, L * C)
+            self._mixed_levels = getattr(self, '_mixed_levels', 0) + (mixed is not None)      # diagnostics / tests
+            if mixed is not None and not is_prop:
+                vd_enc = mixed['enc'](vd)
             _lib.check(lib.ucn_resample(_lib.ptr(sdist_prev), _lib.ptr(weights_prev), n_prev, dilation, anneal,
                                         float(self.resample_padding), u_tab.data_ptr(), _lib.ptr(jitter),
                                         0 if jitter is None else jitter.shape[1], max_jitter, N, S,
@@ -495,10 +538,11 @@ class Model(nn.Module):
                 if prof is not None:
                     e0.record(fstream)
                 _lib.check(lib.ucn_march_features(
-                    ctypes.byref(desc), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
+                    ctypes.byref(desc if mixed is None else mixed['desc']), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
-                    float(self.std_scale), n, S, int(self.levels_per_block), (2 if self.rays_fastest else 0) | co,
+                    float(self.std_scale), n, S, int(self.levels_per_block),
+                    ((2 if self.rays_fastest else 0) | co) if mixed is None else (2 | mixed['table_flag']),
                     fb.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, fstream.cuda_stream))
                 if prof is not None:
                     e1.record(fstream)
@@ -508,8 +552,22 @@ class Model(nn.Module):
                     cur.wait_event(ready)
                 if prof is not None:
                     m0.record(cur)
-                compact = (not is_prop) and (not want_history) and self.compact_min_weight > 0 and mlp.mlp_mode == 1
-                if compact:
+                compact = (not is_prop) and (not want_history) and self.compact_min_weight > 0 and mlp.mlp_mode == 1 and mixed is None
+                if mixed is not None and is_prop:
+                    w0, b0_, w1, b1_ = mixed['prop']
+                    _lib.check(lib.ucn_prop_train_fwd(fb.data_ptr(), L * C, w0.shape[0], w0.data_ptr(), b0_.data_ptr(), w1.data_ptr(),
+                                                      b1_.data_ptr(), float(mlp.density_bias), 1, n * S, density[sl].data_ptr(), n, C, st))
+                elif mixed is not None:
+                    NW = mixed['NW']
+                    with torch.autocast('cuda', enabled=False):    # per-ray direction terms of this pass, accumulator order
+                        eb = vd_enc[sl]
+                        pr0 = torch.addmm(mixed['be'][:NW], eb, mixed['We'][:NW].t()).float()
+                        pr1 = torch.addmm(mixed['be'][NW:], eb, mixed['We'][NW:].t()).float()
+                    _lib.check(lib.ucn_train_fwd(fb.data_ptr(), L * C, mixed['packed'].data_ptr(), mixed['bias0'].data_ptr(),
+                                                 mixed['bias1'].data_ptr(), mixed['biasr'].data_ptr(), pr0.data_ptr(), pr1.data_ptr(), n, S,
+                                                 None, None, None, None, 0, None, None, None, mixed['head'], density[sl].data_ptr(),
+                                                 rgbs[sl].data_ptr(), None, None, None, C, st))
+                elif compact:
                     # density head -> weights of this pass's rays -> alive list -> colour layers of the alive samples
                     rf = int(bool(self.rays_fastest))
                     _lib.check(lib.ucn_field_mlp(ctypes.byref(desc), fb.data_ptr(), n * S, S, rf, None, density[sl].data_ptr(),

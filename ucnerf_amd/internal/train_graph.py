@@ -410,6 +410,34 @@ def _wgrad_cols(gy, act, lo, hi):
     return (gy.t() @ act[:, lo:hi]).float()
 
 
+def prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br):
+    """Everything ucn_train_fwd / ucn_train_bwd need from the NeRF field's dense parameters, as ONE cat + ONE cast + ONE gather:
+    (forward fragment stream, dgrad fragment stream, direction blocks [2 NW, E] and their biases [2 NW] in accumulator
+    order (bf16), bd0 / bd1 / br in accumulator order (fp32)).  The colour layers enter the forward stream composed with
+    the activation-free bottleneck (models.py:508): (W0x Wd1), [W1h | W1x Wd1], W bd1 folded into the biases."""
+    lib = _lib.load()
+    dev, dt = Wd0.device, torch.bfloat16
+    NB, NW, F_in = Wd1.shape[0], W0.shape[0], Wd0.shape[1]
+    E = W0.shape[1] - NB
+    T = lib.ucn_train_fwd_fragments()
+    idx, n_src = _head_gather_index(F_in, NB, NW, E, T, dev)
+    zero = _FRAG_CACHE.get(("zero1", str(dev)))
+    if zero is None:
+        zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
+    W0x32, W1x32, Wd132, bd132 = W0.detach()[:, :NB].float(), W1.detach()[:, NW:NW + NB].float(), Wd1.detach().float(), bd1.detach().float()
+    Wc0, Wc1 = W0x32 @ Wd132, W1x32 @ Wd132
+    b0c, b1c = torch.addmv(b0.detach().float(), W0x32, bd132), torch.addmv(b1.detach().float(), W1x32, bd132)
+    src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0c, b1c, br, Wc0, Wc1)] + [zero]).to(dt)
+    assert src.numel() == n_src
+    got = src[idx]
+    packed, packed_t = got[:T * 512], got[T * 512:2 * T * 512]
+    o = 2 * T * 512
+    We = got[o:o + 2 * NW * E].view(2 * NW, E)
+    be = got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]
+    bv = got[o + 2 * NW * E + 2 * NW:].float()
+    return packed, packed_t, We, be, bv[:64], bv[64:64 + NB], bv[64 + NB:]
+
+
 class _FusedHeads(torch.autograd.Function):
     """Density MLP + colour MLP + rgb layer + output activations of the NeRF field (models.py:507-674, the reference's
     topology and widths) under bf16 autocast: the forward is ONE HIP kernel (`ucn_train_fwd`: activations stay in
@@ -427,24 +455,7 @@ class _FusedHeads(torch.autograd.Function):
         E = W0.shape[1] - NB
         T = lib.ucn_train_fwd_fragments()
         with torch.autocast("cuda", enabled=False):
-            idx, n_src = _head_gather_index(F_in, NB, NW, E, T, dev)
-            zero = _FRAG_CACHE.get(("zero1", str(dev)))
-            if zero is None:
-                zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
-            # the bottleneck has no activation (models.py:508): the forward kernel takes the colour layers composed with it,
-            # (W0x Wd1) h0 and (W1x Wd1) h0, like the rendering kernel; x is still computed and stored for the backward
-            W0x32, W1x32, Wd132, bd132 = W0.detach()[:, :NB].float(), W1.detach()[:, NW:NW + NB].float(), Wd1.detach().float(), bd1.detach().float()
-            Wc0, Wc1 = W0x32 @ Wd132, W1x32 @ Wd132
-            b0c, b1c = torch.addmv(b0.detach().float(), W0x32, bd132), torch.addmv(b1.detach().float(), W1x32, bd132)
-            src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0c, b1c, br, Wc0, Wc1)] + [zero]).to(dt)
-            assert src.numel() == n_src
-            got = src[idx]
-            packed, packed_t = got[:T * 512], got[T * 512:2 * T * 512]
-            o = 2 * T * 512
-            We = got[o:o + 2 * NW * E].view(2 * NW, E)
-            be = got[o + 2 * NW * E:o + 2 * NW * E + 2 * NW]
-            bv = got[o + 2 * NW * E + 2 * NW:].float()
-            bias0, bias1, biasr = bv[:64], bv[64:64 + NB], bv[64 + NB:]
+            packed, packed_t, We, be, bias0, bias1, biasr = prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br)
             eb = enc.to(dt)
             pr0 = torch.addmm(be[:NW], eb, We[:NW].t()).float()          # what the bf16 GEMM + bias would hold, acc order
             pr1 = torch.addmm(be[NW:], eb, We[NW:].t()).float()
@@ -464,7 +475,7 @@ class _FusedHeads(torch.autograd.Function):
                                          biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, base + 2 * _ACT_X,
                                          base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX,
                                          base + 2 * _ACT_FB if fb_in_act else None, hd, density.data_ptr(),
-                                         rgb.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), _lib.stream()))
+                                         rgb.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), 0, _lib.stream()))
             if not fb_in_act:
                 act[:, _ACT_FB:_ACT_FB + F_in] = f
         ctx.save_for_backward(act, m0, m1, m2, packed_t, density, rgb)
@@ -518,7 +529,7 @@ class _PropHeads(torch.autograd.Function):
         M, F_in = feat.shape
         density = torch.empty(M, device=feat.device)
         _lib.check(lib.ucn_prop_train_fwd(feat.data_ptr(), F_in, W0.shape[0], W0.data_ptr(), b0.data_ptr(), W1.data_ptr(), b1.data_ptr(),
-                                          float(density_bias), int(bf16), M, density.data_ptr(), _lib.stream()))
+                                          float(density_bias), int(bf16), M, density.data_ptr(), 0, 0, _lib.stream()))
         ctx.save_for_backward(feat, W0, b0, W1, b1, density)
         ctx.consts = (float(density_bias), int(bf16))
         return density
