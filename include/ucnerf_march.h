@@ -305,7 +305,10 @@ uint64_t ucn_train_fwd_fragments(void);
  * copied into every sample's row at ray_dst (a column-offset pointer into the same buffer).  Rows that start on 128-byte
  * lines matter: act_ld = 864 (1728-byte rows) costs 15 % against 1024.  feat_bf16 | NULL (row stride act_ld when act_ld != 0,
  * i.e. one more column block of the same buffer, else F).  h0 / x / h1 / h2 / m0 / m1 / m2 all NULL = INFERENCE: nothing but
- * raw / y (density / rgb with head) is written -- the mixed-precision render path (render_image under autocast): bf16 copy of the features (operand of the first layer's weight gradient;
+ * raw / y (density / rgb with head) is written -- the mixed-precision render path (render_image under autocast).  There
+ * pr0 = pr1 = NULL selects the stream form with the direction tile inside: ray_cols [N,32] bf16 = [dir_enc (27), 1, 0...]
+ * is one more input tile of the two colour layers (its column 27 carries the bias), packed by
+ * train_graph.py::_head_gather_index(dir_in_stream=True): bf16 copy of the features (operand of the first layer's weight gradient;
  * F % 8 == 0).  head: HOST float[4] {density_bias, rgb_premultiplier, rgb_bias, rgb_padding} | NULL.  With head the
  * output activations (models.py:515 softplus, :667-672 sigmoid + padding) are applied in fp32 before the store:
  * raw := density, y := rgb. */

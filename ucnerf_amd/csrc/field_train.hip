@@ -150,8 +150,8 @@ constexpr int kTChunk = 16, kTSlots = 4, kTLead = 2;
 constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
 using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;                            // the backward's stream
 // the forward's stream (composed colour layers, see k_train_fwd): 2 NTF 2 + 32 + 32 + 4 (40 + 4) = 244 / 248 fragments
-constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 32 + 4 * 44;
-constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 256
+constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 4 * 12 + 4 * 48;     // with the direction tile in the stream (inference): 276 / 280
+constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 288
 using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
 
 template <int... Is, class F>
@@ -183,7 +183,10 @@ __device__ __forceinline__ void ring_start(RING &ring) {
 #ifndef UCN_TRAIN_FWD_WGS
 #define UCN_TRAIN_FWD_WGS 2
 #endif
-template <int NTF>   // feature tiles: F <= 32 * NTF
+// AUX (inference with rays-fastest lanes): the per-ray direction term is NOT pre-multiplied by the caller (pr0 / pr1 would
+// be 2 KiB per LANE there, 64 KiB of loads per wave); the ray's 32-column tile [dir_enc (27), 1, 0...] (a.ray_cols) enters
+// the two colour layers as one more input tile whose column 27 carries the layer bias, like in the rendering kernel.
+template <int NTF, bool AUX = false>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             if (a.fb && live && a.F % 8 == 0 && 32u * ft + 16u * s + 8u * h < a.F)
                 *reinterpret_cast<uint4 *>(a.fb + (size_t)sample * a.ld_fb + 32u * ft + 16u * s + 8u * h) = __builtin_bit_cast(uint4, fin[ft][s]);
         }
-    if (a.ray_cols && live) {               // lane (j, h): columns 16 h .. 16 h + 15 of its sample's row
+    if (!AUX && a.ray_cols && live) {       // lane (j, h): columns 16 h .. 16 h + 15 of its sample's row
         const uint4 *src = reinterpret_cast<const uint4 *>(a.ray_cols + (size_t)ray * 32 + 16 * h);
         uint4 *dst = reinterpret_cast<uint4 *>(a.ray_dst + (size_t)sample * a.ld_act + 16 * h);
         dst[0] = src[0];
@@ -238,10 +241,19 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
     // the 64 registers that held x as an operand are free, which is what lets two workgroups share a CU without spills.
     // stream positions: L0 | L1: 4 pairs x 8 | L2': 4 pairs x 8 | 4 x (L3' pair: [h1 (8 tiles) | h0 (2 tiles)] = 40, then the
     // rgb layer's fragments for the two h2 tiles just finished: 4)
-    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 32;
+    constexpr int NA = AUX ? 1 : 0;                        // extra input tiles of the colour layers
+    constexpr int P2 = (2 + NA) * 4, P3 = (10 + NA) * 4;   // fragments per output pair of L2' / L3'
+    constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 4 * P2;
     // ---- density layer 0
-    bf8 hin[10][2];                        // tiles 0..7: h1 (filled below), 8..9: h0  -- the order of [W1h | W1x W_d1]
+    bf8 hin[10 + NA][2];                   // tiles 0..7: h1 (filled below), 8..9: h0, (10: the ray's direction tile)
     bf8 (&h0)[2][2] = reinterpret_cast<bf8(&)[2][2]>(hin[8]);
+    if constexpr (AUX) {
+        // accumulator-order operand of a 32-wide natural row: k-step s = pieces {0-3, 8-11} / {16-19, 24-27} + 4 h
+        const uint2 *src = reinterpret_cast<const uint2 *>(a.ray_cols + (size_t)ray * 32 + 4 * h);
+        const uint2 p0 = src[0], p1 = src[2], p2 = src[4], p3 = src[6];
+        hin[10][0] = __builtin_bit_cast(bf8, make_uint4(p0.x, p0.y, p1.x, p1.y));
+        hin[10][1] = __builtin_bit_cast(bf8, make_uint4(p2.x, p2.y, p3.x, p3.y));
+    }
     {
         f32x16 a0[2];
         load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
@@ -285,9 +297,14 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
         sfor<4>([&](auto pp) {
             constexpr int p = pp.value;
             f32x16 acc[2];
-            load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
-            load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
-            tile_pair<2, 2, G2 + 8 * p>(ring, acc, h0);
+            if constexpr (AUX) {
+                zero_acc(acc[0]);
+                zero_acc(acc[1]);
+            } else {
+                load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+                load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+            }
+            tile_pair<2, 2 + NA, G2 + P2 * p>(ring, acc, reinterpret_cast<const bf8(&)[2 + NA][2]>(hin[8]));
 #pragma unroll
             for (int o = 0; o < 2; o++) {
                 hin[2 * p + o][0] = to_b(acc[o], 0, true);
@@ -305,9 +322,14 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
         sfor<4>([&](auto pp) {
             constexpr int p = pp.value;
             f32x16 acc[2];
-            load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
-            load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
-            tile_pair<2, 10, G3 + 44 * p>(ring, acc, hin);
+            if constexpr (AUX) {
+                zero_acc(acc[0]);
+                zero_acc(acc[1]);
+            } else {
+                load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+                load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+            }
+            tile_pair<2, 10 + NA, G3 + (P3 + 4) * p>(ring, acc, hin);
             bf8 hp[2][2];
 #pragma unroll
             for (int o = 0; o < 2; o++) {
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdAr
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
             f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
             zero_acc(yo[0]);
-            tile_pair<1, 2, G3 + 44 * p + 40>(ring, yo, hp);
+            tile_pair<1, 2, G3 + (P3 + 4) * p + P3>(ring, yo, hp);
             y3[0] += yo[0][0]; y3[1] += yo[0][1]; y3[2] += yo[0][2];
         });
         if (live && a.store) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -496,22 +518,32 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
                              float *raw, float *y, uint32_t *m0, void *m1, void *m2, uint32_t feat_level_dim, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
-    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && pr0 && pr1 && raw && y, "train_fwd: null pointer argument");
+    UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && raw && y, "train_fwd: null pointer argument");
+    const bool aux = !pr0 && !pr1;           // direction tile in the stream instead of pre-multiplied per-ray terms
+    UCN_REQUIRE(aux || (pr0 && pr1), "train_fwd: pr0 and pr1 come together");
+    UCN_REQUIRE(!aux || (ray_cols && !h0 && !x && !h1 && !h2), "train_fwd: the in-stream direction tile is an inference form: ray_cols, no stores");
     const bool store = h0 || x || h1 || h2 || m0 || m1 || m2;
     UCN_REQUIRE(!store || (h0 && x && h1 && h2 && m0 && m1 && m2), "train_fwd: the activation / mask outputs come together (all, or none = inference)");
-    UCN_REQUIRE(feat_level_dim == 0 || (!store && !feat_bf16 && !ray_cols && F % feat_level_dim == 0),
+    UCN_REQUIRE(feat_level_dim == 0 || (!store && !feat_bf16 && (!ray_cols || aux) && F % feat_level_dim == 0),
                 "train_fwd: level-major rays-fastest features are an inference layout (no stores), F a multiple of the level dim");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
     UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 8 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 8)", act_ld);
-    UCN_REQUIRE(!ray_cols || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
+    UCN_REQUIRE(!ray_cols || aux || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
     UCN_REQUIRE(!feat_bf16 || F % 8 == 0, "train_fwd: the bf16 feature copy needs F %% 8 == 0, got %u", F);
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
                    (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, store ? 1 : 0, N, feat_level_dim, head != nullptr,
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_fwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_fwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    const dim3 grid(ucn_div_up(M, 128));
+    const size_t lds = kTSlots * kTChunk * 1024;
+    if (aux) {
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
 }

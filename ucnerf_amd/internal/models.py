@@ -421,11 +421,11 @@ class Model(nn.Module):
             else:
                 d0, d1, c0, c1, lr = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1, mlp.rgb_layer
                 packed, _, We, be, bias0, bias1, biasr = tg.prepare_heads(d0.weight, d0.bias, d1.weight, d1.bias, c0.weight, c0.bias,
-                                                                         c1.weight, c1.bias, lr.weight, lr.bias)
+                                                                         c1.weight, c1.bias, lr.weight, lr.bias, dir_in_stream=True)
                 out.update(packed=packed, We=We, be=be, bias0=bias0, bias1=bias1, biasr=biasr, NW=c0.weight.shape[0],
                            head=(ctypes.c_float * 4)(float(mlp.density_bias), float(mlp.rgb_premultiplier), float(mlp.rgb_bias),
                                                      float(mlp.rgb_padding)),
-                           enc=lambda v: tg.view_encoding(v.float(), mlp.deg_view).to(torch.bfloat16))
+                           enc=lambda v: _dir_tiles(tg.view_encoding(v.float(), mlp.deg_view)))
         return out
 
     def _march(self, rand, batch, train_frac, compute_extras, eval_camidx, want_history):
@@ -558,15 +558,11 @@ class Model(nn.Module):
                     _lib.check(lib.ucn_prop_train_fwd(fb.data_ptr(), L * C, w0.shape[0], w0.data_ptr(), b0_.data_ptr(), w1.data_ptr(),
                                                       b1_.data_ptr(), float(mlp.density_bias), 1, n * S, density[sl].data_ptr(), n, C, st))
                 elif mixed is not None:
-                    NW = mixed['NW']
-                    with torch.autocast('cuda', enabled=False):    # per-ray direction terms of this pass, accumulator order
-                        eb = vd_enc[sl]
-                        pr0 = torch.addmm(mixed['be'][:NW], eb, mixed['We'][:NW].t()).float()
-                        pr1 = torch.addmm(mixed['be'][NW:], eb, mixed['We'][NW:].t()).float()
+                    # the ray's direction tile rides in the weight stream's last input tile (no per-ray terms to pre-multiply)
                     _lib.check(lib.ucn_train_fwd(fb.data_ptr(), L * C, mixed['packed'].data_ptr(), mixed['bias0'].data_ptr(),
-                                                 mixed['bias1'].data_ptr(), mixed['biasr'].data_ptr(), pr0.data_ptr(), pr1.data_ptr(), n, S,
-                                                 None, None, None, None, 0, None, None, None, mixed['head'], density[sl].data_ptr(),
-                                                 rgbs[sl].data_ptr(), None, None, None, C, st))
+                                                 mixed['bias1'].data_ptr(), mixed['biasr'].data_ptr(), None, None, n, S,
+                                                 None, None, None, None, 0, vd_enc[sl].data_ptr(), None, None, mixed['head'],
+                                                 density[sl].data_ptr(), rgbs[sl].data_ptr(), None, None, None, C, st))
                 elif compact:
                     # density head -> weights of this pass's rays -> alive list -> colour layers of the alive samples
                     rf = int(bool(self.rays_fastest))
@@ -713,6 +709,16 @@ def unwrap_model(model):
     if not hasattr(model, '_march'):
         raise TypeError(f"render_image: expected a ucnerf_amd Model (possibly DDP-wrapped), got {type(model).__name__}")
     return model
+
+
+def _dir_tiles(enc):
+    """[N, E <= 31] direction encodings -> [N, 32] bf16 tiles [enc, 1, 0...]: the input tile whose column E meets the bias column
+    of the colour layers' weight streams (train_graph._head_gather_index(dir_in_stream=True))."""
+    n, e = enc.shape
+    t = torch.zeros(n, 32, device=enc.device, dtype=torch.bfloat16)
+    t[:, :e] = enc
+    t[:, e] = 1.0
+    return t
 
 
 _TILE_ORDER = {}

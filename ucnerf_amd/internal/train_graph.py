@@ -341,13 +341,13 @@ def _weave(parts, producer, consumer):
     return parts[:producer] + [woven] + parts[consumer + 1:]
 
 
-def _head_gather_index(F_in, NB, NW, E, total, device):
+def _head_gather_index(F_in, NB, NW, E, total, device, dir_in_stream=False):
     """ONE gather index over the flat bf16 copy of (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0', b1', br, W0x Wd1, W1x Wd1, 0) -- the
     colour layers composed with the activation-free bottleneck and W bd1 folded into their biases -- that yields, in this
     order: the forward fragment stream, the dgrad (transposed) fragment stream, the direction blocks of W0 / W1 with
     rows in accumulator order [2 NW, E], their biases [2 NW], and bd0 / bd1 / br in accumulator order (64 + NB + 32).
     A logical matrix is a list of column blocks (base, row_stride, col_stride, ncols) of the flat source."""
-    key = ("heads", F_in, NB, NW, E, total, str(device))
+    key = ("heads", F_in, NB, NW, E, total, str(device), dir_in_stream)
     hit = _FRAG_CACHE.get(key)
     if hit is not None:
         return hit
@@ -383,8 +383,12 @@ def _head_gather_index(F_in, NB, NW, E, total, device):
     # forward: the rgb layer's fragments ride behind each pair of the last hidden layer's output tiles; backward: the
     # density layer's behind each pair of bottleneck-gradient tiles (field_train.hip: the consumer layer runs on every
     # finished pair, so that only one pair of accumulators is live and two workgroups fit a CU)
-    fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oWc0, 64, 1, 64)], False),
-                  (NW, [(oW1, k1, 1, NW), (oWc1, 64, 1, 64)], False), (3, [(oWr, NW, 1, NW)], False)], weave=(3, 4))
+    # dir_in_stream (inference with rays-fastest lanes): the direction block, the layer bias (against the constant-1 column of
+    # the ray's tile) and zero padding form one more 32-column input tile of the two colour layers
+    aux0 = [(oW0 + NB, k0, 1, E), (ob0, 1, 0, 1), (zero, 0, 0, 31 - E)] if dir_in_stream else []
+    aux1 = [(oW1 + NW + NB, k1, 1, E), (ob1, 1, 0, 1), (zero, 0, 0, 31 - E)] if dir_in_stream else []
+    fwd = stream([(64, [(oWd0, F_in, 1, F_in)], True), (NB, [(oWd1, 64, 1, 64)], False), (NW, [(oWc0, 64, 1, 64)] + aux0, False),
+                  (NW, [(oW1, k1, 1, NW), (oWc1, 64, 1, 64)] + aux1, False), (3, [(oWr, NW, 1, NW)], False)], weave=(3, 4))
     bwd = stream([(NW, [(oWr, 1, NW, 3)], True), (NW, [(oW1, 1, k1, NW)], False),
                   (NB, [(oW1 + NW, 1, k1, NW), (oW0, 1, k0, NW)], False), (64, [(oWd1, 1, 64, NB)], False),
                   (F_in, [(oWd0, 1, F_in, 64)], False)], weave=(2, 3))
@@ -410,7 +414,7 @@ def _wgrad_cols(gy, act, lo, hi):
     return (gy.t() @ act[:, lo:hi]).float()
 
 
-def prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br):
+def prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, dir_in_stream=False):
     """Everything ucn_train_fwd / ucn_train_bwd need from the NeRF field's dense parameters, as ONE cat + ONE cast + ONE gather:
     (forward fragment stream, dgrad fragment stream, direction blocks [2 NW, E] and their biases [2 NW] in accumulator
     order (bf16), bd0 / bd1 / br in accumulator order (fp32)).  The colour layers enter the forward stream composed with
@@ -420,7 +424,7 @@ def prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br):
     NB, NW, F_in = Wd1.shape[0], W0.shape[0], Wd0.shape[1]
     E = W0.shape[1] - NB
     T = lib.ucn_train_fwd_fragments()
-    idx, n_src = _head_gather_index(F_in, NB, NW, E, T, dev)
+    idx, n_src = _head_gather_index(F_in, NB, NW, E, T, dev, dir_in_stream)
     zero = _FRAG_CACHE.get(("zero1", str(dev)))
     if zero is None:
         zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
