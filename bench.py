@@ -432,16 +432,19 @@ def main():
         lo, hi = udist.shard_bounds(n_rays, world, rank)
         rays_rank = (hi - lo) * args.steps
         assert rays_seen[1] == rays_rank
-        gather = dict(bound="hbm", kernel="k_march_features<2> (NeRF level)",
-                      achieved=rays_seen[1] * GATHER_BYTES_NERF / (feat_ms[1] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+        gather = dict(bound="hbm", kernel="k_march_features<2> (NeRF level)" + (", half tables" if args.autocast else ""),
+                      achieved=rays_seen[1] * (GATHER_BYTES_NERF // 2 if args.autocast else GATHER_BYTES_NERF) / (feat_ms[1] * 1e-3) / 1e9,
+                      peak=PEAK_HBM_GBS, unit="GB/s",
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
+        if args.autocast:
+            gather["bytes_note"] = "half tables: 2-byte entries, half the algorithmic gather bytes of the fp32 path"
         gather["frac"] = gather["achieved"] / gather["peak"]
         # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
         # same command (profiles/r02c/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
         # when this run's launches have the size those passes measured
         try:
             tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02c", "traffic.json")))
-            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5:
+            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and not args.autocast:
                 gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
                 gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
                                           "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
@@ -455,7 +458,7 @@ def main():
         # is what the matrix cores actually ran.
         mlp = dict(bound="mfma", kernel=("k_field_mlp_h8<8,4,...> (two 4-wave workgroups per CU)" if split else "k_field_mlp<8,8>") + " (NeRF level)",
                    achieved=rays_seen[1] * FLOP_NERF_RAY / (mlp_ms[1] * 1e-3) / 1e12,
-                   peak=PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                   peak=PEAK_F16_MFMA_TF if (split or args.autocast) else PEAK_F32_MFMA_TF, unit="TFLOP/s",
                    avg_launch_ms=mlp_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
         mlp["frac"] = mlp["achieved"] / mlp["peak"]
         mlp["issue_model_note"] = ("per wave (32 samples): 696 MFMAs, 1463 VALU, 622 LDS reads, 118 LDS-DMA pieces, 29 barriers "
@@ -465,7 +468,15 @@ def main():
                                    "reaches (0.50-0.56 of the same peak)")
         mlp["peak_note"] = ("dense f16 MFMA peak; fp32-class products = 3 f16 MFMAs each, composed layers = 0.52x MACs" if split
                             else "fp32-input MFMA peak (= fp32 vector rate on CDNA4)")
-        if split:
+        if args.autocast:
+            # mixed-precision render: ucn_train_fwd without stores, the direction tile in the stream: 276 bf16 MFMAs of
+            # 32 x 32 x 16 per 32 samples, one product per MAC
+            mlp["kernel"] = "k_train_fwd<1, AUX> (bf16 MFMA inference: composed colour layers, direction tile in the weight stream) (NeRF level)"
+            mlp["peak_note"] = "dense bf16 MFMA peak"
+            mlp["issue_model_note"] = "276 MFMAs per wave (32 samples), two workgroups per CU"
+            mlp["executed_mfma_tflops"] = rays_seen[1] * S_NERF * (276 * 32768 / 32) / (mlp_ms[1] * 1e-3) / 1e12
+            mlp["executed_frac"] = mlp["executed_mfma_tflops"] / PEAK_F16_MFMA_TF
+        elif split:
             mlp["executed_mfma_tflops"] = 3 * rays_seen[1] * S_NERF * 2 * MAC_NERF_SPLIT / (mlp_ms[1] * 1e-3) / 1e12
             mlp["executed_frac"] = mlp["executed_mfma_tflops"] / PEAK_F16_MFMA_TF
         dominant, other = (gather, mlp) if feat_ms[1] >= mlp_ms[1] else (mlp, gather)
