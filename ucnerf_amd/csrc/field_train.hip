@@ -17,13 +17,10 @@
 // into MFMA A-fragments in consumption order (frag = 64 lanes x 8 bf16 = 1 KiB; k-order permuted to the accumulator
 // layout of the producing layer, exactly like the rendering engine's packers): 436 fragments per tile, staged through
 // LDS in 64 KiB chunks shared by the workgroup's four waves (reading them per wave straight from L2 was 5x slower).
-#include <utility>
-
-#include "mlp_ring.h"
+#include "bf_tiles.h"
 
 namespace {
 
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 struct TrainFwdArgs {
     const float *feat;        // [M, F] fp32, F <= 64 (sample-major, what k_march_features writes for the GEMMs)
@@ -46,22 +43,7 @@ struct TrainFwdArgs {
     uint32_t M, S, F;
 };
 
-__device__ __forceinline__ f32x16 mfma_bf(bf8 a, bf8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-// fp32 -> bf16, round to nearest even: the C cast is v_cvt_pk_bf16_f32 on gfx950 (two values per instruction)
-__device__ __forceinline__ bf8 pack8(const float (&v)[8]) {
-    bf8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
-    return o;
-}
-// 8 accumulator registers (k-step s of a tile) -> the B operand of the next layer
-__device__ __forceinline__ bf8 to_b(const f32x16 &a, int s, bool relu) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = relu ? fmaxf(a[8 * s + e], 0.0f) : a[8 * s + e];
-    return pack8(v);
-}
 // bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile)
 __device__ __forceinline__ uint32_t mask16(const f32x16 &a) {
     uint32_t m = 0;
@@ -129,24 +111,12 @@ __device__ __forceinline__ void store_two(uint16_t *__restrict__ dst, uint32_t w
         store_tile(dst, width, sample, tp + 1, h, t1, live);
     }
 }
-__device__ __forceinline__ void zero_acc(f32x16 &a) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) a[r] = 0.0f;
-}
-__device__ __forceinline__ void load_acc(const float *__restrict__ p, f32x16 &acc) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float4 v = reinterpret_cast<const float4 *>(p)[q];
-        acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
-    }
-}
 
 // Weight staging = the rendering engine's DMA ring (mlp_ring.h): a 64 KiB LDS ring of 4 x 16 KiB chunks filled by
 // global_load_lds two chunks ahead, one piece per four MFMAs, one barrier per chunk -- 64 KiB and <= 256 registers per
 // wave, so that TWO workgroups share a CU: at one wave per SIMD (the first version: two 64 KiB buffers, 456 registers)
 // both kernels spent 75 % of their wave-cycles waiting (profiles/r02c/pmc_table_train.txt).
 constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
-constexpr int kTChunk = 16, kTSlots = 4, kTLead = 2;
 constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
 using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;                            // the backward's stream
 // the forward's stream (composed colour layers, see k_train_fwd): 2 NTF 2 + 32 + 32 + 4 (40 + 4) = 244 / 248 fragments
@@ -154,31 +124,6 @@ constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 4 * 12 + 4 * 48;     // with the d
 constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 288
 using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
 
-template <int... Is, class F>
-__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequence<int, N>{}, f); }
-
-// P output tiles (a PAIR, or one) from NT_IN input tiles: acc[o2] += A(frag) . in[it][s], fragments [it][s][o2] from
-// stream position G0.  The two tiles of a pair alternate (two MFMAs into the same accumulator do not issue back to
-// back); only the pair's 32 accumulator registers are live, the caller converts / stores it before the next pair.
-template <int P, int NT_IN, int G0, class RING>
-__device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
-    sfor<NT_IN * 2 * P>([&](auto i) {
-        constexpr int I = i.value, G = G0 + I;
-        constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
-        if constexpr (G % kTChunk == 0 && G / kTChunk >= 1) ring.template boundary<G / kTChunk>();
-        if constexpr (G % 4 == 0) ring.template piece<G / kTChunk + kTLead, (G % kTChunk) / 4>();
-        acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
-        // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    });
-}
-template <class RING>
-__device__ __forceinline__ void ring_start(RING &ring) {
-    rstatic_for<kTLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
-}
 
 #ifndef UCN_TRAIN_FWD_WGS
 #define UCN_TRAIN_FWD_WGS 2
