@@ -269,10 +269,23 @@ def sky_layer_ms(batch_flat, device, n_rays=65536, steps=3):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    for _ in range(2):
+        net.render(o, d, cam, far, mixed=True)
+    e0.record()
+    for _ in range(steps):
+        net.render(o, d, cam, far, mixed=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_bf = e0.elapsed_time(e1) / steps
     flops = 2.0 * 562688 * 120 * n_rays
+    # executed bf16 MFMAs of the mixed kernel: 984 of 32 x 32 x 16 per 32 samples (the composed views layer saves 64 K MAC)
+    flops_bf = 984 * 32768 / 32 * 120 * n_rays
     return dict(ms=ms, rays=n_rays, rays_per_s=n_rays / ms * 1e3, algorithmic_tflops=flops / ms / 1e9,
                 frac_of_f16_mfma_peak=flops / ms / 1e9 / PEAK_F16_MFMA_TF, ms_per_frame=ms * tot / n_rays,
-                kernel="k_sky_mlp (split-f16 MFMA, composed views layer) + k_sky_composite")
+                kernel="k_sky_mlp (split-f16 MFMA, composed views layer) + k_sky_composite",
+                mixed=dict(ms=ms_bf, rays_per_s=n_rays / ms_bf * 1e3, executed_mfma_tflops=flops_bf / ms_bf / 1e9,
+                           frac_of_bf16_mfma_peak=flops_bf / ms_bf / 1e9 / PEAK_F16_MFMA_TF,
+                           kernel="k_sky_mlp_bf (bf16 MFMA, two workgroups per CU; under autocast) + k_sky_composite"))
 
 
 def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
@@ -484,8 +497,10 @@ def main():
         if args.cfg5:
             workload = (f"BASELINE configs[4]: {args.cameras}-camera 1280x1920 frame ({n_rays:,} rays) of VIRTUAL (perturbed) poses, sky NeRF "
                         "layer + per-camera colour-correction head (210 views) on, proposal 64 + NeRF 128 samples, NeRF grid L=16 C=2 "
-                        "T=2^19; dense layers on f16 MFMA with hi/lo operands and fp32 accumulation (fp32-class: >= the bf16 the config "
-                        "names), grid + compositing fp32")
+                        "T=2^19; " + ("MIXED bf16 / fp32 as the config names it: half tables, bf16 MFMA dense layers (fields and sky), "
+                                      "fp32 resampling / compositing / colour head" if args.autocast else
+                                      "dense layers on f16 MFMA with hi/lo operands and fp32 accumulation (fp32-class: >= the bf16 "
+                                      "the config names), grid + compositing fp32"))
         elif args.cameras > 1:
             workload = (f"BASELINE configs[3]: full {args.cameras}-camera 1280x1920 frame ({n_rays:,} rays), row tiles over the ranks, "
                         "proposal 64 + NeRF 128 samples, NeRF grid L=16 C=2 T=2^19, proposal grid L=6 C=2 T=2^19, fp32 forward render")

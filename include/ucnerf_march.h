@@ -374,11 +374,14 @@ uint64_t ucn_sky_packed_floats(void);
 int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream);
 uint64_t ucn_sky_workspace_floats(uint32_t N);
 /* t_vals: DEVICE [120] = linspace(0,1,120) (models.py:870); far0_times_1p5 = 1.5*far[0] (:329);
- * workspace: DEVICE ucn_sky_workspace_floats(N) floats (per-ray view bias + per-sample raw outputs). */
+ * workspace: DEVICE ucn_sky_workspace_floats(N) floats (per-ray view bias + per-sample raw outputs).
+ * mixed = 0: fp32-class products (split-f16 MFMA, the parity path).  mixed = 1: what the reference's NeRF.forward is
+ * under a bf16 autocast (models.py:957, :786-815): bf16 operands, fp32 accumulation, for the 256-wide layers; layer 0,
+ * the two heads and the compositing stay fp32. */
 int ucn_sky_render(const ucn_sky_t *s, const float *origins, const float *directions,
                    const float *cam_dirs, const float *far_ /*[N]*/, float far0_times_1p5,
                    const float *t_vals, uint32_t N, float *workspace, float *sky_rgb_out /*[N,3]*/,
-                   ucn_stream_t stream);
+                   int mixed, ucn_stream_t stream);
 
 /* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
 int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,

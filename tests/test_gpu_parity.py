@@ -874,6 +874,92 @@ def test_sky_is_skipped_for_rays_without_background_weight():
 
 
 # ------------------------------------------------------------------ mixed precision: render_image under autocast
+def test_sky_layer_mixed_precision_against_its_rounding_model():
+    """ucn_sky_render(mixed = 1): the sky NeRF with bf16 MFMA layers (what the reference's nn.Linear layers are under the
+    bf16 autocast render_image runs its chunks in, models.py:957).  Pinned to a torch restatement of exactly this
+    arithmetic -- bf16-rounded weights and activations at the kernel's rounding points, exact products, fp32 sums;
+    layer 0 and both heads fp32; the composed matrices formed in fp64 -- over a ragged ray count; the residual is the
+    order of the fp32 sums plus the rare activation that rounds the other way (stated bars: mean 2e-4, max 5e-3).
+    And to the fp32-class kernel at bf16 accuracy; through Model._march the switch is the autocast state."""
+    from ucnerf_amd.internal import sky as skymod
+    torch.manual_seed(3)
+    net = skymod.NeRF(D=8, d_in_view=3, W=256, multires_view=4, output_ch=4, skips=[4]).cuda()
+    with torch.no_grad():
+        net.alpha_linear.weight.mul_(6.0)                   # densities that matter over the sample spacing
+        net.alpha_linear.bias.add_(0.05)
+    n = 301                                                  # 36 120 samples: the last workgroup is ragged
+    g = torch.Generator().manual_seed(4)
+    o = (torch.randn(n, 3, generator=g) * 0.3).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda() * 1.3
+    cam = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    far = (2.0 + 3.0 * torch.rand(n, generator=g)).cuda()
+    full = net.render(o, d, cam, far)
+    mixed = net.render(o, d, cam, far, mixed=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(mixed).all()
+
+    def bf(t):
+        return t.to(torch.bfloat16).float()
+
+    with torch.no_grad():
+        S = skymod.N_SKY_SAMPLES
+        tv = torch.linspace(0., 1., steps=S).cuda()
+        inv_far = 1.0 / (float(far[0]) * 1.5)
+        z = far[:, None] * (1 - tv) + inv_far * tv
+        pts = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3)
+        views = cam[:, None, :].expand(-1, S, -1).reshape(-1, 3)
+        venc = torch.cat([views] + [fn(views * f) for f in (1., 2., 4., 8.) for fn in (torch.sin, torch.cos)], -1)
+        L = net.pts_linears
+        h = bf(torch.relu(pts @ L[0].weight.t() + L[0].bias))
+        acc = None
+        for i in range(1, 8):
+            if i == 5:
+                acc = h @ bf(L[5].weight[:, 3:]).t() + bf(pts) @ bf(L[5].weight[:, :3]).t() + bf(L[5].bias)
+            else:
+                acc = h @ bf(L[i].weight).t() + L[i].bias
+            h = bf(torch.relu(acc))
+        sigma = torch.relu(acc) @ net.alpha_linear.weight.t() + net.alpha_linear.bias
+        Wv = net.views_linears[0].weight.double()
+        Mh = bf((Wv[:, :256] @ net.feature_linear.weight.double()).float())
+        bv = bf((net.views_linears[0].bias.double() + Wv[:, :256] @ net.feature_linear.bias.double()).float())
+        v = torch.relu(h @ Mh.t() + bf(venc) @ bf(net.views_linears[0].weight[:, 256:]).t() + bv)
+        rgb = torch.sigmoid(v @ net.rgb_linear.weight.t() + net.rgb_linear.bias).reshape(n, S, 3)
+        sigma = sigma.reshape(n, S)
+        dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * d.norm(dim=-1, keepdim=True)
+        alpha = 1 - torch.exp(-torch.relu(sigma) * dists)
+        trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+        want = ((alpha * trans)[..., None] * rgb).sum(-2)
+    e = (mixed - want).abs()
+    assert float(e.mean()) <= 2e-4 and float(e.max()) <= 5e-3, (float(e.mean()), float(e.max()))
+    e32 = (mixed - full).abs()
+    assert float(e32.max()) <= 3e-2 and float(e32.mean()) <= 5e-3, (float(e32.max()), float(e32.mean()))
+    assert float(e32.max()) > 0.0                            # it IS another arithmetic
+
+    # through the model: the autocast state selects it, the knob switches it off bit-exactly
+    spec = rm.make_spec("tiny", model_sky=True, brightness_correction=True)
+    model, cfg = H.hip_model(spec, rm.init_state(spec, seed=31))
+    with torch.no_grad():
+        model.skynerf.alpha_linear.bias.add_(1.0)             # a sky that is not transparent
+    rays = H.to_dev(rm.synthetic_rays(700, seed=32))
+    rays["rand_vec"] = torch.randn(700, 6, generator=torch.Generator().manual_seed(33)).cuda()
+    camidx = torch.tensor([1]).cuda()
+
+    def march(autocast):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            r, _ = model._march(False, rays, 1.0, False, camidx, want_history=False)
+        torch.cuda.synchronize()
+        return r[-1]["sky_rgbs"].float().clone(), model._sky_mixed
+
+    s32, f0 = march(False)
+    s16, f1 = march(True)
+    assert (f0, f1) == (False, True)
+    dm = (s16 - s32).abs()                                   # init_state's O(1) weights: bf16 through 9 layers of them
+    assert 0.0 < float(dm.max()) <= 0.15 and float(dm.mean()) <= 2e-2, (float(dm.max()), float(dm.mean()))
+    model.autocast_render = False
+    soff, f2 = march(True)
+    assert f2 is False and torch.equal(soff, s32)
+
+
 def test_render_under_autocast_runs_the_mixed_precision_path():
     """The reference wraps the model call of render_image in accelerator.autocast() (models.py:957): with mixed precision
     on, its grid op gathers half tables (grid.py:41-44) and its Linear layers run in bf16.  Here the same context switches

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
@@ -96,7 +96,7 @@ SIGNATURES = {
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],
-    "ucn_sky_render": [ctypes.POINTER(UcnSky), c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u32, c_vp, c_vp, c_vp],
+    "ucn_sky_render": [ctypes.POINTER(UcnSky), c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u32, c_vp, c_vp, c_i32, c_vp],
     "ucn_dense": [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp],
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
 }

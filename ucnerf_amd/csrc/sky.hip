@@ -23,6 +23,7 @@
 // Reference quirks kept: z = near(1-t) + t/far with near = batch.far and
 // far = 1.5*near[0], i.e. z DEcreases; the last interval is 1e10; 1e-10 is added inside the
 // transmittance product.
+#include "bf_tiles.h"
 #include "mlp_ring.h"
 #include "pack_split.h"
 
@@ -45,7 +46,13 @@ constexpr int kSideFloats = 3584; // 14 KiB
 constexpr uint64_t kOffSide = kSkyStreamGroups * 256;
 constexpr uint64_t kOffM5 = kOffSide + kSideFloats;                       // [256][288] composed layer 5
 constexpr uint64_t kOffMv = kOffM5 + 256 * 288;                           // [128][288] composed views layer
-constexpr uint64_t kSkyPackedFloats = kOffMv + 128 * 288;
+// ---- bf16 stream of the mixed-precision kernel (1 KiB A-fragments [otp][it][s][o2]): pts_linears 1..4, 5, 6, 7, views
+constexpr int kBL[7] = {0, 128, 256, 384, 512, 656, 784};
+constexpr int kBV = 912, kBEnd = kBV + 72;                                // 984
+constexpr int kBPadded = (kBEnd + kTChunk - 1) / kTChunk * kTChunk;      // 992
+using BRing = Ring<kBPadded, kTChunk, 4, kTSlots, kTLead>;               // 64 KiB: two workgroups per CU
+constexpr uint64_t kOffBf = kOffMv + 128 * 288;
+constexpr uint64_t kSkyPackedFloats = kOffBf + (uint64_t)kBPadded * 256;
 
 constexpr int kLayerG[7] = {kGL1, kGL2, kGL3, kGL4, kGL5, kGL6, kGL7};
 constexpr int kBiasIdx[7] = {0, 1, 2, 3, -1, 4, 5};              // side-table bias block; layer 5's bias rides in the aux tile
@@ -222,6 +229,157 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
         *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Mixed-precision variant (Model.autocast_render under an active bf16 autocast; the reference's NeRF.forward runs its
+// nn.Linear layers in bf16 there, models.py:957 + :786-815): the same pair-chain sequence on v_mfma_f32_32x32x16_bf16 --
+// one product per MAC instead of three, 984 MFMAs per wave instead of 2952 --, activations as bf16 B operands (two
+// 8-tile buffers = 128 registers), the weight stream through the training kernels' 64 KiB ring, so that with the 14 KiB
+// side table two workgroups share a CU.  Layer 0 (3 -> 256), the alpha head and the rgb head stay fp32 VALU work on the
+// same side table; the skip connection's point and the view encoding enter as the bf16 auxiliary tile (what autocast
+// makes of the reference's concatenated inputs).
+template <int P>
+__device__ __forceinline__ bf8 (&pick_b(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
+    if constexpr (P == 0) return a;
+    else return b;
+}
+
+__global__ __launch_bounds__(256, 2) void k_sky_mlp_bf(SkyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring (64 KiB) + side table
+    const float *side = s_w + kTSlots * kTChunk * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t B = (uint64_t)a.N * kSkySamples;
+    const uint64_t b0 = ((uint64_t)blockIdx.x * 4u + wave) * 32u;
+    const bool live = b0 + j < B;
+    const uint64_t b = live ? b0 + j : B - 1;
+    const uint32_t ray = (uint32_t)(b / kSkySamples), s = (uint32_t)(b - (uint64_t)ray * kSkySamples);
+
+    const float tv = a.t_vals[s];
+    const float z = a.far_[ray] * (1.0f - tv) + a.inv_sky_far * tv;                    // models.py:872
+    const float px = a.origins[ray * 3 + 0] + a.dirs[ray * 3 + 0] * z;
+    const float py = a.origins[ray * 3 + 1] + a.dirs[ray * 3 + 1] * z;
+    const float pz = a.origins[ray * 3 + 2] + a.dirs[ray * 3 + 2] * z;
+
+    // Two activation buffers of 8 tiles + a shared 9th slot each (the auxiliary tile, so that a 9-tile layer sees ONE array)
+    bf8 XA[9][2], XB[9][2];
+    {
+        f32x16 av;
+        const float4 *ap = reinterpret_cast<const float4 *>(a.aux + (size_t)ray * 32 + 4 * h);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 v = ap[2 * r4];
+            av[4 * r4 + 0] = v.x; av[4 * r4 + 1] = v.y; av[4 * r4 + 2] = v.z; av[4 * r4 + 3] = v.w;
+        }
+        if (h == 0) { av[0] = px; av[1] = py; av[2] = pz; }
+        XA[8][0] = XB[8][0] = to_b(av, 0, false);
+        XA[8][1] = XB[8][1] = to_b(av, 1, false);
+    }
+
+    BRing ring(a.packed + kOffBf, s_w, lane, wave);
+    {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kTSlots * kTChunk) * 1024u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int piece = k * 4 + wave;
+            if (piece < kSideFloats / 256)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :
+                             : "s"(lside + piece * 1024u), "v"(lane * 16u), "s"(a.packed + kOffSide + piece * 256)
+                             : "memory");
+        }
+    }
+    ring_start(ring);
+    ring.template boundary<0>();                    // side table + chunk 0 landed
+
+    // ---- layer 0 (3 -> 256), fp32 on the VALU, rounded into XA
+    {
+        const float4 *p0 = reinterpret_cast<const float4 *>(side + kSL0) + h;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float4 w = p0[(t * 16 + r) * 2];
+                acc[r] = ((w.x * px + w.y * py) + w.z * pz) + w.w;
+            }
+            XA[t][0] = to_b(acc, 0, true);
+            XA[t][1] = to_b(acc, 1, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
+    const float *pa = side + kSAlpha + h;
+    sfor<7>([&](auto lic) {
+        constexpr int li = lic.value, NT_IN = li == 4 ? 9 : 8;
+        bf8 (&in)[9][2] = pick_b<li % 2>(XA, XB);
+        bf8 (&out)[9][2] = pick_b<(li + 1) % 2>(XA, XB);
+        sfor<4>([&](auto pc) {
+            constexpr int pr = pc.value;
+            f32x16 cur[2];
+            if constexpr (kBiasIdx[li] >= 0) {
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr, cur[0], h);
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr + 1, cur[1], h);
+            } else {
+                zero_acc(cur[0]);
+                zero_acc(cur[1]);
+            }
+            tile_pair<2, NT_IN, kBL[li] + pr * NT_IN * 4>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            if constexpr (li == 6) {                              // alpha head on the fp32 ReLU output of layer 7
+                alpha_partial<2 * pr, 0>(cur[0], pa, sig);
+                alpha_partial<2 * pr, 1>(cur[0], pa, sig);
+                alpha_partial<2 * pr + 1, 0>(cur[1], pa, sig);
+                alpha_partial<2 * pr + 1, 1>(cur[1], pa, sig);
+            }
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                out[2 * pr + o][0] = to_b(cur[o], 0, true);
+                out[2 * pr + o][1] = to_b(cur[o], 1, true);
+            }
+        });
+    });
+    // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = buffer 1 (7 layers), then the rgb head per pair
+    bf8 (&h7)[9][2] = pick_b<1>(XA, XB);
+    sig = (sig + __shfl_xor(sig, 32, 64)) + side[kSAlpha + 256];
+    const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    sfor<2>([&](auto pc) {
+        constexpr int pr = pc.value;
+        f32x16 v[2];
+        zero_acc(v[0]);
+        zero_acc(v[1]);
+        tile_pair<2, 9, kBV + pr * 36>(ring, v, h7);
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float4 w = prgb[((2 * pr + o) * 16 + r) * 2];
+                const float x = fmaxf(v[o][r], 0.0f);
+                c0 = fmaf(x, w.x, c0); c1 = fmaf(x, w.y, c1); c2 = fmaf(x, w.z, c2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+    c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+    const float *brgb = side + kSRgb + 512;
+    if (live && h == 0)
+        *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);
+}
+
+// bf16 A-fragments of a chain layer: dst[(((otp nt_in + it) 2 + s) 2 + o2)][lane][e] = bf16(W[32 (2 otp + o2) + (lane & 31)]
+// [32 it + perm(8 s + e, lane >> 5)]), perm(r, g) = (r & 3) + 8 (r >> 2) + 4 g (the accumulator order of the producing layer)
+__global__ __launch_bounds__(256) void k_pack_chain_bf(const float *__restrict__ W, uint32_t ld, uint32_t nt_out, uint32_t nt_in,
+                                                       __bf16 *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nt_out * nt_in * 2u * 512u) return;
+    const uint32_t e = i & 7u, lane = (i >> 3) & 63u, grp = i >> 9;
+    const uint32_t o2 = grp & 1u, s = (grp >> 1) & 1u, it = (grp >> 2) % nt_in, ot = 2u * ((grp >> 2) / nt_in) + o2;
+    const uint32_t r = 8u * s + e;
+    const uint32_t row = 32u * ot + (lane & 31u), col = 32u * it + (r & 3u) + 8u * (r >> 2) + 4u * (lane >> 5);
+    dst[i] = (__bf16)(col < ld ? W[(size_t)row * ld + col] : 0.0f);
+}
+
 // per-ray auxiliary tile: [0, 0, 0, 1, embed(cam_dir) = x, sin(f x), cos(f x) for f in 1,2,4,8 (27), 0]
 __global__ __launch_bounds__(256) void k_sky_aux(const float *__restrict__ cam, uint32_t N, float *__restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -341,6 +499,18 @@ extern "C" int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream) {
     }
     chainpack(M5, 288, 8, 9, kGL5);
     chainpack(Mv, 288, 4, 9, kGV);
+    {   // the mixed-precision kernel's stream (its zero padding comes from the fill below)
+        __bf16 *bs = reinterpret_cast<__bf16 *>(s->packed + kOffBf);
+        hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up((uint64_t)(kBPadded - kBEnd) * 256, 256)), dim3(256), 0, st,
+                           s->packed + kOffBf + (uint64_t)kBEnd * 256, (uint32_t)((kBPadded - kBEnd) * 256));
+        auto bfpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t frag) {
+            hipLaunchKernelGGL(k_pack_chain_bf, dim3(ucn_div_up((uint64_t)nto * nti * 1024, 256)), dim3(256), 0, st, W, ld, nto, nti,
+                               bs + frag * 512);
+        };
+        for (int i = 0; i < 6; i++) bfpack(s->w_pts[plain[i]], 256, 8, 8, kBL[plain[i] - 1]);
+        bfpack(M5, 288, 8, 9, kBL[4]);
+        bfpack(Mv, 288, 4, 9, kBV);
+    }
     hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, s->w_pts[0], 3u, s->b_pts[0], 256u, side + kSL0);
     hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, s->w_alpha, 256u, 0u, 256u, 1u, 1u, side + kSAlpha);
     hipLaunchKernelGGL(k_pack_head, dim3(2), dim3(256), 0, st, s->w_rgb, 128u, 0u, 128u, 3u, 4u, side + kSRgb);
@@ -354,7 +524,7 @@ extern "C" uint64_t ucn_sky_workspace_floats(uint32_t N) { return (uint64_t)N * 
 extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const float *directions,
                                  const float *cam_dirs, const float *far_, float far0_times_1p5,
                                  const float *t_vals /*DEVICE [120] = linspace(0,1,120)*/, uint32_t N,
-                                 float *workspace /*DEVICE N*(128+480) floats*/, float *sky_rgb_out,
+                                 float *workspace /*DEVICE N*(128+480) floats*/, float *sky_rgb_out, int mixed,
                                  ucn_stream_t stream) {
     UCN_REQUIRE(N == 0 || (s && s->packed && origins && directions && cam_dirs && far_ && t_vals && workspace && sky_rgb_out),
                 "sky_render: null pointer argument");
@@ -370,7 +540,11 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
     a.N = N; a.raw = raw;
     const uint64_t B = (uint64_t)N * kSkySamples;
     const size_t lds = ((size_t)kSkySlots * kSkyChunk * 256 + kSideFloats) * sizeof(float);
-    hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
+    if (mixed)
+        hipLaunchKernelGGL(k_sky_mlp_bf, dim3(ucn_div_up(B, 128)), dim3(256), ((size_t)kTSlots * kTChunk * 256 + kSideFloats) * sizeof(float),
+                           st, a);
+    else
+        hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite, dim3(ucn_div_up(N, 256)), dim3(256), 0, st, raw, directions, far_, t_vals,
                        a.inv_sky_far, N, sky_rgb_out);
     UCN_LAUNCH_CHECK("sky_render");

@@ -631,18 +631,22 @@ class Model(nn.Module):
                 r['ray_rgbs'] = final[:, None, :].expand(r['ray_rgbs'].shape)
 
         if getattr(cfg, 'model_sky', False):                           # ref models.py:326-337
+            # inference under an active bf16 autocast: the sky NeRF's nn.Linear layers are bf16 in the reference
+            sky_mixed = bool(self.autocast_render and torch.is_autocast_enabled()
+                             and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+            self._sky_mixed = sky_mixed
             if self.sky_min_background > 0 and not rand:
                 bgw = 1 - renderings[-1]['weights'].reshape(N, -1).sum(dim=-1)
                 keep = torch.nonzero(bgw >= self.sky_min_background).reshape(-1)      # host sync, like far[0] in render()
                 sky = torch.zeros(N, 3, device=dev)
                 if keep.numel() == N:
-                    sky = self.skynerf.render(o, d, cam, far)
+                    sky = self.skynerf.render(o, d, cam, far, mixed=sky_mixed)
                 elif keep.numel():
                     # far0 = 1.5 * far[0] of the FULL batch (models.py:329), not of the kept rays
-                    sky[keep] = self.skynerf.render(o[keep], d[keep], cam[keep], far[keep], far0=far.reshape(-1)[:1])
+                    sky[keep] = self.skynerf.render(o[keep], d[keep], cam[keep], far[keep], far0=far.reshape(-1)[:1], mixed=sky_mixed)
                 self._sky_kept = (int(keep.numel()), N)
             else:
-                sky = self.skynerf.render(o, d, cam, far)
+                sky = self.skynerf.render(o, d, cam, far, mixed=sky_mixed)
             for r in renderings:
                 r['sky_rgbs'] = sky
         if getattr(cfg, 'brightness_correction', False):               # ref models.py:339-363

@@ -67,9 +67,10 @@ class NeRF(nn.Module):
         return d
 
     @torch.no_grad()
-    def render(self, origins, directions, cam_dirs, far, far0=None):
+    def render(self, origins, directions, cam_dirs, far, far0=None, mixed=False):
         """models.py:326-337: near = batch.far, far = 1.5 * near[0] -> rgb_map [N,3].  `far0`: the tensor whose first
-        element stands for near[0] when `far` is a subset of the batch (Model.sky_min_background)."""
+        element stands for near[0] when `far` is a subset of the batch (Model.sky_min_background).  `mixed`: bf16 MFMA
+        layers (what the reference's nn.Linear layers are under a bf16 autocast) instead of the fp32-class ones."""
         lib = _lib.load()
         N = origins.shape[0]
         dev = origins.device
@@ -80,7 +81,7 @@ class NeRF(nn.Module):
         out = torch.empty(N, 3, device=dev)
         _lib.check(lib.ucn_sky_render(ctypes.byref(d), origins.data_ptr(), directions.data_ptr(), cam_dirs.data_ptr(),
                                       far.data_ptr(), far0, _t_vals(dev).data_ptr(), N, ws.data_ptr(), out.data_ptr(),
-                                      _lib.stream()))
+                                      int(bool(mixed)), _lib.stream()))
         return out
 
     def forward(self, input_pts, input_views):
