@@ -21,10 +21,19 @@ __device__ __forceinline__ bf8 pack8(const float (&v)[8]) {
 }
 // 8 accumulator registers (k-step s of a tile) -> the B operand of the next layer
 __device__ __forceinline__ bf8 to_b(const f32x16 &a, int s, bool relu) {
+#ifdef UCN_EXP_NOCVT        // experiment builds (tools/build_variant.sh): timing only, results are garbage
+    return __builtin_bit_cast(bf8, make_uint4(__float_as_uint(a[8 * s]), __float_as_uint(a[8 * s + 1]), __float_as_uint(a[8 * s + 2]),
+                                              __float_as_uint(a[8 * s + 3])));
+#endif
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = relu ? fmaxf(a[8 * s + e], 0.0f) : a[8 * s + e];
-    return pack8(v);
+    for (int e = 0; e < 8; e++) v[e] = a[8 * s + e];
+    const bf8 o = pack8(v);
+    if (!relu) return o;
+    // ReLU on the packed result: a negative bf16 is a negative int16 (v_pk_max_i16, two values per instruction; -0 -> +0)
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf8, __builtin_elementwise_max(__builtin_bit_cast(s8v, o), z));
 }
 __device__ __forceinline__ void zero_acc(f32x16 &a) {
 #pragma unroll
@@ -58,8 +67,10 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
         if constexpr (G % 4 == 0) ring.template piece<G / kTChunk + kTLead, (G % kTChunk) / 4>();
         acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
         // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
+#ifndef UCN_EXP_NOSGB
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
     });
 }
 template <class RING>

@@ -243,7 +243,10 @@ __device__ __forceinline__ bf8 (&pick_b(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
     else return b;
 }
 
-__global__ __launch_bounds__(256, 2) void k_sky_mlp_bf(SkyArgs a) {
+#ifndef UCN_SKY_BF_WGS
+#define UCN_SKY_BF_WGS 2
+#endif
+__global__ __launch_bounds__(256, UCN_SKY_BF_WGS) void k_sky_mlp_bf(SkyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring (64 KiB) + side table
     const float *side = s_w + kTSlots * kTChunk * 256;
     const int lane = threadIdx.x & 63;
@@ -541,8 +544,8 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
     const uint64_t B = (uint64_t)N * kSkySamples;
     const size_t lds = ((size_t)kSkySlots * kSkyChunk * 256 + kSideFloats) * sizeof(float);
     if (mixed)
-        hipLaunchKernelGGL(k_sky_mlp_bf, dim3(ucn_div_up(B, 128)), dim3(256), ((size_t)kTSlots * kTChunk * 256 + kSideFloats) * sizeof(float),
-                           st, a);
+        hipLaunchKernelGGL(k_sky_mlp_bf, dim3(ucn_div_up(B, 128)), dim3(256),
+                           ((size_t)kTSlots * kTChunk * 256 + kSideFloats) * sizeof(float) + (UCN_SKY_BF_WGS == 1 ? 8192 : 0), st, a);
     else
         hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite, dim3(ucn_div_up(N, 256)), dim3(256), 0, st, raw, directions, far_, t_vals,
