@@ -13,10 +13,19 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf(bf8 a, bf8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 // fp32 -> bf16, round to nearest even: the C cast is v_cvt_pk_bf16_f32 on gfx950 (two values per instruction)
+// (written as two-element vector conversions: element by element -- these files are built without the SLP vectoriser --
+// the compiler emitted one conversion per VALUE plus a v_perm_b32 per pair, twice the instructions)
 __device__ __forceinline__ bf8 pack8(const float (&v)[8]) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
     bf8 o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = (__bf16)v[e];
+    for (int e = 0; e < 8; e += 2) {
+        const f2v t = {v[e], v[e + 1]};
+        const bf2v r = __builtin_convertvector(t, bf2v);
+        o[e] = r[0];
+        o[e + 1] = r[1];
+    }
     return o;
 }
 // 8 accumulator registers (k-step s of a tile) -> the B operand of the next layer
@@ -63,8 +72,9 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
-        if constexpr (G % kTChunk == 0 && G / kTChunk >= 1) ring.template boundary<G / kTChunk>();
-        if constexpr (G % 4 == 0) ring.template piece<G / kTChunk + kTLead, (G % kTChunk) / 4>();
+        constexpr int CH = RING::kChunk, NW = RING::kWaves;     // a wave issues one DMA piece per NW fragments
+        if constexpr (G % CH == 0 && G / CH >= 1) ring.template boundary<G / CH>();
+        if constexpr (G % NW == 0) ring.template piece<G / CH + RING::kLeadChunks, (G % CH) / NW>();
         acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
         // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
 #ifndef UCN_EXP_NOSGB
@@ -75,7 +85,7 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
 }
 template <class RING>
 __device__ __forceinline__ void ring_start(RING &ring) {
-    rstatic_for<kTLead>([&](auto c) { ring.template issue_chunk<c.value>(); });
+    rstatic_for<RING::kLeadChunks>([&](auto c) { ring.template issue_chunk<c.value>(); });
 }
 
 }  // namespace

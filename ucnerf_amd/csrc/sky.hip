@@ -49,8 +49,14 @@ constexpr uint64_t kOffMv = kOffM5 + 256 * 288;                           // [12
 // ---- bf16 stream of the mixed-precision kernel (1 KiB A-fragments [otp][it][s][o2]): pts_linears 1..4, 5, 6, 7, views
 constexpr int kBL[7] = {0, 128, 256, 384, 512, 656, 784};
 constexpr int kBV = 912, kBEnd = kBV + 72;                                // 984
-constexpr int kBPadded = (kBEnd + kTChunk - 1) / kTChunk * kTChunk;      // 992
-using BRing = Ring<kBPadded, kTChunk, 4, kTSlots, kTLead>;               // 64 KiB: two workgroups per CU
+// workgroup = kBWaves waves sharing one ring of kBSlots chunks of kBChunk fragments; 12 waves = three per SIMD from ONE
+// workgroup (96 KiB ring + 14 KiB side table; two 4-wave workgroups with a 64 KiB ring each: 2 per SIMD)
+#ifndef UCN_SKY_BF_WAVES
+#define UCN_SKY_BF_WAVES 12
+#endif
+constexpr int kBWaves = UCN_SKY_BF_WAVES, kBChunk = kBWaves == 4 ? 16 : 2 * kBWaves, kBSlots = 4, kBLead = 2;
+constexpr int kBPadded = (kBEnd + kBChunk - 1) / kBChunk * kBChunk;      // 984 (24-fragment chunks) / 992 (16)
+using BRing = Ring<kBPadded, kBChunk, kBWaves, kBSlots, kBLead>;
 constexpr uint64_t kOffBf = kOffMv + 128 * 288;
 constexpr uint64_t kSkyPackedFloats = kOffBf + (uint64_t)kBPadded * 256;
 
@@ -243,17 +249,14 @@ __device__ __forceinline__ bf8 (&pick_b(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
     else return b;
 }
 
-#ifndef UCN_SKY_BF_WGS
-#define UCN_SKY_BF_WGS 2
-#endif
-__global__ __launch_bounds__(256, UCN_SKY_BF_WGS) void k_sky_mlp_bf(SkyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring (64 KiB) + side table
-    const float *side = s_w + kTSlots * kTChunk * 256;
+__global__ __launch_bounds__(64 * kBWaves, kBWaves == 4 ? 2 : 1) void k_sky_mlp_bf(SkyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring + side table
+    const float *side = s_w + kBSlots * kBChunk * 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const uint64_t B = (uint64_t)a.N * kSkySamples;
-    const uint64_t b0 = ((uint64_t)blockIdx.x * 4u + wave) * 32u;
+    const uint64_t b0 = ((uint64_t)blockIdx.x * kBWaves + wave) * 32u;
     const bool live = b0 + j < B;
     const uint64_t b = live ? b0 + j : B - 1;
     const uint32_t ray = (uint32_t)(b / kSkySamples), s = (uint32_t)(b - (uint64_t)ray * kSkySamples);
@@ -281,10 +284,10 @@ __global__ __launch_bounds__(256, UCN_SKY_BF_WGS) void k_sky_mlp_bf(SkyArgs a) {
 
     BRing ring(a.packed + kOffBf, s_w, lane, wave);
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
-        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kTSlots * kTChunk) * 1024u;
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kBSlots * kBChunk) * 1024u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int piece = k * 4 + wave;
+        for (int k = 0; k < (kSideFloats / 256 + kBWaves - 1) / kBWaves; k++) {
+            const int piece = k * kBWaves + wave;
             if (piece < kSideFloats / 256)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                              :
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256, UCN_SKY_BF_WGS) void k_sky_mlp_bf(SkyArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const float4 w = p0[(t * 16 + r) * 2];
-                acc[r] = ((w.x * px + w.y * py) + w.z * pz) + w.w;
+                acc[r] = fmaf(w.z, pz, fmaf(w.y, py, fmaf(w.x, px, w.w)));
             }
             XA[t][0] = to_b(acc, 0, true);
             XA[t][1] = to_b(acc, 1, true);
@@ -504,8 +507,9 @@ extern "C" int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream) {
     chainpack(Mv, 288, 4, 9, kGV);
     {   // the mixed-precision kernel's stream (its zero padding comes from the fill below)
         __bf16 *bs = reinterpret_cast<__bf16 *>(s->packed + kOffBf);
-        hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up((uint64_t)(kBPadded - kBEnd) * 256, 256)), dim3(256), 0, st,
-                           s->packed + kOffBf + (uint64_t)kBEnd * 256, (uint32_t)((kBPadded - kBEnd) * 256));
+        if (kBPadded > kBEnd)
+            hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up((uint64_t)(kBPadded - kBEnd) * 256, 256)), dim3(256), 0, st,
+                               s->packed + kOffBf + (uint64_t)kBEnd * 256, (uint32_t)((kBPadded - kBEnd) * 256));
         auto bfpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t frag) {
             hipLaunchKernelGGL(k_pack_chain_bf, dim3(ucn_div_up((uint64_t)nto * nti * 1024, 256)), dim3(256), 0, st, W, ld, nto, nti,
                                bs + frag * 512);
@@ -544,8 +548,8 @@ extern "C" int ucn_sky_render(const ucn_sky_t *s, const float *origins, const fl
     const uint64_t B = (uint64_t)N * kSkySamples;
     const size_t lds = ((size_t)kSkySlots * kSkyChunk * 256 + kSideFloats) * sizeof(float);
     if (mixed)
-        hipLaunchKernelGGL(k_sky_mlp_bf, dim3(ucn_div_up(B, 128)), dim3(256),
-                           ((size_t)kTSlots * kTChunk * 256 + kSideFloats) * sizeof(float) + (UCN_SKY_BF_WGS == 1 ? 8192 : 0), st, a);
+        hipLaunchKernelGGL(k_sky_mlp_bf, dim3(ucn_div_up(B, 32 * kBWaves)), dim3(64 * kBWaves),
+                           ((size_t)kBSlots * kBChunk * 256 + kSideFloats) * sizeof(float), st, a);
     else
         hipLaunchKernelGGL(k_sky_mlp, dim3(ucn_div_up(B, 128)), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite, dim3(ucn_div_up(N, 256)), dim3(256), 0, st, raw, directions, far_, t_vals,
