@@ -47,6 +47,79 @@ def test_grid_forward_bitexact(D, C, interp):
     assert torch.equal(gjac.cpu(), wjac)
 
 
+def test_gridencoder_extension_is_the_same_operator_as_the_ctypes_backend():
+    """The `_gridencoder` torch extension (ucnerf_amd/csrc/ext/gridencoder_bindings.cpp, what the reference's grid.py:10
+    imports) against the ctypes form of the same three functions: bit-identical forward (fp32 + fp16 tables, with dy_dx),
+    backward (table + input gradients) and total variation; launches land on the CURRENT stream; and GridEncoder routed
+    through it gives the same forward / backward as through the default backend."""
+    from ucnerf_amd.gridencoder import _backend, native, GridEncoder
+    ext = native.load()
+    rng = np.random.default_rng(11)
+    L, C, D, T = 8, 2, 3, 11
+    pls, offsets, sizes, _ = grid_cpu.table_layout(L, C, 16, 2048, T)
+    B = 3000
+    x = dev(torch.from_numpy(rng.random((B, D), dtype=np.float32)))
+    S = np.log2(pls)
+    off = dev(offsets)
+    for dt in (torch.float32, torch.float16):
+        table = dev(torch.from_numpy(rng.random((int(offsets[-1]), C), dtype=np.float32) * 2 - 1)).to(dt)
+        outs = []
+        for be in (_backend, ext):
+            o = torch.empty(L, B, C, device="cuda", dtype=dt)
+            j = torch.empty(B, L * D * C, device="cuda", dtype=dt)
+            be.grid_encode_forward(x, table, off, o, B, D, C, L, S, 16, j, 0, False, 0)
+            grad = dev(torch.from_numpy(np.random.default_rng(12).standard_normal((L, B, C)).astype(np.float32))).to(dt)
+            ge = torch.zeros_like(table)
+            gi = torch.zeros(B, D, device="cuda", dtype=dt)
+            be.grid_encode_backward(grad, x, table, off, ge, B, D, C, L, S, 16, j, gi, 0, False, 0)
+            outs.append((o, j, ge, gi))
+        (o0, j0, ge0, gi0), (o1, j1, ge1, gi1) = outs
+        assert torch.equal(o0, o1) and torch.equal(j0, j1) and torch.equal(gi0, gi1)
+        # the table gradient is accumulated with atomics: equal up to the order of the additions
+        tol = 1e-5 if dt == torch.float32 else 2e-2
+        assert float((ge0.float() - ge1.float()).abs().max()) <= tol * max(1.0, float(ge0.float().abs().max())) and float(ge0.abs().max()) > 0
+    table = dev(torch.from_numpy(rng.random((int(offsets[-1]), C), dtype=np.float32)))
+    tv = []
+    for be in (_backend, ext):
+        g = torch.zeros_like(table)
+        be.grad_total_variation(x, table, g, off, 0.3, B, D, C, L, S, 16, 0, False)
+        tv.append(g)
+    assert float(tv[0].abs().max()) > 0, 'total variation wrote nothing'
+    assert float((tv[0] - tv[1]).abs().max()) <= 1e-5 * max(1.0, float(tv[0].abs().max()))      # atomics again
+    # current-stream semantics: a side stream that first waits on a long fill must still see its own ordering
+    side = torch.cuda.Stream()
+    o = torch.empty(L, B, C, device="cuda")
+    with torch.cuda.stream(side):
+        tbl = torch.zeros_like(table)
+        tbl.copy_(table)                                   # enqueued on `side`; the encode below must run after it
+        ext.grid_encode_forward(x, tbl, off, o, B, D, C, L, S, 16, None, 0, False, 0)
+    side.synchronize()
+    ref = torch.empty(L, B, C, device="cuda")
+    _backend.grid_encode_forward(x, table, off, ref, B, D, C, L, S, 16, None, 0, False, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(o, ref)
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        ext.grid_encode_forward(x, table, off, o, B, D, 3, L, S, 16, None, 0, False, 0)
+    # the module through the extension
+    torch.manual_seed(0)
+    enc = GridEncoder(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, desired_resolution=2048, log2_hashmap_size=11).cuda()
+    with torch.no_grad():
+        enc.embeddings.uniform_(-1, 1)
+    xin = (x * 2 - 1).requires_grad_(False)
+    res = []
+    for use_native in (False, True):
+        native.use(use_native)
+        try:
+            enc.embeddings.grad = None
+            y = enc(xin, bound=1.0)
+            (y * y).sum().backward()
+            res.append((y.detach().clone(), enc.embeddings.grad.clone()))
+        finally:
+            native.use(False)
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * max(1.0, float(res[0][1].abs().max()))
+
+
 def test_grid_forward_baseline_layout_quirk_levels():
     """L=16 / T=2^19: levels 12 and 13 fall back to wrapped 'dense' strides (uint32 overflow in
     gridencoder.cu:71-75); the device addressing must follow."""

@@ -40,6 +40,32 @@ def test_argument_errors_surface_as_messages_without_a_gpu():
     assert rc != 0 and b"num_samples must be > 1" in lib.ucn_last_error()       # stepfun.py:271-272
 
 
+def test_gridencoder_extension_module_exports_the_reference_operator():
+    """`_gridencoder` as a real torch extension (pybind11 over the C ABI): the three names of
+    bindings.cpp:5-9, importable the way grid.py:10 imports it, linked to THIS libucnerf_march.so, and the reference's
+    TORCH_CHECK preconditions (gridencoder.cu:15-18, 449-465) surface as RuntimeError before any launch."""
+    from ucnerf_amd import _lib
+    from ucnerf_amd.gridencoder import native
+    if not os.path.exists(native.path()):
+        subprocess.check_call([os.path.join(REPO, "ucnerf_amd", "csrc", "ext", "build_ext.sh")])
+    code = ("import sys, torch; sys.path.insert(0, %r); import _gridencoder as _backend; "
+            "print(_backend.__file__); print(sorted(n for n in dir(_backend) if not n.startswith('_')))" % native.NATIVE_DIR)
+    out = subprocess.check_output([sys.executable, "-c", code], text=True).splitlines()
+    assert out[0] == native.path()
+    assert out[1] == "['abi_version', 'grad_total_variation', 'grid_encode_backward', 'grid_encode_forward']"
+    g = native.load()
+    assert g.abi_version() == _lib.ABI_VERSION
+    x, off = torch.zeros(4, 3), torch.zeros(3, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="inputs must be a CUDA tensor"):
+        g.grid_encode_forward(x, x, off, x, 4, 3, 2, 2, 1.0, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="grad must be a CUDA tensor"):
+        g.grid_encode_backward(x, x, x, off, x, 4, 3, 2, 2, 1.0, 16, None, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="inputs must be a CUDA tensor"):
+        g.grad_total_variation(x, x, x, off, 1.0, 4, 3, 2, 2, 1.0, 16, 0, False)
+    with pytest.raises(TypeError):                    # pybind11 signature: positional arguments as in gridencoder.h:12-15
+        g.grid_encode_forward(x, x, off, x)
+
+
 def test_product_has_no_cpu_path():
     from ucnerf_amd.internal import configs, models
     with models.bindings(NerfMLP=dict(grid_log2_hashmap_size=10), PropMLP=dict(grid_log2_hashmap_size=10)):
