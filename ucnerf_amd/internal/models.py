@@ -306,7 +306,7 @@ class Model(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ('_side_stream', '_prof', '_alive_idx', '_alive_cnt', '_alive_stats'):
+        for k in ('_side_stream', '_prof', '_alive_idx', '_alive_cnt', '_alive_stats', '_mixed_cache'):
             state.pop(k, None)
         return state
 
@@ -406,6 +406,12 @@ class Model(nn.Module):
                 return None
         elif not tg._fusable_heads(mlp, probe):
             return None
+        # the half table and the packed weights are rebuilt only when a parameter changed (a frame is tens of chunks)
+        key = tuple((p.data_ptr(), p._version) for p in mlp.parameters())
+        cache = self.__dict__.setdefault('_mixed_cache', {})
+        hit = cache.get(id(mlp))
+        if hit is not None and hit[0] == key:
+            return hit[1]
         out = {}
         half = mlp.encoder.level_dim % 2 == 0                      # grid.py:41-44: half tables when C is even
         d16 = _lib.UcnField()
@@ -426,6 +432,7 @@ class Model(nn.Module):
                            head=(ctypes.c_float * 4)(float(mlp.density_bias), float(mlp.rgb_premultiplier), float(mlp.rgb_bias),
                                                      float(mlp.rgb_padding)),
                            enc=lambda v: _dir_tiles(tg.view_encoding(v.float(), mlp.deg_view)))
+        cache[id(mlp)] = (key, out)
         return out
 
     def _march(self, rand, batch, train_frac, compute_extras, eval_camidx, want_history):
