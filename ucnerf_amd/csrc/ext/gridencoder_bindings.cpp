@@ -19,13 +19,24 @@
 
 namespace {
 
-#define UCN_CHECK_CUDA(x) TORCH_CHECK((x).device().is_cuda(), #x " must be a CUDA tensor")
-#define UCN_CHECK_CONTIGUOUS(x) TORCH_CHECK((x).is_contiguous(), #x " must be a contiguous tensor")
-#define UCN_CHECK_IS_INT(x) TORCH_CHECK((x).scalar_type() == at::ScalarType::Int, #x " must be an int tensor")
-#define UCN_CHECK_IS_FLOATING(x)                                                                            \
-    TORCH_CHECK((x).scalar_type() == at::ScalarType::Float || (x).scalar_type() == at::ScalarType::Half ||  \
-                    (x).scalar_type() == at::ScalarType::Double,                                            \
-                #x " must be a floating tensor")
+// Preconditions with the messages of the reference's host functions (gridencoder.cu:15-18, 449-465, 474-496), raised as
+// c10::Error -> Python RuntimeError before anything is launched.
+enum class Kind { Floating, Int };
+
+void require(const at::Tensor &t, const char *name, Kind kind) {
+    TORCH_CHECK(t.device().is_cuda(), name, " must be a CUDA tensor");
+    TORCH_CHECK(t.is_contiguous(), name, " must be a contiguous tensor");
+    const auto st = t.scalar_type();
+    if (kind == Kind::Int) {
+        TORCH_CHECK(st == at::ScalarType::Int, name, " must be an int tensor");
+    } else {
+        TORCH_CHECK(st == at::ScalarType::Float || st == at::ScalarType::Half || st == at::ScalarType::Double, name,
+                    " must be a floating tensor");
+    }
+}
+void require(const at::optional<at::Tensor> &t, const char *name) {
+    if (t.has_value() && t->defined()) require(*t, name, Kind::Floating);
+}
 
 // host copies of level-offset tensors: keyed on the TensorImpl, valid while that impl is alive and unmodified
 struct OffsetEntry {
@@ -77,12 +88,11 @@ void *opt_ptr(const at::optional<at::Tensor> &t) { return t.has_value() && t->de
 void grid_encode_forward(const at::Tensor inputs, const at::Tensor embeddings, const at::Tensor offsets, at::Tensor outputs,
                          const uint32_t B, const uint32_t D, const uint32_t C, const uint32_t L, const float S, const uint32_t H,
                          at::optional<at::Tensor> dy_dx, const uint32_t gridtype, const bool align_corners, const uint32_t interp) {
-    UCN_CHECK_CUDA(inputs); UCN_CHECK_CUDA(embeddings); UCN_CHECK_CUDA(offsets); UCN_CHECK_CUDA(outputs);
-    UCN_CHECK_CONTIGUOUS(inputs); UCN_CHECK_CONTIGUOUS(embeddings); UCN_CHECK_CONTIGUOUS(offsets); UCN_CHECK_CONTIGUOUS(outputs);
-    UCN_CHECK_IS_FLOATING(inputs); UCN_CHECK_IS_FLOATING(embeddings); UCN_CHECK_IS_INT(offsets); UCN_CHECK_IS_FLOATING(outputs);
-    if (dy_dx.has_value() && dy_dx->defined()) {
-        UCN_CHECK_CUDA(*dy_dx); UCN_CHECK_CONTIGUOUS(*dy_dx); UCN_CHECK_IS_FLOATING(*dy_dx);
-    }
+    require(inputs, "inputs", Kind::Floating);
+    require(embeddings, "embeddings", Kind::Floating);
+    require(offsets, "offsets", Kind::Int);
+    require(outputs, "outputs", Kind::Floating);
+    require(dy_dx, "dy_dx");
     TORCH_CHECK(inputs.scalar_type() == at::ScalarType::Float, "inputs must be float32 (gridencoder.cu:469 reads them as float)");
     TORCH_CHECK(outputs.scalar_type() == embeddings.scalar_type(), "outputs must have the embeddings' dtype");
     check_rc(ucn_grid_encode_forward(inputs.data_ptr<float>(), embeddings.data_ptr(), host_offsets(offsets, L), outputs.data_ptr(), B, D,
@@ -94,17 +104,13 @@ void grid_encode_backward(const at::Tensor grad, const at::Tensor inputs, const 
                           at::Tensor grad_embeddings, const uint32_t B, const uint32_t D, const uint32_t C, const uint32_t L,
                           const float S, const uint32_t H, const at::optional<at::Tensor> dy_dx, at::optional<at::Tensor> grad_inputs,
                           const uint32_t gridtype, const bool align_corners, const uint32_t interp) {
-    UCN_CHECK_CUDA(grad); UCN_CHECK_CUDA(inputs); UCN_CHECK_CUDA(embeddings); UCN_CHECK_CUDA(offsets); UCN_CHECK_CUDA(grad_embeddings);
-    UCN_CHECK_CONTIGUOUS(grad); UCN_CHECK_CONTIGUOUS(inputs); UCN_CHECK_CONTIGUOUS(embeddings); UCN_CHECK_CONTIGUOUS(offsets);
-    UCN_CHECK_CONTIGUOUS(grad_embeddings);
-    UCN_CHECK_IS_FLOATING(grad); UCN_CHECK_IS_FLOATING(inputs); UCN_CHECK_IS_FLOATING(embeddings); UCN_CHECK_IS_INT(offsets);
-    UCN_CHECK_IS_FLOATING(grad_embeddings);
-    if (dy_dx.has_value() && dy_dx->defined()) {
-        UCN_CHECK_CUDA(*dy_dx); UCN_CHECK_CONTIGUOUS(*dy_dx); UCN_CHECK_IS_FLOATING(*dy_dx);
-    }
-    if (grad_inputs.has_value() && grad_inputs->defined()) {
-        UCN_CHECK_CUDA(*grad_inputs); UCN_CHECK_CONTIGUOUS(*grad_inputs); UCN_CHECK_IS_FLOATING(*grad_inputs);
-    }
+    require(grad, "grad", Kind::Floating);
+    require(inputs, "inputs", Kind::Floating);
+    require(embeddings, "embeddings", Kind::Floating);
+    require(offsets, "offsets", Kind::Int);
+    require(grad_embeddings, "grad_embeddings", Kind::Floating);
+    require(dy_dx, "dy_dx");
+    require(grad_inputs, "grad_inputs");
     TORCH_CHECK(grad.scalar_type() == grad_embeddings.scalar_type(), "grad and grad_embeddings must have the same dtype");
     check_rc(ucn_grid_encode_backward(grad.data_ptr(), inputs.data_ptr<float>(), embeddings.data_ptr(), host_offsets(offsets, L),
                                       grad_embeddings.data_ptr(), B, D, C, L, S, H, opt_ptr(dy_dx), opt_ptr(grad_inputs), gridtype,
@@ -114,9 +120,10 @@ void grid_encode_backward(const at::Tensor grad, const at::Tensor inputs, const 
 void grad_total_variation(const at::Tensor inputs, const at::Tensor embeddings, at::Tensor grad, const at::Tensor offsets,
                           const float weight, const uint32_t B, const uint32_t D, const uint32_t C, const uint32_t L, const float S,
                           const uint32_t H, const uint32_t gridtype, const bool align_corners) {
-    UCN_CHECK_CUDA(inputs); UCN_CHECK_CUDA(embeddings); UCN_CHECK_CUDA(grad); UCN_CHECK_CUDA(offsets);
-    UCN_CHECK_CONTIGUOUS(inputs); UCN_CHECK_CONTIGUOUS(embeddings); UCN_CHECK_CONTIGUOUS(grad); UCN_CHECK_CONTIGUOUS(offsets);
-    UCN_CHECK_IS_FLOATING(inputs); UCN_CHECK_IS_FLOATING(embeddings); UCN_CHECK_IS_FLOATING(grad); UCN_CHECK_IS_INT(offsets);
+    require(inputs, "inputs", Kind::Floating);
+    require(embeddings, "embeddings", Kind::Floating);
+    require(grad, "grad", Kind::Floating);
+    require(offsets, "offsets", Kind::Int);
     TORCH_CHECK(inputs.scalar_type() == at::ScalarType::Float && embeddings.scalar_type() == at::ScalarType::Float &&
                     grad.scalar_type() == at::ScalarType::Float,
                 "grad_total_variation: float32 tensors only on this build");
@@ -128,8 +135,8 @@ void grad_total_variation(const at::Tensor inputs, const at::Tensor embeddings, 
 }  // namespace
 
 PYBIND11_MODULE(_gridencoder, m) {
-    m.def("grid_encode_forward", &grid_encode_forward, "grid_encode_forward (HIP, gfx950)");
-    m.def("grid_encode_backward", &grid_encode_backward, "grid_encode_backward (HIP, gfx950)");
-    m.def("grad_total_variation", &grad_total_variation, "grad_total_variation (HIP, gfx950)");
+    m.def("grid_encode_forward", &grid_encode_forward, "hash-grid interpolation, forward (+ dy_dx): HIP kernels of grid_op.hip on the current stream");
+    m.def("grid_encode_backward", &grid_encode_backward, "hash-grid interpolation, table (+ input) gradients: HIP kernels of grid_op.hip on the current stream");
+    m.def("grad_total_variation", &grad_total_variation, "total-variation gradient of the table, accumulated into grad");
     m.def("abi_version", []() { return ucn_abi_version(); }, "ABI version of the libucnerf_march.so this module is linked to");
 }
