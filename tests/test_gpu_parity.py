@@ -1007,6 +1007,10 @@ def test_sky_layer_mixed_precision_against_its_rounding_model():
     e32 = (mixed - full).abs()
     assert float(e32.max()) <= 3e-2 and float(e32.mean()) <= 5e-3, (float(e32.max()), float(e32.mean()))
     assert float(e32.max()) > 0.0                            # it IS another arithmetic
+    # a ray's result does not depend on the launch it rides in (1 ... 5 rays: waves without a live lane, ragged tiles)
+    for k in (1, 5):
+        sub = net.render(o[:k].contiguous(), d[:k].contiguous(), cam[:k].contiguous(), far[:k].contiguous(), mixed=True)
+        assert torch.equal(sub, mixed[:k]), k
 
     # through the model: the autocast state selects it, the knob switches it off bit-exactly
     spec = rm.make_spec("tiny", model_sky=True, brightness_correction=True)
