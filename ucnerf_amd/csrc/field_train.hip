@@ -131,18 +131,33 @@ using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
 // AUX (inference with rays-fastest lanes): the per-ray direction term is NOT pre-multiplied by the caller (pr0 / pr1 would
 // be 2 KiB per LANE there, 64 KiB of loads per wave); the ray's 32-column tile [dir_enc (27), 1, 0...] (a.ray_cols) enters
 // the two colour layers as one more input tile whose column 27 carries the layer bias, like in the rendering kernel.
+// The AUX form is inference only: its store paths fold away at compile time (88 -> 79 -> 70.5 ms per frame with them gone).
+// kInferWaves: workgroup shape of that form -- 4 = two 4-wave workgroups per CU like the training form; 8 / 12 = ONE
+// workgroup around a larger ring (the sky layer's bf16 shape; here 12 waves need 168 registers and spill: 72.6 ms, 8: 73.7).
+#ifndef UCN_INFER_WAVES
+#define UCN_INFER_WAVES 4
+#endif
+constexpr int kInferWaves = UCN_INFER_WAVES;
+using IRing = Ring<(kFwdFragsMax + 2 * kInferWaves - 1) / (2 * kInferWaves) * (2 * kInferWaves), kInferWaves == 4 ? kTChunk : 2 * kInferWaves,
+                   kInferWaves, kTSlots, kTLead>;
+static_assert(IRing::kChunks * IRing::kChunk <= kFwdPadded, "the packed forward stream is padded to kFwdPadded fragments");
+template <bool AUX> struct FwdShape { using ring = FRing; static constexpr int waves = 4, wgs = UCN_TRAIN_FWD_WGS; };
+template <> struct FwdShape<true> { using ring = IRing; static constexpr int waves = kInferWaves, wgs = kInferWaves == 4 ? 2 : 1; };
+
 template <int NTF, bool AUX = false>   // feature tiles: F <= 32 * NTF
-__global__ __launch_bounds__(256, UCN_TRAIN_FWD_WGS) void k_train_fwd(TrainFwdArgs a) {
+__global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void k_train_fwd(TrainFwdArgs aa) {
+    TrainFwdArgs a = aa;
+    if constexpr (AUX) a.store = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
+    const uint32_t s0 = (blockIdx.x * (uint32_t)FwdShape<AUX>::waves + wave) * 32u + j;
     const bool live = s0 < a.M;
     const uint32_t bq = live ? s0 : a.M - 1;             // position in the feature buffer
     const uint32_t ray = a.level_dim ? bq % a.n_rays : bq / a.S;
     const uint32_t sample = a.level_dim ? ray * a.S + bq / a.n_rays : bq;   // position in the [ray][sample] outputs
     extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
-    FRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
+    typename FwdShape<AUX>::ring ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
     ring_start(ring);
 
     // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
@@ -483,8 +498,10 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     const dim3 grid(ucn_div_up(M, 128));
     const size_t lds = kTSlots * kTChunk * 1024;
     if (aux) {
-        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_train_fwd<2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+        const dim3 igrid(ucn_div_up(M, 32 * kInferWaves)), iblock(64 * kInferWaves);
+        const size_t ilds = (size_t)IRing::kSlots * IRing::kChunk * 1024;
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
     } else {
         if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
