@@ -338,7 +338,8 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--ray-major", action="store_true", help="lanes = consecutive samples of a ray (default: neighbouring rays)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="0 fp32-input MFMA, 1 split-f16 MFMA (default: the package default)")
-    ap.add_argument("--overlap", action="store_true", help="featurisation of pass i+1 beside the MLP of pass i (2 streams)")
+    ap.add_argument("--overlap", type=int, nargs="?", const=1, default=0,
+                    help="featurisation of pass i+1 beside the MLP of pass i on 2 streams: 1 = co-resident launch shapes, 2 = plain shapes")
     ap.add_argument("--levels-per-block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--compact", type=float, default=0.0,
@@ -393,7 +394,7 @@ def main():
     if args.ray_major:
         model.rays_fastest = False
     if args.overlap:
-        model.overlap_streams = True
+        model.overlap_streams = args.overlap
     if args.fit_steps:
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import fit_scene

@@ -523,7 +523,7 @@ class Model(nn.Module):
             # Two HIP streams: featurisation of pass i+1 (L2-request / VALU bound) runs beside the MLP of pass i
             # (MFMA bound) on a second feature buffer; the hardware splits the CUs between the two kernels.
             overlap = bool(self.overlap_streams) and N > chunk
-            co = _lib.LAUNCH_CORESIDENT if (overlap and not is_prop) else 0     # launch shapes that share a CU
+            co = _lib.LAUNCH_CORESIDENT if (overlap and not is_prop and self.overlap_streams != 2) else 0     # launch shapes that share a CU (2: plain shapes, tails only)
             cur = torch.cuda.current_stream()
             feats = [feat]
             if overlap:
