@@ -316,8 +316,9 @@ int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
                   void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16,
                   const float *head, float *raw, float *y, uint32_t *m0 /*[M,2]*/, void *m1 /*[M,2] x 16 B*/, void *m2,
-                  uint32_t feat_level_dim /*0: feat [M,F]; C (inference): feat = ucn_march_features' layout 2, [L][B][C]
-                  with b = s N + ray -- a wave's lanes are then neighbouring rays, outputs stay [ray][sample]*/,
+                  uint32_t feat_level_dim /*0: feat [M,F]; C (the inference form only: pr0 = pr1 = NULL, ray_cols = the
+                  rays' direction tiles, no stores): feat = ucn_march_features' layout 2, [L][B][C] with b = s N + ray -- a
+                  wave's lanes are then neighbouring rays, outputs stay [ray][sample]*/,
                   ucn_stream_t stream);
 /* The same chain backwards (dgrad): gy [M,3] bf16 (gradient of y), graw [M] bf16|NULL (gradient of raw), packed_t =
  * the TRANSPOSED weights in the same fragment format (Wr^T, W1h^T, [W1x^T | W0x^T], Wd1^T, Wd0^T), m0/m1/m2 = the ReLU

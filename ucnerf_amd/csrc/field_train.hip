@@ -148,6 +148,7 @@ template <int NTF, bool AUX = false>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void k_train_fwd(TrainFwdArgs aa) {
     TrainFwdArgs a = aa;
     if constexpr (AUX) a.store = 0;
+    else a.level_dim = 0;                 // the training form reads sample-major features (checked by the entry point)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: the DMA addresses live in SGPRs
     const int j = lane & 31, h = lane >> 5;
@@ -484,8 +485,8 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     UCN_REQUIRE(!aux || (ray_cols && !h0 && !x && !h1 && !h2), "train_fwd: the in-stream direction tile is an inference form: ray_cols, no stores");
     const bool store = h0 || x || h1 || h2 || m0 || m1 || m2;
     UCN_REQUIRE(!store || (h0 && x && h1 && h2 && m0 && m1 && m2), "train_fwd: the activation / mask outputs come together (all, or none = inference)");
-    UCN_REQUIRE(feat_level_dim == 0 || (!store && !feat_bf16 && (!ray_cols || aux) && F % feat_level_dim == 0),
-                "train_fwd: level-major rays-fastest features are an inference layout (no stores), F a multiple of the level dim");
+    UCN_REQUIRE(feat_level_dim == 0 || (aux && !store && !feat_bf16 && F % feat_level_dim == 0),
+                "train_fwd: level-major rays-fastest features are the inference layout (in-stream direction tile, no stores), F a multiple of the level dim");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_fwd: too many samples");
     UCN_REQUIRE(act_ld == 0 || (act_ld >= 256 && act_ld % 8 == 0), "train_fwd: act_ld = %u (0, or >= 256 and a multiple of 8)", act_ld);
