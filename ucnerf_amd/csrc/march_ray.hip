@@ -11,6 +11,7 @@
 // k_composite give one wave64 to each ray (step function in LDS, ranks by binary search, sums as wave scans): transmittance is a wave prefix-sum (DPP-free shuffles), the percentile
 // lookups are ballots over the CDF held in LDS.
 #include "ucn_common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -30,6 +31,7 @@ namespace {
 //     is invisible after the cast back to float.
 // (The first version ran one THREAD per ray with its arrays in scratch memory: 6.4 ms per 2.46 M rays; the stores
 //  are now coalesced across the lanes of the ray's wave as well.)
+#ifdef UCN_WAVE_SHFL          // the first form: butterflies / Hillis-Steele steps over __shfl (ds_bpermute_b32)
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -48,6 +50,11 @@ __device__ __forceinline__ float wave_max_f(float v) {
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+#else
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_dpp<double>(v); }
+__device__ __forceinline__ double wave_scan_d(double v, int) { return wave_scan_dpp<double>(v); }      // inclusive
+__device__ __forceinline__ float wave_max_f(float v) { return wave_max_dpp(v); }
+#endif
 // #{j < len : f(j) <= x} / #{j < len : f(j) < x} for a non-decreasing f
 template <bool STRICT, class F>
 __device__ __forceinline__ uint32_t count_before(F f, uint32_t len, float x) {
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(256) void k_cone_basis(const float *__restrict__ ca
 }
 
 // ------------------------------------------------------------------ composite
+#ifdef UCN_WAVE_SHFL
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -291,6 +299,21 @@ __device__ __forceinline__ float wave_scan(float v, int lane) {
     }
     return v;
 }
+__device__ __forceinline__ float wave_excl(float incl, int lane) {      // inclusive -> exclusive (0 in lane 0)
+    const float u = __shfl_up(incl, 1, 64);
+    return lane == 0 ? 0.0f : u;
+}
+__device__ __forceinline__ uint32_t wave_count(uint32_t cnt) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    return cnt;
+}
+#else
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp<float>(v); }
+__device__ __forceinline__ float wave_scan(float v, int) { return wave_scan_dpp<float>(v); }            // inclusive
+__device__ __forceinline__ float wave_excl(float incl, int) { return wave_shift_up1<float>(incl); }    // -> exclusive
+__device__ __forceinline__ uint32_t wave_count(uint32_t cnt) { return wave_sum_dpp<uint32_t>(cnt); }
+#endif
 __device__ __forceinline__ float nan_to_num_inf(float v) {
     // torch.nan_to_num(x, nan=inf): NaN -> +inf (as given), +inf -> FLT_MAX, -inf -> -FLT_MAX
     if (v != v) return INFINITY;
@@ -337,8 +360,7 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
     }
     // exclusive prefix of tau over the ray = transmittance exponent
     // (shifted inclusive scan, not `inclusive - own`: with opaque_background the last tau is +inf)
-    float before = __shfl_up(wave_scan(lane_tau, lane), 1, 64);
-    if (lane == 0) before = 0.0f;
+    float before = wave_excl(wave_scan(lane_tau, lane), lane);
     float acc = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, dnum = 0.0f, lnum = 0.0f;
     float wloc[CH];
     float lane_w = 0.0f;
@@ -380,8 +402,7 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
     }
     if (!out_extras) return;
     // CDF of [w_0..w_{S-1}, bg_w] at the S+2 fenceposts [t_0..t_S, far]  (render.py:234-238)
-    float incl = __shfl_up(wave_scan(lane_w, lane), 1, 64);
-    if (lane == 0) incl = 0.0f;
+    float incl = wave_excl(wave_scan(lane_w, lane), lane);
     float *cdf = s_cdf[wv], *tt = s_t[wv];
 #pragma unroll
     for (int c = 0; c < CH; c++) {
@@ -401,8 +422,7 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
         // #{i in [0,S+1] : cdf[i] <= p}; the CDF is non-decreasing so this is a prefix
         uint32_t cnt = 0;
         for (uint32_t i = lane; i <= S + 1; i += 64) cnt += (cdf[i] <= ps[q]) ? 1u : 0u;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        cnt = wave_count(cnt);
         const uint32_t i0 = cnt > 0 ? cnt - 1 : 0;
         const uint32_t i1 = cnt <= S + 1 ? cnt : S + 1;
         const float x0 = cdf[i0], x1 = cdf[i1];
@@ -458,8 +478,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float *__restrict__
         }
         lane_tau += tau[c];
     }
-    float before = __shfl_up(wave_scan(lane_tau, lane), 1, 64);
-    if (lane == 0) before = 0.0f;
+    float before = wave_excl(wave_scan(lane_tau, lane), lane);
     float lane_w = 0.0f, dnum = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
