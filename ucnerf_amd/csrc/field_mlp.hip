@@ -23,6 +23,7 @@
 //         colour layer 1, h1 [ot < NTW][r4]                    W_c1[:, 32t:32t+32]
 // padded to a whole number of LDS chunks.
 #include "field_plan.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_prop_mlp(MlpArgs a) {
     for (int it = 0; it < 2; it++)
 #pragma unroll
         for (int r = 0; r < 16; r++) part = fmaf(h0[it][r], pd[(it * 16 + r) * 2 + h], part);
-    const float raw = (part + __shfl_xor(part, 32, 64)) + a.b_d1[0];
+    const float raw = xor32_sum(part) + a.b_d1[0];
     if (live && h == 0) a.density[out_index(a, b)] = softplus(raw + a.density_bias);
 }
 

@@ -43,6 +43,7 @@
 //       B   for each output pair otp: skip part [it < 3][s][o2] of M_B = [W_c1x W_d1 | W_c1 dir | bias | 0],
 //                                     then      [it < NTW][s][o2] of W_c1[:, 0:NW]
 #include "field_plan.h"
+#include "wave_dpp.h"
 #include "mlp_ring.h"
 
 namespace {
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
         for (int it = 0; it < 2; it++)
 #pragma unroll
             for (int r = 0; r < 16; r++) part = fmaf(acc0[it][r], pd[(it * 16 + r) * 2 + h], part);
-        const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
+        const float raw = xor32_sum(part) + pd[64];
         if (live && h == 0 && a.idx == nullptr) a.density[oi] = softplus(raw + a.density_bias);
     }
     if constexpr (RGB) {
@@ -438,9 +439,9 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
         rstatic_for<8>([&](auto e) { head_eighth<2 * (NP - 1), e.value>(acc[(2 * NP - 1) % 2], side, h, s0, s1, s2); });
         UCN_STAMP(14);
         // ---- rgb: sigmoid + padding (models.py:657-674)
-        s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
+        s0 = xor32_sum(s0);
+        s1 = xor32_sum(s1);
+        s2 = xor32_sum(s2);
         if (live && h == 0) {
             const float pad = a.rgb_padding;
             const float v[3] = {s0 + a.b_rgb[0], s1 + a.b_rgb[1], s2 + a.b_rgb[2]};
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void k_field_mlp_h8(MlpArgs a) {
         for (int it = 0; it < 2; it++)
 #pragma unroll
             for (int r = 0; r < 16; r++) part = fmaf(relu_bits(acc[it][r]), pd[(it * 16 + r) * 2 + h], part);
-        const float raw = (part + __shfl_xor(part, 32, 64)) + pd[64];
+        const float raw = xor32_sum(part) + pd[64];
         if (live && h == 0 && a.idx == nullptr) a.density[oi] = softplus(raw + a.density_bias);
     }
     UCN_STAMP8(3);
@@ -591,9 +592,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void k_field_mlp_h8(MlpArgs a) {
         rstatic_for<8>([&](auto e) { head_eighth<2 * p, e.value>(acc, side, h, s0, s1, s2); });
         UCN_STAMP8(7 + 2 * p);
     });
-    s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s0 = xor32_sum(s0);
+    s1 = xor32_sum(s1);
+    s2 = xor32_sum(s2);
     if (live && h == 0) {
         const float pad = a.rgb_padding;
         const float v[3] = {s0 + a.b_rgb[0], s1 + a.b_rgb[1], s2 + a.b_rgb[2]};

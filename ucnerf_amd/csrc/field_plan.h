@@ -2,6 +2,7 @@
 // mlp_mode 1): layout of ucn_field_t::packed, kernel arguments, small device helpers.
 #pragma once
 #include "mfma_chain.h"
+#include "wave_dpp.h"
 #include "mlp_ring.h"
 
 struct PackPlan {
@@ -136,9 +137,9 @@ __device__ __forceinline__ void rgb_head(const f32x16 (&h2)[NTW], const MlpArgs 
             s1 = fmaf(v, w.y, s1);
             s2 = fmaf(v, w.z, s2);
         }
-    s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s0 = xor32_sum(s0);
+    s1 = xor32_sum(s1);
+    s2 = xor32_sum(s2);
     if (live && h == 0) {
         const float pad = a.rgb_padding;
         float v[3] = {s0 + a.b_rgb[0], s1 + a.b_rgb[1], s2 + a.b_rgb[2]};

@@ -24,6 +24,7 @@
 // far = 1.5*near[0], i.e. z DEcreases; the last interval is 1e10; 1e-10 is added inside the
 // transmittance product.
 #include "bf_tiles.h"
+#include "wave_dpp.h"
 #include "mlp_ring.h"
 #include "pack_split.h"
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
         for (int r = 0; r < 16; r++) v[t][r] = 0.0f;
     pair_chain<kGV, 9>(v[0], v[1], h7, aux, p, ring);
     pair_chain<kGV + 9 * 8, 9>(v[2], v[3], h7, aux, p, ring);
-    sig = (sig + __shfl_xor(sig, 32, 64)) + side[kSAlpha + 256];
+    sig = xor32_sum(sig) + side[kSAlpha + 256];
     const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+    c0 = xor32_sum(c0); c1 = xor32_sum(c1); c2 = xor32_sum(c2);
     const float *brgb = side + kSRgb + 512;
     if (live && h == 0)
         *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64 * kBWaves, kBWaves == 4 ? 2 : 1) void k_sky_mlp_
     });
     // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = buffer 1 (7 layers), then the rgb head per pair
     bf8 (&h7)[9][2] = pick_b<1>(XA, XB);
-    sig = (sig + __shfl_xor(sig, 32, 64)) + side[kSAlpha + 256];
+    sig = xor32_sum(sig) + side[kSAlpha + 256];
     const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     sfor<2>([&](auto pc) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(64 * kBWaves, kBWaves == 4 ? 2 : 1) void k_sky_mlp_
             __builtin_amdgcn_sched_barrier(0);
         }
     });
-    c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+    c0 = xor32_sum(c0); c1 = xor32_sum(c1); c2 = xor32_sum(c2);
     const float *brgb = side + kSRgb + 512;
     if (live && h == 0)
         *reinterpret_cast<float4 *>(a.raw + b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);

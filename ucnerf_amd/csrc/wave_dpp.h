@@ -60,4 +60,12 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return wave_last<float>(v);
 }
 
+// v + (the value of lane ^ 32): the two halves of a sample's accumulator row meet through one v_permlane32_swap (VALU)
+// instead of a ds_bpermute_b32 round trip; the same two addends, so bit-identical to v + __shfl_xor(v, 32).
+__device__ __forceinline__ float xor32_sum(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);   // r[0] = {lo, lo}, r[1] = {hi, hi}
+    return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+
 }  // namespace
