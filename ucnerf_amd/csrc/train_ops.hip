@@ -8,6 +8,7 @@
 // The reference's optimiser step over a 7.1 M x 2 table is ~12 elementwise passes (nan_to_num, lerp, mul, addcmul,
 // sqrt, div, add, addcdiv); here every element is read and written once: 5 x 4 B per parameter.
 #include "ucn_common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -54,19 +55,8 @@ __global__ __launch_bounds__(256) void k_adam_step(float *__restrict__ param, fl
     }
 }
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wscan(float v, int lane) {        // inclusive
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave_sum_dpp<float>(v); }
+__device__ __forceinline__ float wscan(float v, int) { return wave_scan_dpp<float>(v); }        // inclusive (wave_dpp.h)
 
 // One wave per ray, lane owns CH consecutive intervals.  loss = sum_i w_i^2 d_i / 3 + sum_ij w_i w_j |u_i - u_j| with
 // u = interval midpoints (sorted, so the double sum is 2 sum_i w_i (u_i W_i - M_i), W / M exclusive prefix sums of w and
@@ -105,7 +95,7 @@ __global__ __launch_bounds__(256) void k_distortion(const float *__restrict__ t,
         acc = wsum(acc);
         if (lane == 0) out[ray] = acc;
     } else {
-        const float Wt = __shfl(iw, 63, 64), Mt = __shfl(im, 63, 64), g = g_loss[ray];
+        const float Wt = wave_last<float>(iw), Mt = wave_last<float>(im), g = g_loss[ray];
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const uint32_t i = lane * CH + c;
@@ -124,14 +114,7 @@ __global__ __launch_bounds__(256) void k_distortion(const float *__restrict__ t,
 // detached, so only d/d wp exists.  One wave per ray; the reference's sort of 2(S+1) knots is a two-list merge rank,
 // its O(n m) interpolation masks a binary search, its cumulative sums wave scans (accumulated in double like
 // torch-CPU's cumsum; the reference's device cumsum is fp32 and agrees to ~3e-5).
-__device__ __forceinline__ double wscan_d(double v, int lane) {      // inclusive; torch-CPU's cumsum accumulates in double
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
+__device__ __forceinline__ double wscan_d(double v, int) { return wave_scan_dpp<double>(v); }      // inclusive; torch-CPU's cumsum accumulates in double
 
 __global__ __launch_bounds__(256) void k_interlevel(const float *__restrict__ c_, const float *__restrict__ w_, uint32_t S1,
                                                     const float *__restrict__ cp_, const float *__restrict__ wp_, uint32_t Sp, float r,
