@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
     extern __shared__ float s_mem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t ray_raw = blockIdx.x * 4u + wv;
-    const bool live = ray_raw < N;                       // wave-uniform; dead waves still reach the barriers
-    const uint32_t ray = live ? ray_raw : N - 1;
+    if (ray_raw >= N) return;                            // wave-uniform; every hand-off below is inside the wave
+    const bool live = true;
+    const uint32_t ray = ray_raw;
     const uint32_t n = n_prev, m = 3 * n + 1;            // n >= 1: the first level is k_resample_first
     float *t = s_mem + (size_t)wv * ((n + 1) + n + (m + 1) + m + (m + 1) + S);
     float *p = t + (n + 1), *kn = p + n, *wt = kn + (m + 1), *cdf = wt + m, *c = cdf + (m + 1);
@@ -124,10 +125,10 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         for (uint32_t i = lane; i <= n; i += 64) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
         for (uint32_t i = lane; i < n; i += 64) wt[i] = w_prev[(size_t)ray * n + i];
         sd = t; w = wt; nw = n;
-        __syncthreads();
+        wave_lds_handoff();
     } else {
         for (uint32_t i = lane; i <= n; i += 64) t[i] = sd_prev[(size_t)ray * (n + 1) + i];
-        __syncthreads();
+        wave_lds_handoff();
         for (uint32_t i = lane; i < n; i += 64)
             p[i] = w_prev[(size_t)ray * n + i] / fmaxf(t[i + 1] - t[i], UCN_EPS);       // weight_to_pdf
         // sort(cat[t, t0-d, t1+d]) == ranks in the 3-way merge of three sorted lists, then clip to [0,1]
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
             kn[pos] = fminf(fmaxf(v, 0.0f), 1.0f);
             src[pos] = near;
         }
-        __syncthreads();
+        wave_lds_handoff();
         // max-pool the pdf over the dilated intervals covering each knot interval, times its width
         double part = 0.0;
         for (uint32_t i = lane; i + 1 < m; i += 64) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         const float norm = fmaxf((float)wave_sum_d(part), UCN_EPS);
         for (uint32_t i = lane; i + 1 < m; i += 64) wt[i] = wt[i] / norm;
         sd = kn + 1; w = wt + 1; nw = m - 3;                             // models.py:175-176
-        __syncthreads();
+        wave_lds_handoff();
     }
     // logits -> softmax -> CDF; lane owns CH consecutive intervals so that the prefix sum is a wave scan.  The logit
     // and then the exponential of an interval are parked in the lane's own cdf[] slots (one logf / expf each).
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         }
     }
     if (lane == 0) cdf[nw] = 1.0f;
-    __syncthreads();
+    wave_lds_handoff();
     // inverse CDF at the sorted u's (stepfun.py:283-293): idx = #{1 <= j <= nw : cdf[j] <= u}
     const float jit = jitter ? jitter[(size_t)ray * jcols] : 0.0f;
     auto Cdf1 = [&](uint32_t j) { return cdf[j + 1]; };
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ sd_p
         const float f0 = sd[idx], f1 = sd[i1];
         c[k] = f0 + fr * (f1 - f0);
     }
-    __syncthreads();
+    wave_lds_handoff();
     // midpoints + reflected / clamped ends; the S + 1 outputs of the ray leave as coalesced stores
     if (!live) return;
     float *out = sd_out + (size_t)ray * (S + 1);
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void k_composite(const float *__restrict__ den
         }
     }
     if (lane == 0) { cdf[0] = 0.0f; cdf[S + 1] = 1.0f; tt[S] = t_last; tt[S + 1] = fr; }
-    __syncthreads();
+    wave_lds_handoff();
     float pct[3];
     const float ps[3] = {0.05f, 0.5f, 0.95f};
 #pragma unroll

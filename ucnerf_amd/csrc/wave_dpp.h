@@ -60,6 +60,15 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return wave_last<float>(v);
 }
 
+// LDS written by some lanes and read by OTHER LANES OF THE SAME WAVE (a wave working in its own LDS region): the writes
+// are drained (lgkmcnt) and the compiler may not move LDS accesses across, but no s_barrier -- the other waves of the
+// workgroup work on other rays and have nothing to wait for.
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // v + (the value of lane ^ 32): the two halves of a sample's accumulator row meet through one v_permlane32_swap (VALU)
 // instead of a ds_bpermute_b32 round trip; the same two addends, so bit-identical to v + __shfl_xor(v, 32).
 __device__ __forceinline__ float xor32_sum(float v) {
