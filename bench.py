@@ -353,6 +353,7 @@ def main():
                     help="render under torch.autocast(bf16) like the reference's render_image under `accelerate --mixed_precision "
                          "bf16` (models.py:957): half tables in the gather, dense layers as bf16 MFMAs, fp32 compositing -- the "
                          "'mixed bf16/fp32' of BASELINE configs[4]; NOT the fp32 headline")
+    ap.add_argument("--float-features", action="store_true", help="with --autocast: float features between gather and MLP (Model.autocast_bf16_features = False)")
     ap.add_argument("--sky-skip", type=float, default=0.0,
                     help="Model.sky_min_background (with --cfg5): sky layer only for rays whose background weight reaches this "
                          "value.  Default off: the reference returns sky_rgbs for every ray, and on the random-init field "
@@ -404,6 +405,7 @@ def main():
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     model.compact_min_weight = args.compact
     model.sky_min_background = args.sky_skip
+    model.autocast_bf16_features = not args.float_features
     cfg.render_ray_tile = args.ray_tile
     batch = frame_rays(device, args.cameras, virtual=args.cfg5)
     n_rays = args.cameras * H_IMG * W_IMG

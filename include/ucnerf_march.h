@@ -135,6 +135,12 @@ int ucn_tsdf_integrate(const float *voxel_world, uint32_t N, const float *w2c /*
  * _Float16) -- what the reference gathers under autocast (gridencoder/grid.py:41-44: `embeddings.to(torch.half)` when
  * autocast is on and C is even).  The interpolation arithmetic stays fp32. */
 #define UCN_TABLE_F16 0x200
+/* ... and (with UCN_TABLE_F16, level_dim 2, a level-major layout) features_out receives [num_levels][N*S] PAIRS OF BF16
+ * (4 bytes per level and sample, round to nearest even) instead of float pairs: the operand format of the bf16 inference
+ * MLP (ucn_train_fwd with feat_level_dim = 2 | UCN_FEAT_BF16), which would round the floats the same way. */
+#define UCN_FEATURES_BF16 0x400
+/* OR-ed into ucn_train_fwd's feat_level_dim: `feat` holds the bf16 pairs UCN_FEATURES_BF16 produced. */
+#define UCN_FEAT_BF16 0x100
 
 /* ref: render.py:94-152 cast_rays + coord.py:60-116 contraction + grid.py:158-174 /
  * gridencoder.cu:87-199 + models.py:494-496 (erf damping, mean over the 6 multisamples).

@@ -1065,6 +1065,12 @@ def test_render_under_autocast_runs_the_mixed_precision_path():
     d = (mixed["rgb"] - full["rgb"]).abs()
     assert float(d.max()) <= 3e-2 and float(d.mean()) <= 3e-3, (float(d.max()), float(d.mean()))
     assert float((mixed["acc"] - full["acc"]).abs().max()) <= 3e-2
+    model.autocast_bf16_features = False                     # float features between gather and MLP: the same pixels, bit for bit
+    wide, used3 = march(True)
+    model.autocast_bf16_features = True
+    assert used3 == 2
+    for k in mixed:
+        assert torch.equal(wide[k], mixed[k]), k
     model.autocast_render = False
     off, used2 = march(True)
     model.autocast_render = True

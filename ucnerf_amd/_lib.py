@@ -12,7 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
 ABI_VERSION = 17
 LAUNCH_CORESIDENT = 0x100
-TABLE_F16 = 0x200          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
+TABLE_F16 = 0x200
+FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
+FEAT_BF16 = 0x100          # ucn_train_fwd feat_level_dim flag: the features are those pairs          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 
 c_u32, c_u64, c_i32, c_f32, c_vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

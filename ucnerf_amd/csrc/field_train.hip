@@ -34,6 +34,7 @@ struct TrainFwdArgs {
     float *raw, *y;           // [M], [M, 3]: raw density and colour logits, or (head) density and rgb
     uint32_t ld_h0, ld_act, ld_fb;
     int store;                // 0: inference -- no activation / mask stores (h0, x, h1, h2, m0, m1, m2 are NULL)
+    int feat_bf16_in;         // (inference form) feat holds [L][B] pairs of bf16 (level_dim 2): what UCN_FEATURES_BF16 wrote
     uint32_t n_rays, level_dim;   // level_dim != 0 (inference only): feat is the rendering gather's [L][B][C] with b = s * n_rays + ray
     //                              (rays fastest) and the wave's 32 lanes are 32 consecutive b; outputs stay [ray][sample]
     int head;                 // 1: raw := softplus(raw + density_bias), y := sigmoid(premult y + rgb_bias) (1 + 2 pad) - pad
@@ -171,7 +172,13 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint32_t k = 32u * ft + 16u * s + 8u * h + e;
-                if (a.level_dim == 2u) {                       // one 8-byte load per level
+                if (AUX && a.feat_bf16_in) {                   // bf16 pairs as the gather left them: one 4-byte load per level, no conversion
+                    if (e % 2 == 0) {
+                        const uint32_t t = k < a.F ? reinterpret_cast<const uint32_t *>(a.feat)[(size_t)(k >> 1) * a.M + bq] : 0u;
+                        v[e] = __uint_as_float(t << 16);
+                        v[e + 1] = __uint_as_float(t & 0xFFFF0000u);
+                    }
+                } else if (a.level_dim == 2u) {                // one 8-byte load per level
                     if (e % 2 == 0) {
                         const float2 t = k < a.F ? *reinterpret_cast<const float2 *>(a.feat + ((size_t)(k >> 1) * a.M + bq) * 2) : make_float2(0.0f, 0.0f);
                         v[e] = t.x;
@@ -481,6 +488,9 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     if (M == 0) return 0;
     UCN_REQUIRE(feat && packed && bias_d0 && bias_d1 && bias_rgb && raw && y, "train_fwd: null pointer argument");
     const bool aux = !pr0 && !pr1;           // direction tile in the stream instead of pre-multiplied per-ray terms
+    const bool bf16_in = (feat_level_dim & UCN_FEAT_BF16) != 0;
+    feat_level_dim &= ~(uint32_t)UCN_FEAT_BF16;
+    UCN_REQUIRE(!bf16_in || (feat_level_dim == 2 && !pr0 && !pr1), "train_fwd: bf16 features are the inference form's, level_dim 2");
     UCN_REQUIRE(aux || (pr0 && pr1), "train_fwd: pr0 and pr1 come together");
     UCN_REQUIRE(!aux || (ray_cols && !h0 && !x && !h1 && !h2), "train_fwd: the in-stream direction tile is an inference form: ray_cols, no stores");
     const bool store = h0 || x || h1 || h2 || m0 || m1 || m2;
@@ -493,7 +503,7 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     UCN_REQUIRE(!ray_cols || aux || (ray_dst && act_ld && act_ld % 8 == 0), "train_fwd: ray_cols needs ray_dst and act_ld %% 8 == 0");
     UCN_REQUIRE(!feat_bf16 || F % 8 == 0, "train_fwd: the bf16 feature copy needs F %% 8 == 0, got %u", F);
     TrainFwdArgs a{feat, (const uint4 *)packed, bias_d0, bias_d1, bias_rgb, pr0, pr1, (uint16_t *)h0, (uint16_t *)x, (uint16_t *)h1,
-                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, store ? 1 : 0, N, feat_level_dim, head != nullptr,
+                   (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, store ? 1 : 0, bf16_in ? 1 : 0, N, feat_level_dim, head != nullptr,
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
     const dim3 grid(ucn_div_up(M, 128));

@@ -487,7 +487,7 @@ constexpr uint32_t kSharedCellMaxRes = UCN_SHARED_CELL_MAX_RES;     // dense lev
 template <uint32_t C, typename TT>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__restrict__ table, uint32_t lvl0,
                                           uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
-                                          size_t B, size_t b, float *__restrict__ out, bool sample_major) {
+                                          size_t B, size_t b, float *__restrict__ out, bool sample_major, bool out_bf16 = false) {
     const uint32_t F_out = lvls.L * C;
     for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
@@ -516,6 +516,13 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__res
         float *o = sample_major ? out + b * F_out + (size_t)lvl * C : out + ((size_t)lvl * B + b) * C;
         const float inv = (float)G;
         if constexpr (C == 2) {
+            if (out_bf16) {            // [L][B] pairs of bf16 (round to nearest even): what the bf16 MLP would make of the floats
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+                const f2v t = {acc[0] / inv, acc[1] / inv};
+                reinterpret_cast<uint32_t *>(out)[(size_t)lvl * B + b] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf2v));
+                continue;
+            }
             *reinterpret_cast<float2 *>(o) = make_float2(acc[0] / inv, acc[1] / inv);
         } else if constexpr (C == 4) {
             *reinterpret_cast<float4 *>(o) = make_float4(acc[0] / inv, acc[1] / inv, acc[2] / inv, acc[3] / inv);
@@ -679,12 +686,13 @@ __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const TT
     // On the dense coarse levels neighbouring pixels read the same few lattice cells, which the TA
     // coalesces: levels 0-7 drop to the VALU floor (-20 % on the kernel, r01b).  The model's default.
     uint32_t ray, s;
-    if (layout == 2) { s = (uint32_t)(b / N); ray = (uint32_t)(b - (size_t)s * N); }
+    if ((layout & 3) == 2) { s = (uint32_t)(b / N); ray = (uint32_t)(b - (size_t)s * N); }
     else { ray = (uint32_t)(b / S); s = (uint32_t)(b - (size_t)ray * S); }
     float u[6][3], rs[6], csum[3], tsum;
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = grp.lo[blockIdx.y], lvl1 = grp.lo[blockIdx.y + 1];
-    featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
+    if constexpr (sizeof(TT) == 2) featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, (layout & 0x10) != 0);
+    else featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
     if (blockIdx.y == 0) {
         const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
         if (coord_out) {
@@ -1186,9 +1194,13 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features: flip and spin come together");
     const bool coresident = (layout & UCN_LAUNCH_CORESIDENT) != 0;
     const bool half_table = (layout & UCN_TABLE_F16) != 0;
-    layout &= ~(UCN_LAUNCH_CORESIDENT | UCN_TABLE_F16);
+    const bool out_bf16 = (layout & UCN_FEATURES_BF16) != 0;
+    layout &= ~(UCN_LAUNCH_CORESIDENT | UCN_TABLE_F16 | UCN_FEATURES_BF16);
     UCN_REQUIRE(!(half_table && coresident), "march_features: the co-resident launch shape reads fp32 tables");
     UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");
+    UCN_REQUIRE(!out_bf16 || (half_table && f->level_dim == 2 && layout != 1),
+                "march_features: bf16 features come with half tables, level_dim 2 and a level-major layout");
+    if (out_bf16) layout |= 0x10;                      // the kernel's private flag
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;

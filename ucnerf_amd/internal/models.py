@@ -350,6 +350,9 @@ class Model(nn.Module):
 
     autocast_half_tables: bool = True     # training under autocast gathers a HALF copy of the tables, like the reference's
     #                                      _grid_encode (grid.py:41-44); False keeps the fp32 tables (more exact, 2x the bytes)
+    autocast_bf16_features: bool = True   # (with autocast_render) the NeRF level's features leave the gather as bf16 pairs -- what
+    #                                      its bf16 MLP would round the floats to anyway: bit-identical pixels, half the
+    #                                      workspace traffic
     autocast_render: bool = True          # inference marches called under bf16 autocast (the reference's render_image wraps the
     #                                      model call in accelerator.autocast(), models.py:957) run in the reference's mixed
     #                                      precision: half tables in the gather, dense layers as bf16 MFMAs (the training
@@ -407,7 +410,7 @@ class Model(nn.Module):
         elif not tg._fusable_heads(mlp, probe):
             return None
         # the half table and the packed weights are rebuilt only when a parameter changed (a frame is tens of chunks)
-        key = tuple((p.data_ptr(), p._version) for p in mlp.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in mlp.parameters()) + (bool(self.autocast_bf16_features),)
         cache = self.__dict__.setdefault('_mixed_cache', {})
         hit = cache.get(id(mlp))
         if hit is not None and hit[0] == key:
@@ -420,6 +423,8 @@ class Model(nn.Module):
             out['table'] = emb.detach().to(torch.half)
             d16.embeddings = out['table'].data_ptr()
         out['desc'], out['table_flag'] = d16, (_lib.TABLE_F16 if half else 0)
+        # the NeRF level's features leave the gather as the bf16 pairs its MLP consumes (half the workspace traffic)
+        out['feat_flag'] = _lib.FEATURES_BF16 if (half and mlp.encoder.level_dim == 2 and not is_prop and self.autocast_bf16_features) else 0
         with torch.autocast('cuda', enabled=False):
             if is_prop:
                 l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
@@ -549,7 +554,7 @@ class Model(nn.Module):
                     o[sl].data_ptr(), d[sl].data_ptr(), basis[sl].data_ptr(), rad[sl].data_ptr(),
                     None if flip is None else flip[sl].data_ptr(), None if spin is None else spin[sl].data_ptr(),
                     float(self.std_scale), n, S, int(self.levels_per_block),
-                    ((2 if self.rays_fastest else 0) | co) if mixed is None else (2 | mixed['table_flag']),
+                    ((2 if self.rays_fastest else 0) | co) if mixed is None else (2 | mixed['table_flag'] | (mixed['feat_flag'] if not is_prop else 0)),
                     fb.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, fstream.cuda_stream))
                 if prof is not None:
                     e1.record(fstream)
@@ -569,7 +574,8 @@ class Model(nn.Module):
                     _lib.check(lib.ucn_train_fwd(fb.data_ptr(), L * C, mixed['packed'].data_ptr(), mixed['bias0'].data_ptr(),
                                                  mixed['bias1'].data_ptr(), mixed['biasr'].data_ptr(), None, None, n, S,
                                                  None, None, None, None, 0, vd_enc[sl].data_ptr(), None, None, mixed['head'],
-                                                 density[sl].data_ptr(), rgbs[sl].data_ptr(), None, None, None, C, st))
+                                                 density[sl].data_ptr(), rgbs[sl].data_ptr(), None, None, None,
+                                                 C | (_lib.FEAT_BF16 if mixed['feat_flag'] else 0), st))
                 elif compact:
                     # density head -> weights of this pass's rays -> alive list -> colour layers of the alive samples
                     rf = int(bool(self.rays_fastest))
