@@ -38,6 +38,13 @@ def test_argument_errors_surface_as_messages_without_a_gpu():
     assert rc != 0 and b"D must be" in lib.ucn_last_error()
     rc = lib.ucn_resample(None, None, 0, 0.0, 1.0, 0.0, 1, None, 0, 0.0, 4, 1, 1, None)
     assert rc != 0 and b"num_samples must be > 1" in lib.ucn_last_error()       # stepfun.py:271-272
+    # the bf16 MLP's entry point: level-major / bf16 features belong to the inference form (no per-ray terms, no stores)
+    fwd = lambda pr, lvl, h0=None: lib.ucn_train_fwd(1, 32, 1, 1, 1, 1, pr, pr, 4, 8, h0, None, None, None, 0, 1, None, None, None,
+                                                    1, 1, None, None, None, lvl, None)
+    assert fwd(1, 2) != 0 and b"inference layout" in lib.ucn_last_error()
+    assert fwd(1, 2 | _lib.FEAT_BF16) != 0 and b"bf16 features are the inference form" in lib.ucn_last_error()
+    assert fwd(None, 4 | _lib.FEAT_BF16) != 0 and b"level_dim 2" in lib.ucn_last_error()
+    assert fwd(None, 2, h0=1) != 0 and b"no stores" in lib.ucn_last_error()
 
 
 def test_gridencoder_extension_module_exports_the_reference_operator():
