@@ -156,10 +156,12 @@ def test_coresident_launch_shapes_give_identical_pixels():
     model.max_chunk_rays = 4096
     out = {}
     with torch.no_grad():
-        for ov in (False, True):
+        for ov in (False, True, 2):                           # 2: the same two streams with the plain launch shapes
             model.overlap_streams = ov
             r, _ = model(False, flat, 1.0, True)
             torch.cuda.synchronize()
             out[ov] = {k: r[-1][k].clone() for k in ("rgb", "depth", "acc", "weights")}
+    model.overlap_streams = False
     for k in out[False]:
         assert torch.equal(out[False][k], out[True][k]), k
+        assert torch.equal(out[False][k], out[2][k]), k
