@@ -459,8 +459,9 @@ def main():
         # same command (profiles/r02c/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
         # when this run's launches have the size those passes measured
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02c", "traffic.json")))
-            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and not args.autocast:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02c",
+                                             "traffic_autocast.json" if args.autocast else "traffic.json")))
+            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and (not args.autocast or model.autocast_bf16_features):
                 gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
                 gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
                                           "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
