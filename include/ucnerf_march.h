@@ -179,6 +179,20 @@ int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const 
                                 ucn_stream_t stream);
 uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S);
 
+/* Introspection of the fused featurisation's geometry stage (the parity tests of SURVEY 8 rows a5 / a6; not on the
+ * rendering path): the six multisample Gaussians of every sample exactly as ucn_march_features derives them
+ * (ref: render.py:94-152 cast_rays, then coord.py:60-116 track_linearize('contract') and the /2 of models.py:491-493).
+ * out [N, S, 6, UCN_CAST_PROBE_FLOATS] = {mean x, y, z, std, t  (cast_rays' returns),
+ *                                          contracted mean / 2 x, y, z, contracted std / 2, 1 / sqrt(8 std_c^2)}. */
+#define UCN_CAST_PROBE_FLOATS 10
+int ucn_cast_probe(const float *sdist, const float *near_, const float *far_, const float *origins,
+                   const float *directions, const float *basis, const float *radii, const float *flip /*|NULL*/,
+                   const float *spin /*|NULL*/, float std_scale, uint32_t N, uint32_t S, float *out, ucn_stream_t stream);
+/* coord.py:60-72 contract_mean_std through the kernels' own device function: means [B,3], stds [B] ->
+ * contracted mean / 2 [B,3], contracted std / 2 [B]. */
+int ucn_contract_probe(const float *means, const float *stds, uint32_t B, float *out_mean, float *out_std,
+                       ucn_stream_t stream);
+
 /* Same featurisation for caller-supplied Gaussians (ref: models.py:485-512 predict_density as
  * called by extract.py:56-57,96): means [B,G,3], stds [B,G]; warp=0 skips the contraction. */
 int ucn_points_features(const ucn_field_t *f, const float *means, const float *stds, uint32_t B,

@@ -1077,3 +1077,104 @@ def test_render_under_autocast_runs_the_mixed_precision_path():
     assert used2 == 0
     for k in full:
         assert torch.equal(off[k], full[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY 8 rows a5 / a6 seen DIRECTLY: the fused featurisation's own geometry stage -- the device
+# functions cast_sample / contract_to_unit that k_march_features, k_cast_cache and every backward kernel call -- written
+# out by ucn_cast_probe / ucn_contract_probe and compared with the reference's cast_rays / track_linearize outputs
+# (tests/golden/cast.npz, generated from the imported reference: G3 eval + train draws, G4 contraction).
+def _cast_probe(fx, rand_vec, flip=None, spin=None):
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    dev = "cuda"
+    N, S1 = fx["tdist"].shape
+    S = S1 - 1
+    f = lambda t: t.to(dev).float().contiguous()
+    # near = 0, far = 1: t = s * far + (1 - s) * near = s exactly, so the golden's metric fenceposts go in as sdist
+    sdist, near, far = f(fx["tdist"]), torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    o, d, cam, rad = f(fx["origins"]), f(fx["directions"]), f(fx["cam_dirs"]), f(fx["radii"]).reshape(-1)
+    basis = torch.empty(N, 6, device=dev)
+    _lib.check(lib.ucn_cone_basis(cam.data_ptr(), f(rand_vec).data_ptr(), N, basis.data_ptr(), _lib.stream()))
+    out = torch.full((N, S, 6, 10), float("nan"), device=dev)
+    fl, sp = (None, None) if flip is None else (f(flip), f(spin))
+    _lib.check(lib.ucn_cast_probe(sdist.data_ptr(), near.data_ptr(), far.data_ptr(), o.data_ptr(), d.data_ptr(), basis.data_ptr(),
+                                  rad.data_ptr(), _lib.ptr(fl), _lib.ptr(sp), 0.5, N, S, out.data_ptr(), _lib.stream()))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def test_cone_cast_and_contraction_vs_reference_golden():
+    fx = H.load("cast.npz")
+    for tag, kw in (("eval", {}), ("train", dict(flip=fx["train_flip"], spin=fx["train_spin"]))):
+        got = _cast_probe(fx, fx[f"{tag}_rand_vec"], **kw)
+        means, stds, t = fx[f"{tag}_means"], fx[f"{tag}_stds"], fx[f"{tag}_t"]
+        # every one of the 6 multisamples separately: a swapped / mirrored hexagon offset that keeps the mean of six fails here.
+        # |means| up to ~8: 2 ulp of 8 = 2e-6 (the eval pattern's cos / sin are host constants, the train draws go through
+        # v_sin / v_cos with ~1e-6 absolute error on an offset of size r t / sqrt(2) ~ 1e-3 t)
+        assert H.maxdiff(got[..., 0:3], means) <= 4e-6, tag
+        assert H.maxdiff(got[..., 4], t) <= 2e-6, tag
+        rel = ((got[..., 3] - stds).abs() / stds.abs().clamp_min(1e-30)).max()
+        assert float(rel) <= 4e-7, (tag, float(rel))                 # std = std_scale * r * t / sqrt(2): a multiply for a divide
+        # behind the contraction (coord.py:60-116) and the / 2 of models.py:491-493: against the oracle's restatement of
+        # track_linearize on the GOLDEN's means / stds (itself pinned to the reference by G4 below and test_oracle_golden)
+        cm, cs = rm.contract_points(means.reshape(-1, 3), stds.reshape(-1))
+        assert H.maxdiff(got[..., 5:8].reshape(-1, 3), cm / 2) <= 4e-6, tag
+        relc = ((got[..., 8].reshape(-1) - cs / 2).abs() / (cs / 2).abs().clamp_min(1e-30)).max()
+        assert float(relc) <= 2e-5, (tag, float(relc))               # exp2(log2(.) / 3) on the fast transcendental units
+        rs = 1.0 / torch.sqrt(8.0 * (cs.double() / 2) ** 2)
+        assert float(((got[..., 9].reshape(-1).double() - rs).abs() / rs).max()) <= 3e-5, tag
+    # G4: the reference's track_linearize on its own inputs (origin, points inside / on / far outside the unit ball)
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    m_in, s_in = fx["contract_in_mean"].cuda().contiguous(), fx["contract_in_std"].cuda().contiguous()
+    B = m_in.shape[0]
+    om, os_ = torch.empty(B, 3, device="cuda"), torch.empty(B, device="cuda")
+    _lib.check(lib.ucn_contract_probe(m_in.data_ptr(), s_in.data_ptr(), B, om.data_ptr(), os_.data_ptr(), _lib.stream()))
+    torch.cuda.synchronize()
+    assert H.maxdiff(om.cpu() * 2, fx["contract_mean"]) <= 5e-7       # |z| <= 2: 2 ulp
+    rel = ((os_.cpu() * 2 - fx["contract_std"]).abs() / fx["contract_std"].abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 2e-5, float(rel)
+    assert (om.cpu().norm(dim=-1) <= 1 + 1e-6).all()
+
+
+def test_forward_routes_on_training_mode_not_on_grad_mode():
+    """an eval-mode call OUTSIDE torch.no_grad() runs the fused inference march (no autograd graph,
+    no training activation buffers); the training graph is built only for model.train() with autograd enabled."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=9)
+    n = 64
+    rays = rm.synthetic_rays(n, seed=10)
+    noise = [rm.draw_level_noise(spec, n, l, False, torch.Generator().manual_seed(11 + l)) for l in range(2)]
+    model, _ = H.hip_model(spec, sd)
+    batch = H.pin_noise(H.to_dev(rays), noise)
+    assert torch.is_grad_enabled() and not model.training
+    a, _ = model(False, batch, 1.0, True)
+    assert not a[-1]["rgb"].requires_grad and "distance_median" in a[-1]
+    with torch.no_grad():
+        b, _ = model(False, batch, 1.0, True)
+    assert torch.equal(a[-1]["rgb"], b[-1]["rgb"])
+    model.train()
+    c, _ = model(False, batch, 1.0, True)
+    assert c[-1]["rgb"].requires_grad and "distance_median" in c[-1]
+    assert H.maxdiff(c[-1]["rgb"].detach().cpu().reshape(-1, 3), a[-1]["rgb"].cpu().reshape(-1, 3)) <= 2e-4
+    with torch.no_grad():
+        d, _ = model(False, batch, 1.0, True)
+    assert not d[-1]["rgb"].requires_grad
+    model.march_route = "inference"
+    e, _ = model(False, batch, 1.0, True)
+    assert not e[-1]["rgb"].requires_grad
+
+
+def test_non_positive_dilation_with_dilation_on_is_refused():
+    """use_dilation true (a knob > 0) but a computed dilation <= 0 (negative dilation_bias) must not silently
+    take ucn_resample's undilated branch -- both routes refuse."""
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=9)
+    rays = rm.synthetic_rays(8, seed=10)
+    model, _ = H.hip_model(spec, sd)
+    model.dilation_bias, model.dilation_multiplier = -1.0, 0.5
+    for train in (False, True):
+        model.train(train)
+        with pytest.raises(NotImplementedError, match="dilation"):
+            model(False, H.to_dev(rays), 1.0, False)

@@ -292,10 +292,27 @@ def test_data_loss_levels_and_lazy_stats():
                 per.append((lm * (sq if kind == "mse" else torch.sqrt(sq + 0.001 ** 2))).sum() / lm.sum())
             want = 0.3 * sum(per[:-1]) + 0.7 * per[-1]
             assert abs(float(loss) - float(want)) <= 1e-6
-            got = stats['mses']                                                      # host tensors pass through unfetched
+            got = stats['mses']                                                      # numpy on any device, like the reference's
+            assert isinstance(got, np.ndarray) and not stats.pending('mses')
             assert np.allclose(np.asarray(got), mses, atol=1e-6) and list(stats.keys()) == ['mses']
             stats['psnr'] = 1.0                                                      # train.py:226-227 adds keys
             assert set(dict(stats)) == {'mses', 'psnr'} and len(stats) == 2
+
+
+def test_hash_decay_on_host_tensors_is_the_reference_reduction():
+    """models.py:297-306: mean over (level, channel) of the per-level mean of embeddings^2 -- the host-tensor form of
+    train_graph.hash_decay (the device form is ucn_hash_decay, pinned by the G10 loss values)."""
+    from ucnerf_amd.internal import configs, models, train_graph
+    with models.bindings(NerfMLP=dict(grid_log2_hashmap_size=10), PropMLP=dict(grid_log2_hashmap_size=10)):
+        model = models.Model(config=configs.Config(), num_levels=2)
+    enc = model.nerf_mlp.encoder
+    enc.embeddings.data.normal_()
+    off = enc._offsets_np
+    per_level = torch.stack([(enc.embeddings[off[i]:off[i + 1]] ** 2).mean(dim=0) for i in range(len(off) - 1)])
+    got = train_graph.hash_decay(model.nerf_mlp)
+    assert abs(float(got) - float(per_level.mean())) <= 1e-6 * float(per_level.mean())
+    got.backward()
+    assert enc.embeddings.grad is not None and float(enc.embeddings.grad.abs().sum()) > 0
 
 
 def test_tile_order_is_a_permutation_of_the_frame_in_blocks():

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
@@ -65,6 +65,8 @@ SIGNATURES = {
     "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "ucn_march_features_backward_ws_floats": [ctypes.POINTER(UcnField), c_u32, c_u32],
+    "ucn_cast_probe": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_u32, c_vp, c_vp],
+    "ucn_contract_probe": [c_vp, c_vp, c_u32, c_vp, c_vp, c_vp],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],
     "ucn_field_dir_floats": [ctypes.POINTER(UcnField), c_u32],
     "ucn_field_dir_bias": [ctypes.POINTER(UcnField), c_vp, c_u32, c_vp, c_vp],

@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         tile_pair<2, 16, H2 + 72 * p>(ring, acc, din);
         if constexpr (p == 0) {
             if (a.graw && h == 0) {
-                // head: d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z)), from the saved density; rounded to bf16 like
+                // head: d softplus(z) / dz = sigmoid(z) = -expm1(-softplus(z)) (no cancellation in empty space), from the saved density; rounded to bf16 like
                 // the gradient the per-layer path hands to the bottleneck's GEMM
-                if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (1.0f - __expf(-a.density[sample])));
+                if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (-expm1f(-a.density[sample])));
                 else acc[0][0] += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
             }
         }

@@ -558,8 +558,10 @@ __device__ __forceinline__ void featurise_bwd(const UcnLevels &lvls, float *__re
 // coord.py:60-72 followed by the /2 of models.py:491-493; returns the [0,1] grid coordinate (exact op
 // sequence of the reference) and rs = 1/sqrt(8 std^2) of the contracted, halved std (fast math: it only
 // feeds the erf damping).
+// sd_out (ucn_cast_probe / ucn_contract_probe only): the contracted, halved std as the damping sees it.
 __device__ __forceinline__ void contract_to_unit(float x, float y, float z, float sd, bool warp, float &u0, float &u1,
-                                                 float &u2, float &rs, float &c0, float &c1, float &c2) {
+                                                 float &u2, float &rs, float &c0, float &c1, float &c2,
+                                                 float *sd_out = nullptr) {
     if (warp) {
         const float m = fmaxf((x * x + y * y) + z * z, UCN_EPS);
         if (!(m <= 1.0f)) {
@@ -577,6 +579,7 @@ __device__ __forceinline__ void contract_to_unit(float x, float y, float z, floa
     c0 = x; c1 = y; c2 = z;
     u0 = (x + 1.0f) / 2.0f; u1 = (y + 1.0f) / 2.0f; u2 = (z + 1.0f) / 2.0f;    // grid.py:162, bound = 1
     rs = __builtin_amdgcn_rsqf(8.0f * (sd * sd));
+    if (sd_out) *sd_out = sd;
 }
 
 // The six multisample Gaussians of sample (ray, s): render.py:108-152 then contract_to_unit.
@@ -584,7 +587,7 @@ __device__ __forceinline__ void contract_to_unit(float x, float y, float z, floa
 // 6x4 floats per sample).
 __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPattern &hx, float std_scale, uint32_t ray,
                                             uint32_t s, uint32_t S, float (&u)[6][3], float (&rs)[6],
-                                            float (&csum)[3], float &tsum) {
+                                            float (&csum)[3], float &tsum, float *probe = nullptr) {
     const float nr = in.near_[ray], fr = in.far_[ray];
     const float s0 = in.sdist[(size_t)ray * (S + 1) + s], s1 = in.sdist[(size_t)ray * (S + 1) + s + 1];
     const float t0 = s0 * fr + (1.0f - s0) * nr, t1 = s1 * fr + (1.0f - s1) * nr;
@@ -636,9 +639,40 @@ __device__ __forceinline__ void cast_sample(const RayInputs &in, const HexPatter
         const float wy = ((l0 * e1y + l1 * e2y) + t * dy) + oy;
         const float wz = ((l0 * e1z + l1 * e2z) + t * dz) + oz;
         float c0, c1, c2;
-        contract_to_unit(wx, wy, wz, sd_unit * t, true, u[j][0], u[j][1], u[j][2], rs[j], c0, c1, c2);
+        if (probe) {
+            // ucn_cast_probe: what render.cast_rays returns (means, stds, t) and what the grid sees behind the contraction
+            float *pr = probe + j * UCN_CAST_PROBE_FLOATS;
+            float sdc;
+            contract_to_unit(wx, wy, wz, sd_unit * t, true, u[j][0], u[j][1], u[j][2], rs[j], c0, c1, c2, &sdc);
+            pr[0] = wx; pr[1] = wy; pr[2] = wz; pr[3] = sd_unit * t; pr[4] = t;
+            pr[5] = c0; pr[6] = c1; pr[7] = c2; pr[8] = sdc; pr[9] = rs[j];
+        } else {
+            contract_to_unit(wx, wy, wz, sd_unit * t, true, u[j][0], u[j][1], u[j][2], rs[j], c0, c1, c2);
+        }
         csum[0] += c0; csum[1] += c1; csum[2] += c2; tsum += t;
     }
+}
+
+// Introspection for the parity tests: the product's own cast_sample / contract_to_unit, results
+// written out instead of consumed.
+__global__ __launch_bounds__(256) void k_cast_probe(RayInputs in, HexPattern hx, float std_scale, uint32_t N, uint32_t S,
+                                                    float *__restrict__ out) {
+    const size_t B = (size_t)N * S;
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    float u[6][3], rs[6], csum[3], tsum;
+    cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum, out + b * 6 * UCN_CAST_PROBE_FLOATS);
+}
+
+__global__ __launch_bounds__(256) void k_contract_probe(const float *__restrict__ means, const float *__restrict__ stds,
+                                                        uint32_t B, float *__restrict__ out_mean, float *__restrict__ out_std) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    float u0, u1, u2, rs, c0, c1, c2, sd;
+    contract_to_unit(means[b * 3], means[b * 3 + 1], means[b * 3 + 2], stds[b], true, u0, u1, u2, rs, c0, c1, c2, &sd);
+    out_mean[b * 3] = c0; out_mean[b * 3 + 1] = c1; out_mean[b * 3 + 2] = c2;
+    out_std[b] = sd;
 }
 
 // Levels handled by one thread: group g = levels [lo[g], lo[g+1]).  A thread re-derives the sample's six
@@ -1239,6 +1273,30 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     }
 #undef UCN_MF
     UCN_LAUNCH_CHECK("march_features");
+    return 0;
+}
+
+extern "C" int ucn_cast_probe(const float *sdist, const float *near_, const float *far_, const float *origins,
+                              const float *directions, const float *basis, const float *radii, const float *flip,
+                              const float *spin, float std_scale, uint32_t N, uint32_t S, float *out, ucn_stream_t stream) {
+    UCN_REQUIRE(N == 0 || (sdist && near_ && far_ && origins && directions && basis && radii && out),
+                "cast_probe: null pointer argument");
+    UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "cast_probe: flip and spin come together");
+    if (N == 0 || S == 0) return 0;
+    const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
+    hipLaunchKernelGGL(k_cast_probe, dim3(ucn_div_up((size_t)N * S, 256)), dim3(256), 0, (hipStream_t)stream, in, make_hex(),
+                       std_scale, N, S, out);
+    UCN_LAUNCH_CHECK("cast_probe");
+    return 0;
+}
+
+extern "C" int ucn_contract_probe(const float *means, const float *stds, uint32_t B, float *out_mean, float *out_std,
+                                  ucn_stream_t stream) {
+    UCN_REQUIRE(B == 0 || (means && stds && out_mean && out_std), "contract_probe: null pointer argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_contract_probe, dim3(ucn_div_up(B, 256)), dim3(256), 0, (hipStream_t)stream, means, stds, B, out_mean,
+                       out_std);
+    UCN_LAUNCH_CHECK("contract_probe");
     return 0;
 }
 

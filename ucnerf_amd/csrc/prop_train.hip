@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void k_prop_fwd(PropArgs a) {
     a.density[o] = z > 20.0f ? z : log1pf(__expf(z));                                 // F.softplus, beta 1, threshold 20
 }
 
-// d softplus(z) / dz = sigmoid(z) = 1 - exp(-softplus(z))
+// d softplus(z) / dz = sigmoid(z) = -expm1(-softplus(z)) (expm1: 1 - exp cancels for small densities)
 __device__ __forceinline__ float g_raw_of(const PropArgs &a, uint32_t m) {
-    return bf16r(a.g_density[m] * (1.0f - __expf(-a.density[m])), a.round_bf16);
+    return bf16r(a.g_density[m] * (-expm1f(-a.density[m])), a.round_bf16);
 }
 
 template <int FP>

@@ -10,9 +10,9 @@ composite) instead of ~300 eager ops, and nothing of size [N*S*6, .] is ever mat
 
 Supported configuration = the reference's shipped one (configs/waymo.gin): disable_density_normals,
 no GLO, no reflections / diffuse / IDE, raydist_fn=None.  Anything else raises at construction.
-With gradients disabled forward is the fused inference march; with gradients enabled it routes to
-internal/train_graph.py (same kernels for resampling and featurisation, HIP backward for the tables,
-autograd for the dense layers).  Without the HIP library or a GPU every entry point raises.
+In eval mode or with gradients disabled forward is the fused inference march; a model in training mode
+with gradients enabled routes to internal/train_graph.py (same kernels for resampling and featurisation, HIP
+backward for the tables and the dense layers' dgrad, autograd glue; `Model.march_route`).  Without the HIP library or a GPU every entry point raises.
 """
 import ctypes
 
@@ -357,6 +357,8 @@ class Model(nn.Module):
     #                                      model call in accelerator.autocast(), models.py:957) run in the reference's mixed
     #                                      precision: half tables in the gather, dense layers as bf16 MFMAs (the training
     #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
+    march_route: str = 'auto'            # which march Model.forward runs: 'auto' = the training graph iff self.training and
+    #                                      autograd is enabled, else the fused inference march; 'train' / 'inference' force it
     sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background
     #                                      weight 1 - sum(weights of the last level) reaches this value; the others get
     #                                      sky_rgbs = 0 (their pixel moves by < sky_min_background * |A_sky| through
@@ -389,12 +391,19 @@ class Model(nn.Module):
         stepfun.py:216): 'rand_vec' [..., num_levels*3] and 'march_noise' (list of per-level dicts
         with 'jitter', 'flip', 'spin').
 
-        With autograd enabled the differentiable graph of train_graph.py is built (HIP featurisation
-        forward/backward + library GEMMs); under torch.no_grad() the fully fused HIP march runs."""
-        if torch.is_grad_enabled():
+        Route (`Model.march_route`): 'auto' builds the differentiable graph of train_graph.py (HIP featurisation
+        forward / backward, MFMA train kernels, autograd glue) only for a model in TRAINING mode with autograd enabled
+        -- what train.py:160-167 does; a model in eval mode, or any call under torch.no_grad(), runs the fully fused
+        inference march, whose outputs carry no graph (an eval-mode call outside no_grad used to allocate the training
+        graph's activation buffers, 2.1 GB at 8192 x 128 samples).  'train' / 'inference' force one route."""
+        route = self.march_route
+        if route not in ('auto', 'train', 'inference'):
+            raise ValueError(f"Model.march_route={route!r}: expected 'auto', 'train' or 'inference'")
+        if route == 'train' or (route == 'auto' and self.training and torch.is_grad_enabled()):
             from . import train_graph
             return train_graph.march_train(self, rand, batch, train_frac, compute_extras, eval_camidx)
-        return self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
+        with torch.no_grad():
+            return self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
 
     def _mixed_level(self, mlp, is_prop, F_in):
         """Mixed-precision inference of one level (see `autocast_render`): None = the fp32-class path, else what the bf16
@@ -490,6 +499,10 @@ class Model(nn.Module):
             dilation = self.dilation_bias + self.dilation_multiplier * 1.0 / prod_num_samples
             if not (self.dilation_bias > 0 or self.dilation_multiplier > 0):
                 dilation = 0.0                                           # ref :167 use_dilation False: resample undilated
+            elif not dilation > 0:
+                # use_dilation is on but the value is not positive (a negative dilation_bias): the reference would run
+                # max_dilate_weights with it; ucn_resample reads dilation <= 0 as the UNdilated branch -- refuse
+                raise NotImplementedError(f"dilation {dilation} <= 0 with use_dilation on: outside the shipped configuration")
             prod_num_samples *= S
             # ---- random draws, in the reference's order (stepfun.py:216, render.py:123,124,140)
             jitter = flip = spin = None
@@ -797,9 +810,11 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     last = renderings[-1]
     keys = [k for k in last if not k.startswith('ray_')]
     # rendering['weights'] ([H, W, S] of the last level) is 27x the pixels' payload.  The reference gathers it with
-    # everything else (models.py:965-968) but none of its callers reads it unless return_weights=True (where
-    # models.py:977 overwrites it with the history's copy): at num_processes > 1 it is exchanged only on request.
-    if world > 1 and not return_weights and not getattr(config, 'render_gather_weights', False):
+    # everything else (models.py:965-968) and so does this function by default -- the returned key set never depends
+    # on the world size.  None of the reference's callers reads it unless return_weights=True (where models.py:977
+    # overwrites it with the history's copy): `config.render_gather_weights = False` is the explicit opt-out that drops
+    # the key at EVERY world size.
+    if not return_weights and not getattr(config, 'render_gather_weights', True):
         keys = [k for k in keys if k != 'weights']
     local = {k: last[k].reshape(hi - lo, -1) for k in keys}
     if return_weights:

@@ -691,7 +691,11 @@ def hash_decay(mlp):
     w[row] = 1 / (rows_of_its_level * L * C)."""
     enc = mlp.encoder
     if not enc.embeddings.is_cuda:
-        raise RuntimeError("hash_decay: embeddings must be a CUDA tensor")
+        # host tensors (CPU debugging of a loss): the same weighted sum as plain torch ops
+        off = torch.as_tensor(enc._offsets_np.astype('int64'))
+        rows = (off[1:] - off[:-1]).double()
+        w = torch.repeat_interleave(1.0 / (rows * rows.numel() * enc.embeddings.shape[1]), off[1:] - off[:-1])
+        return (enc.embeddings.double() ** 2 * w[:, None]).sum().to(enc.embeddings.dtype)
     return _HashDecay.apply(enc.embeddings, enc._offsets_np)
 
 
@@ -757,6 +761,9 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         dilation = model.dilation_bias + model.dilation_multiplier * 1.0 / prod
         if not (model.dilation_bias > 0 or model.dilation_multiplier > 0):
             dilation = 0.0                                               # ref models.py:167 use_dilation False
+        elif not dilation > 0:
+            raise NotImplementedError(f"dilation {dilation} <= 0 with use_dilation on (a negative dilation_bias): ucn_resample "
+                                      "takes dilation <= 0 as the reference's UNdilated branch")
         prod *= S
         jitter = flip = spin = None
         u_tab, max_jitter = _u_table(S, bool(rand), dev)

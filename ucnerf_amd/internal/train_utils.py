@@ -126,7 +126,7 @@ class LazyStats(collections.abc.MutableMapping):
 
     def __getitem__(self, k):
         v = self._d[k]
-        if isinstance(v, torch.Tensor) and v.is_cuda:
+        if isinstance(v, torch.Tensor):                # host tensors too: the reference's stats are numpy on any device
             v = self._d[k] = v.detach().float().cpu().numpy()
         return v
 
