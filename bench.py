@@ -250,6 +250,89 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192
                 rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
 
 
+def render_config(device, cameras, heads, autocast, n_cpu=8192):
+    """One more BASELINE config through exactly the headline's code path (render_image on a full frame resident in HBM,
+    one warm-up frame + one timed frame), with its own CPU-oracle check on n_cpu rays of that frame -- so that the
+    driver's bench line carries rays/s AND the RGB L-inf for configs[3] / configs[4], not only builder-run files."""
+    from ucnerf_amd.internal import models
+    model, cfg, sd = build_model(device, heads=heads)
+    cfg.render_ray_tile = 8
+    cfg.render_gather_weights = False
+    batch = frame_rays(device, cameras, virtual=heads)
+    n_rays = cameras * H_IMG * W_IMG
+    rand_vec = torch.randn(n_rays, 6, generator=torch.Generator().manual_seed(1))
+    batch["rand_vec"] = rand_vec.reshape(cameras * H_IMG, W_IMG, 6).to(device)
+    eval_camidx = torch.tensor([7]) if heads else 0
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            return models.render_image(model, Ranks(1, 0), batch, False, 1.0, cfg, verbose=False, eval_camidx=eval_camidx)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+    cpu = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=heads,
+                       eval_camidx=eval_camidx if heads else None, n_sample=n_cpu)
+    res = dict(rays=n_rays, cameras=cameras, ms_per_frame=dt * 1e3, rays_per_s=n_rays / dt, steps=1, warmup=1,
+               dtype=DTYPE_MIXED if autocast else DTYPE_F32_CLASS,
+               rgb_linf_gpu_vs_cpu=cpu["rgb_linf_gpu_vs_cpu"], psnr_gpu_vs_cpu=cpu["psnr_gpu_vs_cpu"],
+               cpu_rays_per_s=cpu["value"], cpu_cores=cpu["cores"], cpu_sample=cpu["sample"])
+    del model, batch, out, flat
+    torch.cuda.empty_cache()
+    return res
+
+
+DTYPE_F32_CLASS = ("f32-class (dense layers: f16 MFMA on hi/lo-split f32 operands, 2^-22 per product, f32 accumulate; "
+                   "grid, resampling, compositing f32)")
+DTYPE_MIXED = "bf16 dense layers + f16 tables, f32 interpolation / resampling / compositing (autocast)"
+
+
+def live_traffic(autocast):
+    """roofline.traffic measured in THIS run when rocprofv3 is on PATH: HBM-side bytes per NeRF-level featurisation
+    launch from two PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes as MI355X_MICROARCH.md prescribes; --kernel-trace
+    only) over a child process of this same script that renders a 160-row slice of the frame (30 launches of 10,240
+    rays: per-launch counters do not need the whole frame).  gfx950 corrections of the guide: both counters are in KiB
+    units; FETCH_SIZE = TCC_EA0_RDREQ x 64 B (a 128-byte request counts 64: true figure between 1x and 2x); Infinity-Cache
+    hits are counted.  Returns None when rocprofv3 is missing or a pass fails -- never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("UCN_BENCH_CHILD") or shutil.which("rocprofv3") is None:
+        return None
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="ucn_pmc_", dir="/tmp")
+    env = dict(os.environ, UCN_BENCH_CHILD="1", TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"] + (["--autocast"] if autocast else [])
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    half = "DF16_" in name or "_Float16" in name
+                    if (r["Counter_Name"] == ctr and "k_march_features" in name and "bwd" not in name and half == bool(autocast)
+                            and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 500000):     # NeRF-level launches (prop: 0.1 ms)
+                        tot += float(r["Counter_Value"]) * 1024.0
+                        n += 1
+            if n == 0:
+                return None
+            got[ctr] = (tot / n, n)
+    except Exception:                       # noqa: BLE001  (a profiler problem must not cost the bench line)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return dict(fetch_bytes_per_launch=got["FETCH_SIZE"][0], write_bytes_per_launch=got["WRITE_SIZE"][0],
+                launches_sampled=got["FETCH_SIZE"][1])
+
+
 def sky_layer_ms(batch_flat, device, n_rays=65536, steps=3):
     """SURVEY 8 row a12 / cfg5's extra term: the sky NeRF (120 samples x 562,688 MAC) on n_rays of the frame,
     random-init weights of the reference architecture (models.py:85-92).  Outside the timed region."""
@@ -288,15 +371,18 @@ def sky_layer_ms(batch_flat, device, n_rays=65536, steps=3):
                            kernel="k_sky_mlp_bf (bf16 MFMA, two workgroups per CU; under autocast) + k_sky_composite"))
 
 
-def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
+def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False):
     """BASELINE configs[2]: one training step on an 8192-ray batch -- Model.forward(rand=True) under bf16
     autocast, the losses of train.py:173-216 with waymo defaults, backward, nan_to_num on grads
-    (train_utils.py:335-344), Adam(lr 0.01, betas (0.9, 0.99), eps 1e-8; waymo.gin:6).  Median of `steps`."""
+    (train_utils.py:335-344), Adam(lr 0.01, betas (0.9, 0.99), eps 1e-8; waymo.gin:6).  Median of `steps`.
+    heads=True: the step the reference's shipped launch trains (scripts/train_waymo.sh:11-12: model_sky +
+    brightness_correction): sky NeRF forward / backward, per-ray colour-correction affines, sky-segment and
+    identity losses (train.py:181-185, sky_weight = idt_weight = 0.002) on top."""
     import types
     from ucnerf_amd.internal import train_utils as tu
     cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
                                 anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
-                                hash_decay_mults=0.1, disable_multiscale_loss=False)
+                                hash_decay_mults=0.1, disable_multiscale_loss=False, sky_weight=0.002, idt_weight=0.002)
     g = torch.Generator(device=device).manual_seed(2)
     opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)   # = create_optimizer (train_utils.py:347)
     model.train()
@@ -306,12 +392,17 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
         idx = torch.randint(0, n_total, (n_rays,), device=device, generator=g)
         batch = {k: v[idx][:, None, None, :] for k, v in batch_flat.items()}
         batch['rgb'] = torch.rand(n_rays, 1, 1, 3, device=device, generator=g)
+        if heads:
+            batch['cam_idx'] = torch.randint(0, 210, (n_rays, 1, 1, 1), device=device, generator=g)
+            batch['sky_segs'] = (torch.rand(n_rays, 1, 1, device=device, generator=g) > 0.7).float()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.autocast('cuda', dtype=torch.bfloat16):
+        with torch.autocast('cuda', dtype=torch.bfloat16):           # train.py:165-171: only the model call is autocast
             rend, hist = model(True, batch, 0.5, False, zero_glo=False)
-            loss = (tu.compute_data_loss(batch, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg)
-                    + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg))
+        loss = (tu.compute_data_loss(batch, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg)
+                + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg))
+        if heads:
+            loss = loss + cfg.sky_weight * tu.sky_loss(batch, rend) + cfg.idt_weight * tu.transformIdentityLoss(rend)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         tu.clip_gradients(model, None, cfg)                         # train_utils.py:335-344: nan_to_num on every gradient
@@ -321,6 +412,8 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12):
             times.append((time.perf_counter() - t0) * 1e3)
     model.eval()
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
+                heads=("sky NeRF (120 samples x 8 x 256 MLP) + per-ray colour-correction affines + sky-segment and identity "
+                       "losses (scripts/train_waymo.sh:11-12)" if heads else "none (BASELINE configs[2])"),
                 autocast="bf16 dense layers; forward gather from a half copy of the tables (the reference's autocast policy, "
                          "gridencoder/grid.py:41-44) with fp32 interpolation; fp32 table gradients, compositing and losses",
                 graph="HIP resample, fused featurisation fwd / bwd (LDS row blocks, no global atomics), NeRF-field dense forward and "
@@ -336,6 +429,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the post-timed configs[3] / configs[4] frames and the PMC traffic passes")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) the short run live_traffic() profiles")
     ap.add_argument("--ray-major", action="store_true", help="lanes = consecutive samples of a ray (default: neighbouring rays)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="0 fp32-input MFMA, 1 split-f16 MFMA (default: the package default)")
     ap.add_argument("--overlap", type=int, nargs="?", const=1, default=0,
@@ -369,6 +464,8 @@ def main():
     args = ap.parse_args()
     if args.cfg5 and args.cameras == 1:
         args.cameras = 5
+    if args.pmc_child:
+        args.steps, args.warmup, args.no_cpu_baseline, args.no_train, args.no_extras = 1, 0, True, True, True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -407,11 +504,18 @@ def main():
     model.sky_min_background = args.sky_skip
     model.autocast_bf16_features = not args.float_features
     cfg.render_ray_tile = args.ray_tile
+    cfg.render_gather_weights = False      # the exchanged tile = pixels + depth / acc / distance statistics (36 B per ray); the
+    #                                        [H, W, 128] per-sample weights (27x that) are computed but not part of the returned
+    #                                        frame at ANY world size (no caller of the reference reads them)
     batch = frame_rays(device, args.cameras, virtual=args.cfg5)
-    n_rays = args.cameras * H_IMG * W_IMG
+    rows = args.cameras * H_IMG
+    if args.pmc_child:                     # 160 rows = 30 passes of 10,240 rays: enough launches for per-launch counters
+        rows = 160
+        batch = {k: v[:rows].contiguous() for k, v in batch.items()}
+    n_rays = rows * W_IMG
     g = torch.Generator().manual_seed(1)
     rand_vec = torch.randn(n_rays, 6, generator=g)                  # pinned cone-basis draws (render.py:140)
-    batch["rand_vec"] = rand_vec.reshape(args.cameras * H_IMG, W_IMG, 6).to(device)
+    batch["rand_vec"] = rand_vec.reshape(rows, W_IMG, 6).to(device)
     acc = Ranks(world, rank)
     # configs[4]: one colour-correction latent per frame, as render.py:146-147 / eval.py:140-141 pass it
     eval_camidx = torch.tensor([7]) if args.cfg5 else 0
@@ -455,18 +559,32 @@ def main():
         if args.autocast:
             gather["bytes_note"] = "half tables: 2-byte entries, half the algorithmic gather bytes of the fp32 path"
         gather["frac"] = gather["achieved"] / gather["peak"]
-        # HBM-side bytes per launch: not measurable inside this process; taken from the committed PMC passes of this
-        # same command (profiles/r02c/traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE, separate passes); only quoted
-        # when this run's launches have the size those passes measured
-        try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02c",
-                                             "traffic_autocast.json" if args.autocast else "traffic.json")))
-            if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and (not args.autocast or model.autocast_bf16_features):
-                gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
-                gather["traffic_note"] = ("bytes per launch from the committed rocprofv3 PMC passes (not live): FETCH_SIZE + WRITE_SIZE; "
-                                          "below the algorithmic gather bytes because the 4 MiB level slices are re-read from L2")
-        except (OSError, KeyError, ValueError):
-            pass
+        # what actually binds the fine hashed levels: L1 / texture-address requests, not bytes
+        gather["l2_request_bound"] = dict(
+            lines_per_sample_level=36, fine_levels=10, l1_lines_per_clk_per_cu=1,
+            ceiling_ms_per_fine_level_per_8_4M_samples=0.49,
+            note="every corner pair of a hashed level is its own 64 B line: ~36 line requests per (sample, level); at one line per "
+                 "clock and CU that is 0.49 ms per fine level per 8.4 M samples -- the kernel's real bound; the `achieved` GB/s is "
+                 "served mostly from L2 (TCC hit ~91 %), so it may exceed what an HBM copy reaches (hbm_probe)")
+        # HBM-side bytes per launch: measured live by two rocprofv3 PMC passes over a child run of this script when
+        # rocprofv3 is on PATH (live_traffic); else from the committed PMC passes of this same command
+        live = None if (args.no_extras or world > 1) else live_traffic(args.autocast)
+        if live is not None:
+            gather["traffic"] = live["fetch_bytes_per_launch"] + live["write_bytes_per_launch"]
+            gather["traffic_note"] = (f"LIVE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a 160-row slice rendered by a child of "
+                                      f"this run, {live['launches_sampled']} NeRF-level launches; KiB units, FETCH_SIZE = TCC_EA0_RDREQ x 64 B on "
+                                      "gfx950 (true figure between 1x and 2x), Infinity-Cache hits included; below the algorithmic gather bytes "
+                                      "because the 4 MiB level slices are re-read from L2")
+            gather["traffic_detail"] = live
+        if live is None:
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", "r02c", "traffic_autocast.json" if args.autocast else "traffic.json")))
+                if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and (not args.autocast or model.autocast_bf16_features):
+                    gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+                    gather["traffic_note"] = ("NOT live (rocprofv3 unavailable or a pass failed): bytes per launch from the committed rocprofv3 PMC "
+                                              "passes of this command (profiles/r02c/traffic*.json): FETCH_SIZE + WRITE_SIZE")
+            except (OSError, KeyError, ValueError):
+                pass
         split = model.nerf_mlp.mlp_mode == 1
         # achieved = ALGORITHMIC flops of the reference formulation / kernel time; peak = the dense peak of
         # the MFMA instruction the kernel issues.  mode 0: exact fp32 products on v_mfma_f32_32x32x2_f32 (157.3 TF).
@@ -514,14 +632,14 @@ def main():
         res = {
             "metric": "rays/sec (fwd render), 1280x1920 @ 64+128 samples", "value": n_rays * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 dense layers + f16 tables, f32 compositing (autocast)" if args.autocast else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_MIXED if args.autocast else (DTYPE_F32_CLASS if split else "f32"), "data": "synthetic",
             "config": {"workload": workload, "rays_per_step": n_rays, "cameras": args.cameras,
                        "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
                                  else "random-init weights, tables U(-1,1) (BASELINE configs)"),
                        "compact_min_weight": args.compact, "ray_tile": args.ray_tile,
                        **({"sky_min_background": args.sky_skip,
                            "sky_rays_kept": getattr(model, "_sky_kept", None)} if args.cfg5 else {}),
-                       "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame",
+                       "parallelism": f"ray-tile shard x{world}, 1 packed all-gather per frame (36 B per ray: rgb, depth, acc, 4 distance statistics)",
                        "levels_per_block": model.levels_per_block, "chunk_rays": model.max_chunk_rays,
                        "mlp_mode": ("bf16 MFMA, composed colour layers (the training forward kernel without its stores)" if args.autocast else
                                     {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]),
@@ -544,6 +662,20 @@ def main():
             res["density_query"] = density_query_ms(model, device)
             res["tsdf_fusion"] = tsdf_fusion_ms(device)
             res["hbm_probe"] = hbm_probe(device)
+            if not args.no_extras:
+                del out, batch
+                torch.cuda.empty_cache()
+                # what the reference's shipped launch trains: sky NeRF + colour-correction head on (train_waymo.sh:11-12)
+                hmodel, _, _ = build_model(device, heads=True)
+                res["train_step_sky"] = train_step_ms(hmodel, flat, device, heads=True)
+                del hmodel, flat
+                torch.cuda.empty_cache()
+                # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
+                res["configs"] = {
+                    "configs[3] 5-camera frame, fp32-class": render_config(device, 5, heads=False, autocast=False),
+                    "configs[4] 5 cameras virtual poses + sky + colour head, fp32-class": render_config(device, 5, heads=True, autocast=False),
+                    "configs[4] same, mixed bf16/fp32 (autocast)": render_config(device, 5, heads=True, autocast=True),
+                }
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -26,6 +26,16 @@ from .extrinsic_optimizer import BrightnessCorrection
 from .sky import NeRF, render_rays  # noqa: F401  (names kept importable like upstream)
 
 
+try:                                    # the reference registers its classes with gin (models.py:30,688,693); so do these,
+    import gin                          # when gin is importable, so that configs/waymo.gin:10-20 binds to them unchanged
+except ImportError:                     # (without gin: `bindings()` below, or constructor keyword arguments)
+    gin = None
+
+
+def _configurable(cls):
+    return gin.configurable(cls) if gin is not None else cls
+
+
 def set_kwargs(self, kwargs):
     """Instance configuration = the class-level knobs AS THEY ARE NOW (gin bindings set class attributes,
     configs/waymo.gin:10-20; `bindings()` below restores them when its block ends) overridden by the constructor's
@@ -293,14 +303,17 @@ class MLP(nn.Module):
                 None if rgb is None else rgb.reshape(prefix + (3,)))
 
 
+@_configurable
 class NerfMLP(MLP):
     pass
 
 
+@_configurable
 class PropMLP(MLP):
     disable_rgb: bool = True      # waymo.gin:16
 
 
+@_configurable
 class Model(nn.Module):
     """ref models.py:31-365."""
 
