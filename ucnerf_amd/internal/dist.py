@@ -28,6 +28,40 @@ def _active(world):
     return world > 1 and dist.is_available() and dist.is_initialized()
 
 
+def _inplace_wanted():
+    import os
+    return os.environ.get("UCN_DIST_INPLACE", "0") == "1"
+
+
+def _exchange(out, mine, rank, rp):
+    """The frame's ONE collective: every rank's packed shard `mine` ([rp, width], a view of rows [rank * rp, (rank + 1) * rp)
+    of `out`) into `out` on every rank.  Default: out-of-place -- the send buffer is a copy of the shard (11 MB per rank for
+    a 1280 x 1920 frame on 8 ranks: microseconds), the form every backend and every torch / RCCL version implements.
+    UCN_DIST_INPLACE=1 hands RCCL the in-place form (send buffer = receive buffer + rank * count, no copy); its
+    precondition is asserted, and any backend error falls back to the out-of-place call."""
+    if _inplace_wanted() and dist.get_backend() == "nccl":
+        assert mine.is_contiguous() and out.is_contiguous()
+        assert mine.data_ptr() == out.data_ptr() + rank * rp * out.shape[1] * out.element_size(), "in-place all-gather: shard is not at its slot"
+        try:
+            dist.all_gather_into_tensor(out, mine)
+            return
+        except RuntimeError:
+            pass
+    dist.all_gather_into_tensor(out, mine.clone())
+
+
+def wrap_ddp(model, device_ids=None, **kw):
+    """DistributedDataParallel for the training step, sized for this model: the table gradients are two dense tensors of
+    57 + 15 MB (config B), so ONE 128 MB bucket (default 25 MB would cut the NeRF table's all-reduce off from the rest and
+    serialise three collectives) whose gradient views alias the bucket (gradient_as_bucket_view: no 76 MB copy per step).
+    What `accelerator.prepare` builds with torch defaults works too (tests/test_train_step.py), just slower; pass
+    `accelerate.DistributedDataParallelKwargs(bucket_cap_mb=128, gradient_as_bucket_view=True)` to the Accelerator for the same."""
+    from torch.nn.parallel import DistributedDataParallel
+    opts = dict(bucket_cap_mb=128, gradient_as_bucket_view=True, broadcast_buffers=False)
+    opts.update(kw)
+    return DistributedDataParallel(model, device_ids=device_ids, **opts)
+
+
 def all_gather_rows(local, num_rays, world, rank):
     """local: dict name -> [rows_local, width_k] float tensors (same keys / widths on every rank).
     Returns dict name -> [num_rays, width_k] on every rank."""
@@ -40,8 +74,7 @@ def all_gather_rows(local, num_rays, world, rank):
     rp = rows_per_rank(num_rays, world)
     any_t = local[keys[0]]
     n_loc = any_t.shape[0]
-    # one receive buffer per frame; this rank's rows are packed straight into its own slot of it (RCCL's in-place
-    # all-gather: send buffer = receive buffer + rank * count), so nothing frame-sized is allocated or zeroed twice
+    # one receive buffer per frame; this rank's rows are packed straight into its own slot of it
     out = torch.empty(world * rp, sum(widths), device=any_t.device, dtype=torch.float32)
     mine = out[rank * rp:(rank + 1) * rp]
     col = 0
@@ -50,8 +83,7 @@ def all_gather_rows(local, num_rays, world, rank):
         col += w
     if n_loc < rp:
         mine[n_loc:].zero_()                          # padding rows of the last shard(s), stripped below
-    send = mine if dist.get_backend() == "nccl" else mine.clone()   # gloo (CPU tests) wants a separate send buffer
-    dist.all_gather_into_tensor(out, send)            # one collective per frame
+    _exchange(out, mine, rank, rp)                    # one collective per frame
     out = out[:num_rays]
     res, col = {}, 0
     for k, w in zip(keys, widths):
