@@ -404,6 +404,35 @@ int ucn_sky_render(const ucn_sky_t *s, const float *origins, const float *direct
                    const float *t_vals, uint32_t N, float *workspace, float *sky_rgb_out /*[N,3]*/,
                    int mixed, ucn_stream_t stream);
 
+/* ---- training step of the sky layer (ref: models.py:326-337, :743-904 under train.py:165-171's bf16 autocast, and
+ * autograd's way back).  The host passes the two 9-tile layers COMPOSED, as differentiable fp32 matrices it forms itself:
+ *   m5 [256, 288] = [W5[:, 3:259] | W5[:, 0:3] | b5 | 0 (28)]
+ *   mv [128, 288] = [W_view[:, :256] W_feat | 0, 0, 0 | b_view + W_view[:, :256] b_feat | W_view[:, 256:283] | 0]
+ * (columns = the kernels' input tiles [h (256) | aux = (p (3), 1, embed(cam_dir) (27), 0)]).
+ * ucn_sky_train_fwd writes, per sample b = ray * 120 + s: raw [M, 4] (colour logits, sigma), the bf16 activation buffer
+ * act [M, ucn_sky_train_act_ld()] = 8 blocks [h_l (256) | aux (32)] then hv (128), and the ReLU masks; sky_rgb_out [N, 3].
+ * ucn_sky_train_bwd turns d loss / d sky_rgb [N, 3] into the bf16 pre-activation gradients grad [M, ucn_sky_train_grad_ld()]
+ * = d0 .. d7 (256 each) | dv (128) | g (32: d logits, d sigma, 0 ...).  Weight gradients are then GEMMs of column blocks:
+ *   d_l^T [h_{l-1} | aux] = [dW_l | . | db_l at column 259 | .],  d0^T aux = [dW0 (3) | db0],  [dv | g]^T [h7 | aux] -> d mv,
+ *   d w_alpha (row 131), g^T hv -> dW_rgb.   sky_far = 1.5 * far[0] is read on the device (no host sync). */
+typedef struct ucn_sky_train {
+    const float *w_pts[8], *b_pts[8]; /* pts_linears.{0..7}; entry 5 unused (m5) */
+    const float *m5, *mv;
+    const float *w_alpha, *b_alpha, *w_rgb, *b_rgb;
+    void *packed;                     /* DEVICE, ucn_sky_train_packed_bytes() bytes */
+} ucn_sky_train_t;
+uint64_t ucn_sky_train_packed_bytes(void);
+uint32_t ucn_sky_train_act_ld(void);
+uint32_t ucn_sky_train_grad_ld(void);
+int ucn_sky_train_pack(const ucn_sky_train_t *s, ucn_stream_t stream);
+int ucn_sky_train_fwd(const void *packed, const float *origins, const float *directions, const float *cam_dirs,
+                      const float *far_ /*[N]*/, const float *t_vals /*DEVICE [120]*/, uint32_t N,
+                      float *aux_ws /*[N,32]*/, float *raw /*[N*120,4]*/, void *act, void *mask /*[8][N*120][2] uint4*/,
+                      void *mask_v /*[N*120][2] uint2*/, float *sky_rgb_out /*[N,3]*/, ucn_stream_t stream);
+int ucn_sky_train_bwd(const void *packed, const float *g_sky_rgb /*[N,3]*/, const float *raw, const float *directions,
+                      const float *far_, const float *t_vals, uint32_t N, const void *mask, const void *mask_v,
+                      float *g_raw_ws /*[N*120,4]*/, void *grad, ucn_stream_t stream);
+
 /* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
 int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,
               uint32_t K, uint32_t Nout, int relu, float *y /*[M,Nout]*/, ucn_stream_t stream);

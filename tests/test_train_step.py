@@ -739,3 +739,56 @@ def test_fused_heads_on_ragged_shapes(monkeypatch, N, S):
     assert rel(g1, g0) <= 1e-1, rel(g1, g0)
     for n in w0:
         assert rel(w1[n], w0[n]) <= 1e-1, (n, rel(w1[n], w0[n]))
+
+
+@pytest.mark.gpu
+def test_fused_sky_training_kernels_match_the_eager_graph():
+    """SURVEY 8 rows a12 / a15, VERDICT r02 missing #2: the sky NeRF of a training step (models.py:326-337, :743-904) on
+    csrc/sky_train.hip -- forward (ucn_sky_train_fwd), compositing backward + dgrad (ucn_sky_train_bwd), one GEMM per layer for
+    the weight gradients -- against autograd through the eager torch formulation (train_graph.sky_forward, itself pinned to the
+    reference's step by the fp32 golden train_step_sky.npz): in fp32 as the truth, and under the same bf16 autocast as the
+    yardstick -- the fused path must be as close to the fp32 truth as the autocast eager graph is (x 1.5), output and
+    every parameter gradient."""
+    from ucnerf_amd.internal import train_graph as tg
+    from ucnerf_amd.internal.sky import NeRF
+    torch.manual_seed(5)
+    net = NeRF(D=8, d_in_view=3, W=256, multires_view=4, output_ch=4, skips=[4]).cuda()
+    with torch.no_grad():                       # biases away from zero, sigma head positive for about half the samples
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    n = 1024
+    g = torch.Generator().manual_seed(6)
+    rays = rm.synthetic_rays(n, seed=12)
+    o, d, cam = (rays[k].cuda() for k in ("origins", "directions", "cam_dirs"))
+    far = rays["far"].cuda()
+    cw = torch.randn(n, 3, generator=g).cuda()
+
+    def run(fn, autocast):
+        for p in net.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = fn(net, o, d, cam, far)
+        (out.float() * cw).sum().backward()
+        return out.detach().float(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters()}
+
+    truth, gt = run(tg.sky_forward, False)
+    eager, ge = run(tg.sky_forward, True)
+    assert tg._sky_fusable(net, o) is False            # outside autocast the eager form is taken
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert tg._sky_fusable(net, o)
+    fused, gf = run(tg.sky_forward_fused, True)
+    assert float(truth.abs().max()) > 1e-2
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-20))
+    e_out, f_out = rel(eager, truth), rel(fused, truth)
+    assert f_out <= max(1.5 * e_out, 2e-3), (f_out, e_out)
+    worst = 0.0
+    for k in gt:
+        assert gt[k].abs().max() > 0, k
+        e_k, f_k = rel(ge[k], gt[k]), rel(gf[k], gt[k])
+        cosf = lambda a: float(torch.nn.functional.cosine_similarity(a.reshape(-1), gt[k].reshape(-1), dim=0))
+        cos, cos_e = cosf(gf[k]), cosf(ge[k])
+        # deep in the trunk the bf16 graph itself drifts from fp32 (layer 0's bias: 0.17 relative in the eager autocast form)
+        assert f_k <= max(1.5 * e_k, 3e-2) and cos >= min(0.995, cos_e - 2e-3), (k, f_k, e_k, cos, cos_e)
+        worst = max(worst, f_k / max(e_k, 1e-3))
+    print(f"fused sky: output rel {f_out:.2e} (eager autocast {e_out:.2e}); worst gradient ratio fused / eager = {worst:.2f}")

@@ -1,10 +1,11 @@
-"""Run only bench.py's training step (for rocprofv3 --stats)."""
+"""Run only bench.py's training step (for rocprofv3 --stats).  `heads` as argv[1]: the sky + colour-head step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 dev = torch.device("cuda", 0)
-model, cfg, sd = bench.build_model(dev)
+heads = len(sys.argv) > 1 and sys.argv[1] == "heads"
+model, cfg, sd = bench.build_model(dev, heads=heads)
 batch = bench.frame_rays(dev)
 n = bench.H_IMG * bench.W_IMG
 flat = {k: v.reshape(n, -1) for k, v in batch.items()}
-print(bench.train_step_ms(model, flat, dev, steps=6))
+print(bench.train_step_ms(model, flat, dev, steps=6, heads=heads))

@@ -45,6 +45,14 @@ class UcnSky(ctypes.Structure):
     ]
 
 
+class UcnSkyTrain(ctypes.Structure):
+    """struct ucn_sky_train (include/ucnerf_march.h)."""
+    _fields_ = [
+        ("w_pts", c_vp * 8), ("b_pts", c_vp * 8), ("m5", c_vp), ("mv", c_vp),
+        ("w_alpha", c_vp), ("b_alpha", c_vp), ("w_rgb", c_vp), ("b_rgb", c_vp), ("packed", c_vp),
+    ]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ucnerf_march.h
 SIGNATURES = {
     "ucn_last_error": [],
@@ -101,13 +109,20 @@ SIGNATURES = {
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],
     "ucn_sky_render": [ctypes.POINTER(UcnSky), c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u32, c_vp, c_vp, c_i32, c_vp],
+    "ucn_sky_train_packed_bytes": [],
+    "ucn_sky_train_act_ld": [],
+    "ucn_sky_train_grad_ld": [],
+    "ucn_sky_train_pack": [ctypes.POINTER(UcnSkyTrain), c_vp],
+    "ucn_sky_train_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_sky_train_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_dense": [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp],
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64,
-             "ucn_prop_train_bwd_ws_floats": c_u64}
+             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
+             "ucn_sky_train_grad_ld": c_u32}
 
 _lib = None
 

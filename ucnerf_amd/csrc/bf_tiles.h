@@ -83,6 +83,68 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
 #endif
     });
 }
+// bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile)
+__device__ __forceinline__ uint32_t mask16(const f32x16 &a) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) m |= (a[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+// the masked (ReLU') half tile as a B operand
+__device__ __forceinline__ bf8 to_b_masked(const f32x16 &a, int s, uint32_t bits) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = ((bits >> (8 * s + e)) & 1u) ? a[8 * s + e] : 0.0f;
+    return pack8(v);
+}
+// store a tile of activations: lane (j, h) holds features 32t + (r&3) + 8(r>>2) + 4h of sample j -- four 8-byte pieces
+// {0-3, 8-11, 16-19, 24-27} + 4h.  The two lanes of a sample first trade pieces (v_permlane32_swap: lane j's pieces 2, 3
+// against lane j + 32's pieces 0, 1), after which lane (j, 0) holds features 0-15 and lane (j, 1) features 16-31 of the
+// tile contiguously: two 16-byte stores per lane instead of four 8-byte ones -- the kernels' 1.8 GB of activations leave
+// in half as many write transactions.  (Transposing whole rows through LDS: 1.13 -> 1.06 ms, not worth 66 KiB of LDS.)
+__device__ __forceinline__ void store_tile(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int t, int h, const bf8 (&b)[2],
+                                           bool live) {
+    const uint4 lo = __builtin_bit_cast(uint4, b[0]), hi = __builtin_bit_cast(uint4, b[1]);
+    // (a, b) -> a keeps lanes 0-31 and takes b's lanes 0-31 into its lanes 32-63; b takes a's lanes 32-63 into its lanes 0-31
+    const auto s0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(lo.z, hi.z, false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(lo.w, hi.w, false, false);
+    if (!live) return;
+    uint4 *p = reinterpret_cast<uint4 *>(dst + (size_t)sample * width + 32 * t + 16 * h);
+    p[0] = make_uint4(s0[0], s1[0], s0[1], s1[1]);      // h = 0: features 0-3 (own), 4-7 (partner);  h = 1: 16-19, 20-23
+    p[1] = make_uint4(s2[0], s3[0], s2[1], s3[1]);      // h = 0: features 8-11, 12-15;                h = 1: 24-27, 28-31
+}
+// ... and for the two tiles of an output PAIR (64 adjacent features = 128 bytes of the row): the two lanes of a sample
+// trade whole tiles' worth of pieces, lane (j, 0) ends up with all 32 features of tile tp, lane (j, 1) with those of tile
+// tp + 1 -- every lane writes one full 64-byte sector (4 x 16 bytes), same instruction count as two store_tile calls.
+__device__ __forceinline__ void store_pair(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h,
+                                           const bf8 (&t0)[2], const bf8 (&t1)[2], bool live) {
+    const uint4 a0 = __builtin_bit_cast(uint4, t0[0]), a1 = __builtin_bit_cast(uint4, t0[1]);   // tile tp:     pieces 0,1 | 2,3
+    const uint4 b0 = __builtin_bit_cast(uint4, t1[0]), b1 = __builtin_bit_cast(uint4, t1[1]);   // tile tp + 1
+    // swap(a, b): lanes 0-31 end with (a, partner's a) = both halves of tile tp's piece, lanes 32-63 with (own b's partner, b)
+    const auto p0x = __builtin_amdgcn_permlane32_swap(a0.x, b0.x, false, false), p0y = __builtin_amdgcn_permlane32_swap(a0.y, b0.y, false, false);
+    const auto p1x = __builtin_amdgcn_permlane32_swap(a0.z, b0.z, false, false), p1y = __builtin_amdgcn_permlane32_swap(a0.w, b0.w, false, false);
+    const auto p2x = __builtin_amdgcn_permlane32_swap(a1.x, b1.x, false, false), p2y = __builtin_amdgcn_permlane32_swap(a1.y, b1.y, false, false);
+    const auto p3x = __builtin_amdgcn_permlane32_swap(a1.z, b1.z, false, false), p3y = __builtin_amdgcn_permlane32_swap(a1.w, b1.w, false, false);
+    if (!live) return;
+    uint4 *p = reinterpret_cast<uint4 *>(dst + (size_t)sample * width + 32 * (tp + h));
+    p[0] = make_uint4(p0x[0], p0y[0], p0x[1], p0y[1]);      // features 0-3 (lane j's piece 0), 4-7 (lane j + 32's piece 0)
+    p[1] = make_uint4(p1x[0], p1y[0], p1x[1], p1y[1]);      // 8-11, 12-15
+    p[2] = make_uint4(p2x[0], p2y[0], p2x[1], p2y[1]);      // 16-19, 20-23
+    p[3] = make_uint4(p3x[0], p3y[0], p3x[1], p3y[1]);      // 24-27, 28-31
+}
+template <bool PAIR>
+__device__ __forceinline__ void store_two(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h, const bf8 (&t0)[2],
+                                          const bf8 (&t1)[2], bool live) {
+    if constexpr (PAIR) {
+        store_pair(dst, width, sample, tp, h, t0, t1, live);
+    } else {
+        store_tile(dst, width, sample, tp, h, t0, live);
+        store_tile(dst, width, sample, tp + 1, h, t1, live);
+    }
+}
+
 template <class RING>
 __device__ __forceinline__ void ring_start(RING &ring) {
     rstatic_for<RING::kLeadChunks>([&](auto c) { ring.template issue_chunk<c.value>(); });

@@ -27,22 +27,16 @@
 #include "wave_dpp.h"
 #include "mlp_ring.h"
 #include "pack_split.h"
+#include "sky_layout.h"
 
 namespace {
 
-constexpr int kSkySamples = 120;
 // ---- weight stream (1 KiB groups, pairs [otp][it][s][o2]): pts_linears 1..4, 5 (9 input tiles), 6, 7, views (9 tiles)
 constexpr int kGL1 = 0, kGL2 = 256, kGL3 = 512, kGL4 = 768, kGL5 = 1024, kGL6 = kGL5 + 288, kGL7 = kGL6 + 256;
 constexpr int kGV = kGL7 + 256, kGEnd = kGV + 144;                       // 1968
 constexpr uint64_t kSkyStreamGroups = (kGEnd + 4 + kChunkGroups - 1) / kChunkGroups * kChunkGroups;   // 1984
 constexpr int kSkyChunk = 16, kSkySlots = 8, kSkyLead = 6;        // ring geometry (128 KiB)
 using SkyRing = Ring<kGEnd, kSkyChunk, 4, kSkySlots, kSkyLead>;
-// ---- side table (floats), resident in LDS behind the ring
-constexpr int kSB = 0;            // 6 x 256: biases of pts_linears 1,2,3,4,6,7 as bias tiles [t][h][16]
-constexpr int kSL0 = 1536;        // 256 x {w0,w1,w2,b} of pts_linears.0, accumulator-slot order
-constexpr int kSAlpha = 2560;     // 256 alpha_linear weights (slot order), then b_alpha
-constexpr int kSRgb = 2820;       // 128 x {w_r,w_g,w_b,0} (slot order), then b_rgb[3]
-constexpr int kSideFloats = 3584; // 14 KiB
 // ---- ucn_sky_t::packed
 constexpr uint64_t kOffSide = kSkyStreamGroups * 256;
 constexpr uint64_t kOffM5 = kOffSide + kSideFloats;                       // [256][288] composed layer 5
@@ -62,7 +56,6 @@ constexpr uint64_t kOffBf = kOffMv + 128 * 288;
 constexpr uint64_t kSkyPackedFloats = kOffBf + (uint64_t)kBPadded * 256;
 
 constexpr int kLayerG[7] = {kGL1, kGL2, kGL3, kGL4, kGL5, kGL6, kGL7};
-constexpr int kBiasIdx[7] = {0, 1, 2, 3, -1, 4, 5};              // side-table bias block; layer 5's bias rides in the aux tile
 
 struct SkyArgs {
     const float *packed;
@@ -89,23 +82,6 @@ __device__ __forceinline__ void pair_chain(f32x16 &acc0, f32x16 &acc1, const HPa
         if constexpr (i / 2 < 8) dstep<G + 4 * i, kGEnd>(acc0, acc1, in[i / 2].hi[i % 2], in[i / 2].lo[i % 2], p, ring);
         else dstep<G + 4 * i, kGEnd>(acc0, acc1, aux.hi[i % 2], aux.lo[i % 2], p, ring);
     });
-}
-
-// alpha head (256 -> 1, VALU) on the fp32 ReLU output of layer 7, taken half a tile at a time while that half is
-// being split anyway: sig += sum_e relu(acc[8S+e]) * w[slot(TILE, 8S+e)]
-template <int TILE, int S>
-__device__ __forceinline__ void alpha_partial(const f32x16 &acc, const float *__restrict__ pa_h, float &sig) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) sig = fmaf(relu_bits(acc[8 * S + e]), pa_h[(TILE * 16 + 8 * S + e) * 2], sig);
-}
-
-__device__ __forceinline__ void side_bias_tile(const float *side, int off, int tile, f32x16 &acc, int h) {
-    const float4 *p = reinterpret_cast<const float4 *>(side + off + tile * 32 + h * 16);
-#pragma unroll
-    for (int r4 = 0; r4 < 4; r4++) {
-        const float4 v = p[r4];
-        acc[4 * r4 + 0] = v.x; acc[4 * r4 + 1] = v.y; acc[4 * r4 + 2] = v.z; acc[4 * r4 + 3] = v.w;
-    }
 }
 
 __global__ __launch_bounds__(256) void k_sky_mlp(SkyArgs a) {
@@ -385,25 +361,6 @@ __global__ __launch_bounds__(256) void k_pack_chain_bf(const float *__restrict__
     const uint32_t r = 8u * s + e;
     const uint32_t row = 32u * ot + (lane & 31u), col = 32u * it + (r & 3u) + 8u * (r >> 2) + 4u * (lane >> 5);
     dst[i] = (__bf16)(col < ld ? W[(size_t)row * ld + col] : 0.0f);
-}
-
-// per-ray auxiliary tile: [0, 0, 0, 1, embed(cam_dir) = x, sin(f x), cos(f x) for f in 1,2,4,8 (27), 0]
-__global__ __launch_bounds__(256) void k_sky_aux(const float *__restrict__ cam, uint32_t N, float *__restrict__ out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= N * 32u) return;
-    const uint32_t ray = i >> 5, k = i & 31u;
-    float v = 0.0f;
-    if (k == 3u) v = 1.0f;
-    else if (k >= 4u && k < 31u) {
-        const uint32_t e = k - 4u;
-        if (e < 3u) v = cam[ray * 3 + e];
-        else {
-            const uint32_t kk = e - 3u, a = kk % 3u, fn = (kk / 3u) & 1u, fi = kk / 6u;
-            const float x = cam[ray * 3 + a] * (float)(1u << fi);
-            v = fn ? cosf(x) : sinf(x);
-        }
-    }
-    out[i] = v;
 }
 
 // Composed fp32 matrices behind the two 9-tile layers, columns in input-tile order [h (256) | aux (32)]:

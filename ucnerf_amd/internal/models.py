@@ -370,6 +370,7 @@ class Model(nn.Module):
     #                                      model call in accelerator.autocast(), models.py:957) run in the reference's mixed
     #                                      precision: half tables in the gather, dense layers as bf16 MFMAs (the training
     #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
+    fused_sky_train: bool = True         # training under bf16 autocast runs the sky NeRF on csrc/sky_train.hip (False: eager torch)
     march_route: str = 'auto'            # which march Model.forward runs: 'auto' = the training graph iff self.training and
     #                                      autograd is enabled, else the fused inference march; 'train' / 'inference' force it
     sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background

@@ -725,6 +725,106 @@ def sky_forward(net, origins, directions, cam_dirs, far):
     return ((alpha * trans)[..., None] * rgb).sum(dim=-2)
 
 
+class _SkyFused(torch.autograd.Function):
+    """The sky NeRF of a training step under bf16 autocast (models.py:326-337, :743-904) as hand-written kernels
+    (csrc/sky_train.hip): forward = `ucn_sky_train_fwd` (one MFMA kernel through all ten layers + the compositing; every
+    hidden activation stored once as bf16, ReLU masks as bits), backward = `ucn_sky_train_bwd` (compositing backward +
+    one dgrad MFMA kernel on transposed fragments) and ONE split-K GEMM per layer for weight + bias gradient on the
+    288-column blocks [h_l | aux] of the activation buffer.  The two 9-tile layers arrive composed (M5, Mv: see
+    `sky_forward_fused`), so autograd carries their gradients on to pts_linears.5 / views_linears.0 / feature_linear."""
+
+    @staticmethod
+    def forward(ctx, o, d, cam, far, W0, b0, W1, b1, W2, b2, W3, b3, W4, b4, W6, b6, W7, b7, M5, Mv, wa, ba, Wr, br):
+        from .sky import _t_vals
+        lib = _lib.load()
+        dev, N = o.device, o.shape[0]
+        ws = [t.detach().float().contiguous() for t in (W0, b0, W1, b1, W2, b2, W3, b3, W4, b4, W6, b6, W7, b7, M5, Mv, wa, ba, Wr, br)]
+        W0_, b0_, W1_, b1_, W2_, b2_, W3_, b3_, W4_, b4_, W6_, b6_, W7_, b7_, M5_, Mv_, wa_, ba_, Wr_, br_ = ws
+        desc = _lib.UcnSkyTrain()
+        for i, (w, b) in {0: (W0_, b0_), 1: (W1_, b1_), 2: (W2_, b2_), 3: (W3_, b3_), 4: (W4_, b4_), 6: (W6_, b6_), 7: (W7_, b7_)}.items():
+            desc.w_pts[i], desc.b_pts[i] = w.data_ptr(), b.data_ptr()
+        desc.m5, desc.mv = M5_.data_ptr(), Mv_.data_ptr()
+        desc.w_alpha, desc.b_alpha, desc.w_rgb, desc.b_rgb = wa_.data_ptr(), ba_.data_ptr(), Wr_.data_ptr(), br_.data_ptr()
+        packed = torch.empty(lib.ucn_sky_train_packed_bytes(), dtype=torch.uint8, device=dev)
+        desc.packed = packed.data_ptr()
+        st = _lib.stream()
+        _lib.check(lib.ucn_sky_train_pack(ctypes.byref(desc), st))
+        M = N * 120
+        act_ld, g_ld = lib.ucn_sky_train_act_ld(), lib.ucn_sky_train_grad_ld()
+        o_, d_, cam_ = (t.detach().float().contiguous() for t in (o, d, cam))
+        far_ = far.detach().float().reshape(N).contiguous()
+        act = torch.empty(M, act_ld, device=dev, dtype=torch.bfloat16)
+        mask = torch.empty(8, M, 2, 4, device=dev, dtype=torch.int32)
+        mask_v = torch.empty(M, 2, 2, device=dev, dtype=torch.int32)
+        raw = torch.empty(M, 4, device=dev)
+        aux = torch.empty(N, 32, device=dev)
+        sky = torch.empty(N, 3, device=dev)
+        tv = _t_vals(dev)
+        _lib.check(lib.ucn_sky_train_fwd(packed.data_ptr(), o_.data_ptr(), d_.data_ptr(), cam_.data_ptr(), far_.data_ptr(), tv.data_ptr(),
+                                         N, aux.data_ptr(), raw.data_ptr(), act.data_ptr(), mask.data_ptr(), mask_v.data_ptr(),
+                                         sky.data_ptr(), st))
+        ctx.save_for_backward(packed, raw, d_, far_, act, mask, mask_v)
+        ctx.meta = (N, act_ld, g_ld, tuple(t.dtype for t in (W0, b0, M5, Mv, wa, ba, Wr, br)))
+        return sky
+
+    @staticmethod
+    def backward(ctx, g_sky):
+        from .sky import _t_vals
+        lib = _lib.load()
+        packed, raw, d_, far_, act, mask, mask_v = ctx.saved_tensors
+        N, act_ld, g_ld, dts = ctx.meta
+        dev, M = act.device, act.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            g = g_sky.reshape(N, 3).float().contiguous()
+            g_raw = torch.empty(M, 4, device=dev)
+            dl = torch.empty(M, g_ld, device=dev, dtype=torch.bfloat16)
+            _lib.check(lib.ucn_sky_train_bwd(packed.data_ptr(), g.data_ptr(), raw.data_ptr(), d_.data_ptr(), far_.data_ptr(),
+                                             _t_vals(dev).data_ptr(), N, mask.data_ptr(), mask_v.data_ptr(), g_raw.data_ptr(),
+                                             dl.data_ptr(), _lib.stream()))
+            BLK = 288
+            G0 = _wgrad_cols(dl[:, 0:256], act, 256, 288)                                  # d0^T aux: [256, 32] = [dW0 (3) | db0 | .]
+            out = {0: (G0[:, :3], G0[:, 3])}
+            for l in (1, 2, 3, 4, 5, 6, 7):
+                G = _wgrad_cols(dl[:, 256 * l:256 * (l + 1)], act, BLK * (l - 1), BLK * l)  # d_l^T [h_{l-1} | aux]: [256, 288]
+                out[l] = G if l == 5 else (G[:, :256], G[:, 259])
+            Gv = _wgrad_cols(dl[:, 2048:2048 + 160], act, BLK * 7, BLK * 8)               # [dv | g]^T [h7 | aux]: [160, 288]
+            gMv, gwa, gba = Gv[:128], Gv[131:132, :256], Gv[131, 259].reshape(1)
+            gbr = Gv[128:131, 259]
+            gWr = _wgrad_cols(dl[:, 2048 + 128:2048 + 160], act, BLK * 8, BLK * 8 + 128)[:3]   # g^T hv: [3, 128]
+        w_dt, b_dt, m5_dt, mv_dt, wa_dt, ba_dt, wr_dt, br_dt = dts
+        res = [None, None, None, None, out[0][0].to(w_dt), out[0][1].to(b_dt)]
+        for l in (1, 2, 3, 4, 6, 7):
+            res += [out[l][0].to(w_dt), out[l][1].to(b_dt)]
+        res += [out[5].to(m5_dt), gMv.to(mv_dt), gwa.to(wa_dt), gba.to(ba_dt), gWr.to(wr_dt), gbr.to(br_dt)]
+        return tuple(res)
+
+
+def sky_forward_fused(net, origins, directions, cam_dirs, far):
+    """sky_forward through the hand-written training kernels.  The two layers with 9 input tiles are handed over composed,
+    formed HERE with differentiable torch ops (fp32) so that autograd maps their gradients back to the parameters:
+        M5 = [W5[:, 3:] | W5[:, :3] | b5 | 0]                  (the skip layer, its input [pts, h] reordered to [h | pts, 1])
+        Mv = [Wv[:, :256] Wf | 0 | bv + Wv[:, :256] bf | Wv[:, 256:] | 0]   (feature_linear has no activation behind it)"""
+    P = net.pts_linears
+    with torch.autocast("cuda", enabled=False):
+        W5, b5 = P[5].weight.float(), P[5].bias.float()
+        Wv, bv = net.views_linears[0].weight.float(), net.views_linears[0].bias.float()
+        Wf, bf = net.feature_linear.weight.float(), net.feature_linear.bias.float()
+        z = W5.new_zeros
+        M5 = torch.cat([W5[:, 3:], W5[:, :3], b5[:, None], z(256, 28)], dim=1)
+        Wvf = Wv[:, :256]
+        Mv = torch.cat([Wvf @ Wf, z(128, 3), (bv + Wvf @ bf)[:, None], Wv[:, 256:], z(128, 1)], dim=1)
+        args = [origins, directions, cam_dirs, far, P[0].weight, P[0].bias]
+        for l in (1, 2, 3, 4, 6, 7):
+            args += [P[l].weight, P[l].bias]
+        args += [M5, Mv, net.alpha_linear.weight, net.alpha_linear.bias, net.rgb_linear.weight, net.rgb_linear.bias]
+        return _SkyFused.apply(*args)
+
+
+def _sky_fusable(net, origins):
+    return (origins.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and origins.shape[0] * 120 % 8192 == 0 and all(p.dtype == torch.float32 for p in net.parameters()))
+
+
 def brightness_forward(bc, idx, which="latent_code"):
     x = getattr(bc, which)[idx.reshape(-1).long()]
     for lin in bc.brightness_MLP.pts_linears:
@@ -827,7 +927,8 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
             r['ray_rgbs'] = final[:, None, :].expand(r['ray_rgbs'].shape)
     with_sky = getattr(cfg, 'model_sky', False)
     if with_sky:
-        sky = sky_forward(model.skynerf, o, d, cam, far)
+        # under bf16 autocast (what train.py:165 runs): the hand-written sky kernels; else the eager fp32 form (the G10 parity path)
+        sky = (sky_forward_fused if (model.fused_sky_train and _sky_fusable(model.skynerf, o)) else sky_forward)(model.skynerf, o, d, cam, far)
         for r in renderings:
             r['sky_rgbs'] = sky
     if getattr(cfg, 'brightness_correction', False):
@@ -835,11 +936,15 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         A = brightness_forward(model.brightness_corr, idx)
         A_sky = brightness_forward(model.brightness_corr, idx, 'sky_latent_code') if with_sky else None
         last_w = renderings[-1]['weights'].reshape(N, -1)
+        # models.py:350-354's per-ray 3 x 3 products as broadcast multiplies + a 3-term sum: torch.bmm with a batch of 8192
+        # tiny matrices costs 1.3 ms of HOST time per call on this stack (12 calls per step forward + backward: the GPU idled
+        # 45 ms of a 66 ms step, tools/train_cpu.py)
+        affine = lambda M, v: (M[:, :3, :3] * v.reshape(N, 1, 3)).sum(dim=-1, keepdim=True) + M[:, :3, 3:]
         for r in renderings:
-            rgb = torch.bmm(A[:, :3, :3], r['rgb'].reshape(N, 3, 1)) + A[:, :3, 3:]
+            rgb = affine(A, r['rgb'])
             if with_sky:
                 opac = 1 - last_w.sum(dim=-1, keepdim=True)
-                rgb = rgb + opac[..., None] * (torch.bmm(A_sky[:, :3, :3], r['sky_rgbs'].reshape(N, 3, 1)) + A_sky[:, :3, 3:])
+                rgb = rgb + opac[..., None] * affine(A_sky, r['sky_rgbs'])
             r['rgb'] = rgb.reshape(N, 1, 1, 3) if eval_camidx is None else rgb.reshape(N, 3)
             r['affine_trans'] = A
             if with_sky:
