@@ -410,9 +410,9 @@ int ucn_sky_render(const ucn_sky_t *s, const float *origins, const float *direct
  *   mv [128, 288] = [W_view[:, :256] W_feat | 0, 0, 0 | b_view + W_view[:, :256] b_feat | W_view[:, 256:283] | 0]
  * (columns = the kernels' input tiles [h (256) | aux = (p (3), 1, embed(cam_dir) (27), 0)]).
  * ucn_sky_train_fwd writes, per sample b = ray * 120 + s: raw [M, 4] (colour logits, sigma), the bf16 activation buffer
- * act [M, ucn_sky_train_act_ld()] = 8 blocks [h_l (256) | aux (32)] then hv (128), and the ReLU masks; sky_rgb_out [N, 3].
+ * act [M, ucn_sky_train_act_ld()] = h_0 .. h_7 (256 each) | aux (32) | hv (128), and the ReLU masks; sky_rgb_out [N, 3].
  * ucn_sky_train_bwd turns d loss / d sky_rgb [N, 3] into the bf16 pre-activation gradients grad [M, ucn_sky_train_grad_ld()]
- * = d0 .. d7 (256 each) | dv (128) | g (32: d logits, d sigma, 0 ...).  Weight gradients are then GEMMs of column blocks:
+ * = d0 .. d7 (256 each) | dv (128) | g (32: d logits, d sigma, 0 ...).  Weight gradients are then ucn_wgrad_bf16 passes:
  *   d_l^T [h_{l-1} | aux] = [dW_l | . | db_l at column 259 | .],  d0^T aux = [dW0 (3) | db0],  [dv | g]^T [h7 | aux] -> d mv,
  *   d w_alpha (row 131), g^T hv -> dW_rgb.   sky_far = 1.5 * far[0] is read on the device (no host sync). */
 typedef struct ucn_sky_train {
@@ -432,6 +432,15 @@ int ucn_sky_train_fwd(const void *packed, const float *origins, const float *dir
 int ucn_sky_train_bwd(const void *packed, const float *g_sky_rgb /*[N,3]*/, const float *raw, const float *directions,
                       const float *far_, const float *t_vals, uint32_t N, const void *mask, const void *mask_v,
                       float *g_raw_ws /*[N*120,4]*/, void *grad, ucn_stream_t stream);
+
+/* Weight gradient of a dense layer over a training batch (ref: autograd through nn.Linear, models.py:438-483, :743-820):
+ *   out[KA][kb1 + kb2] (fp32) = A^T [B1 | B2],  A = pre-activation gradients [M, lda] bf16 (KA columns from A),
+ *   B1 / B2 = column blocks of the layer's inputs [M, ldb*] bf16 (B2 optional: e.g. the tile holding the constant 1 whose
+ *   column is the bias gradient).  KA, kb1, kb2 multiples of 32, KA <= 256, kb1 + kb2 <= 288; row strides multiples of 8.
+ * Split-K over the samples with a fixed-order reduction (deterministic); workspace: ucn_wgrad_ws_floats(KA, KB, M) floats. */
+uint64_t ucn_wgrad_ws_floats(uint32_t KA, uint32_t KB, uint64_t M);
+int ucn_wgrad_bf16(const void *A, uint32_t lda, uint32_t KA, const void *B1, uint32_t ldb1, uint32_t kb1, const void *B2,
+                   uint32_t ldb2, uint32_t kb2, uint64_t M, float *workspace, float *out, ucn_stream_t stream);
 
 /* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
 int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,

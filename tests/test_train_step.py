@@ -792,3 +792,34 @@ def test_fused_sky_training_kernels_match_the_eager_graph():
         assert f_k <= max(1.5 * e_k, 3e-2) and cos >= min(0.995, cos_e - 2e-3), (k, f_k, e_k, cos, cos_e)
         worst = max(worst, f_k / max(e_k, 1e-3))
     print(f"fused sky: output rel {f_out:.2e} (eager autocast {e_out:.2e}); worst gradient ratio fused / eager = {worst:.2f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,KA,kb1,kb2", [(5000, 96, 256, 32), (37, 256, 32, 0), (70000, 256, 256, 32), (4096, 160, 128, 0), (0, 32, 32, 0)])
+def test_wgrad_kernel_against_a_float_matmul(M, KA, kb1, kb2):
+    """ucn_wgrad_bf16 (csrc/wgrad.hip: LDS transpose reads + bf16 MFMA, split-K with a fixed-order reduction) against
+    A^T [B1 | B2] in float64 on the same bf16 values: ragged row counts, column blocks out of wider strided buffers, one and
+    two B blocks, fewer A columns than waves; deterministic run to run."""
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + KA)
+    lda, ldb1, ldb2 = KA + 40, kb1 + 64, 64
+    A = torch.randn(max(M, 1), lda, generator=g).to(torch.bfloat16).cuda()
+    B1 = torch.randn(max(M, 1), ldb1, generator=g).to(torch.bfloat16).cuda()
+    B2 = torch.randn(max(M, 1), ldb2, generator=g).to(torch.bfloat16).cuda()
+    a0, b0, c0 = 8, 32, 16                                    # column offsets inside the wider buffers (16-byte aligned)
+    Av, B1v, B2v = A[:, a0:a0 + KA], B1[:, b0:b0 + kb1], B2[:, c0:c0 + kb2]
+    KB = kb1 + kb2
+    ws = torch.empty(lib.ucn_wgrad_ws_floats(KA, KB, M), device="cuda")
+    outs = []
+    for _ in range(2):
+        out = torch.full((KA, KB), float("nan"), device="cuda")
+        _lib.check(lib.ucn_wgrad_bf16(Av.data_ptr(), lda, KA, B1v.data_ptr(), ldb1, kb1, B2v.data_ptr() if kb2 else None, ldb2, kb2, M,
+                                      ws.data_ptr(), out.data_ptr(), _lib.stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    Bc = torch.cat([B1v, B2v], dim=1) if kb2 else B1v
+    want = (Av[:M].double().t() @ Bc[:M].double()).cpu() if M else torch.zeros(KA, KB, dtype=torch.float64)
+    err = float((outs[0].double() - want).abs().max())
+    assert err <= 2e-5 * max(1.0, float(want.abs().max())) * max(1.0, M ** 0.5 / 16), (err, float(want.abs().max()))

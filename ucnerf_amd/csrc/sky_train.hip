@@ -10,16 +10,16 @@
 //   k_sky_train_fwd   the rendering kernel's bf16 pair-chain sequence (sky.hip k_sky_mlp_bf) in the training kernels'
 //                     shape (4 waves, 64 KiB LDS-DMA ring + 14 KiB side table, two workgroups per CU); a wave keeps its
 //                     32 samples in registers through all ten layers; every hidden activation is written ONCE, as the
-//                     bf16 B operand the next layer consumed, into one [M, 2432] buffer whose 288-column blocks
-//                     [h_l (256) | aux (32) = (p, 1, embed(cam_dir), 0)] are the reference's concatenated layer inputs
-//                     plus the constant-1 column: every layer's weight + bias gradient is then ONE GEMM on a block.
-//                     ReLU masks as 16 bits per tile.
+//                     bf16 B operand the next layer consumed, into one [M, 2240] buffer h_0 .. h_7 | aux | hv, where
+//                     aux (32) = (p, 1, embed(cam_dir), 0) holds the rest of the reference's concatenated layer inputs
+//                     plus the constant-1 column: every layer's weight + bias gradient is then ONE pass of
+//                     ucn_wgrad_bf16 (wgrad.hip) over [h_{l-1} | aux].  ReLU masks as 16 bits per tile.
 //   k_sky_composite_bwd   d rgb_map / d (colour logits, sigma) per sample (suffix-sum form of the transmittance gradient)
 //   k_sky_train_bwd   the chain backwards on transposed fragments: dv = (W_rgb^T g) m_v, d7 = ([Mv_h | w_alpha]^T [dv | g]) m_7,
 //                     d_l = (W_{l+1}^T d_{l+1}) m_l; pre-activation gradients stored once, bf16, [M, 2240].
 // feature_linear (no activation behind it) stays composed into the views layer as in rendering: the host forms
 // Mv = W_view[:, :256] W_feat with differentiable torch ops, so autograd carries d Mv back to both factors -- the
-// `feature` activation is neither computed nor stored.  Weight gradients: split-K GEMMs over the two buffers (host).
+// `feature` activation is neither computed nor stored.  Weight gradients: csrc/wgrad.hip over the two buffers.
 #include "pack_split.h"
 #include "sky_layout.h"
 
@@ -33,8 +33,8 @@ constexpr int kFL[7] = {0, 128, 256, 384, 512, 656, 784};
 constexpr int kFV = 912;
 // backward stream: W_rgb^T (2 pairs x 1 tile) | [Mv_h | w_alpha]^T (4 pairs x 5 tiles) | W7^T, W6^T, M5_h^T, W4^T .. W1^T
 constexpr int kGV = 0, kG7 = 8, kGL = 88;
-// activation buffer (bf16 [M, kActLd]): blocks [h_l | aux] for l = 0..7, then hv (128)
-constexpr int kActBlock = 288, kActHv = 8 * kActBlock, kActLd = kActHv + 128;          // 2432 columns = 38 x 128 bytes
+// activation buffer (bf16 [M, kActLd]): h_0 .. h_7 (256 each) | aux (32) | hv (128) | pad
+constexpr int kActBlock = 256, kActAux = 8 * kActBlock, kActHv = kActAux + 32, kActLd = 2240;    // rows of 35 x 128 bytes
 // gradient buffer (bf16 [M, kDlLd]): d0 .. d7 (256 each) | dv (128) | g (32: d logits r, g, b, d sigma, 0...) | pad
 constexpr int kDlV = 2048, kDlG = kDlV + 128, kDlLd = 2240;                              // 35 x 128 bytes
 // packed buffer (bytes): forward stream | backward stream | side table | scratch matrices of the two composite stages
@@ -93,10 +93,9 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
         XA[8][1] = XB[8][1] = to_b(av, 1, false);
     }
     uint16_t *row = a.act;
-    // the auxiliary tile behind each of the eight hidden blocks: the skip connection's point, the view encoding and the
-    // constant 1 are then columns of every layer's weight-gradient GEMM operand
-#pragma unroll
-    for (int l = 0; l < 8; l++) store_tile(row + l * kActBlock + 256, kActLd, b, 0, h, XA[8], live);
+    // the auxiliary tile, once per sample: the skip connection's point, the view encoding and the constant 1 are the second
+    // column block of every layer's weight-gradient GEMM (ucn_wgrad_bf16 takes B as two blocks)
+    store_tile(row + kActAux, kActLd, b, 0, h, XA[8], live);
 
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)

@@ -405,6 +405,29 @@ def _head_gather_index(F_in, NB, NW, E, total, device, dir_in_stream=False):
     return hit
 
 
+_WGRAD_WS = {}
+
+
+def wgrad(A, B1, B2=None):
+    """A^T [B1 | B2] as float32 [A columns, B columns] by the hand-written kernel (csrc/wgrad.hip: LDS transpose reads + bf16
+    MFMA, every operand element read once, fixed-order split-K): A, B1, B2 are column-slice views [M, k] of bf16 buffers
+    (k a multiple of 32; A <= 256 columns, B1 + B2 <= 288)."""
+    lib = _lib.load()
+    M, KA = A.shape
+    kb1, kb2 = B1.shape[1], (0 if B2 is None else B2.shape[1])
+    for t in (A, B1) + ((B2,) if B2 is not None else ()):
+        assert t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.shape[0] == M and t.shape[1] % 32 == 0, (t.dtype, t.stride(), t.shape)
+    n = lib.ucn_wgrad_ws_floats(KA, kb1 + kb2, M)
+    key = str(A.device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _WGRAD_WS[key] = torch.empty(max(n, 256 * 256 * 288), device=A.device)
+    out = torch.empty(KA, kb1 + kb2, device=A.device)
+    _lib.check(lib.ucn_wgrad_bf16(A.data_ptr(), A.stride(0), KA, B1.data_ptr(), B1.stride(0), kb1, _lib.ptr(B2),
+                                  0 if B2 is None else B2.stride(0), kb2, M, ws.data_ptr(), out.data_ptr(), _lib.stream()))
+    return out
+
+
 def _wgrad_cols(gy, act, lo, hi):
     """gy^T @ act[:, lo:hi] as float32 [gy columns, hi - lo]: split-K batched GEMM over 8192-row chunks on a strided
     column view of the activation buffer (no copy; see _TallLinear for why the reduction is cut)."""
@@ -506,10 +529,17 @@ class _FusedHeads(torch.autograd.Function):
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
             # 302 + 119 us, tools/wgrad_bench.py); the 288-column GEMM of layer 0 is fine (255 us)
-            G1a, G1b = _wgrad_cols(d1, act, _ACT_H1, _ACT_AUX), _wgrad_cols(d1, act, _ACT_AUX, _ACT_AUX + 32)
-            G1 = torch.cat([G1a, G1b], dim=1)
-            G0 = _wgrad_cols(d0, act, _ACT_X, _ACT_AUX + 32)                  # [NW, NB + 32]
-            Gd1 = _wgrad_cols(gx, act, _ACT_AUX, _ACT_FB)                     # [NB, 32 + 64]
+            if NW == 256 and NB == 256:
+                # hand-written weight-gradient kernel (csrc/wgrad.hip), each pass reads its operands once:
+                aux = act[:, _ACT_AUX:_ACT_AUX + 32]
+                G1 = torch.cat([wgrad(d1, act[:, _ACT_H1:_ACT_H1 + NW]), wgrad(d1, act[:, _ACT_X:_ACT_X + NB], aux)], dim=1)   # [NW, NW + NB + 32]
+                G0 = wgrad(d0, act[:, _ACT_X:_ACT_X + NB], aux)                # [NW, NB + 32]
+                Gd1 = wgrad(gx, act[:, _ACT_AUX:_ACT_FB])                     # [NB, 32 + 64]
+            else:
+                G1a, G1b = _wgrad_cols(d1, act, _ACT_H1, _ACT_AUX), _wgrad_cols(d1, act, _ACT_AUX, _ACT_AUX + 32)
+                G1 = torch.cat([G1a, G1b], dim=1)
+                G0 = _wgrad_cols(d0, act, _ACT_X, _ACT_AUX + 32)                  # [NW, NB + 32]
+                Gd1 = _wgrad_cols(gx, act, _ACT_AUX, _ACT_FB)                     # [NB, 32 + 64]
             Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)                  # [4, NW]
             gW1, gb1 = G1[:, :NW + NB + E], G1[:, NW + NB + E]
             gW0, gb0 = G0[:, :NB + E], G0[:, NB + E]
@@ -729,8 +759,8 @@ class _SkyFused(torch.autograd.Function):
     """The sky NeRF of a training step under bf16 autocast (models.py:326-337, :743-904) as hand-written kernels
     (csrc/sky_train.hip): forward = `ucn_sky_train_fwd` (one MFMA kernel through all ten layers + the compositing; every
     hidden activation stored once as bf16, ReLU masks as bits), backward = `ucn_sky_train_bwd` (compositing backward +
-    one dgrad MFMA kernel on transposed fragments) and ONE split-K GEMM per layer for weight + bias gradient on the
-    288-column blocks [h_l | aux] of the activation buffer.  The two 9-tile layers arrive composed (M5, Mv: see
+    one dgrad MFMA kernel on transposed fragments) and ONE pass of the weight-gradient kernel (`wgrad`, csrc/wgrad.hip) per layer
+    for weight + bias gradient over [h_{l-1} | aux] of the activation buffer.  The two 9-tile layers arrive composed (M5, Mv: see
     `sky_forward_fused`), so autograd carries their gradients on to pts_linears.5 / views_linears.0 / feature_linear."""
 
     @staticmethod
@@ -781,16 +811,17 @@ class _SkyFused(torch.autograd.Function):
             _lib.check(lib.ucn_sky_train_bwd(packed.data_ptr(), g.data_ptr(), raw.data_ptr(), d_.data_ptr(), far_.data_ptr(),
                                              _t_vals(dev).data_ptr(), N, mask.data_ptr(), mask_v.data_ptr(), g_raw.data_ptr(),
                                              dl.data_ptr(), _lib.stream()))
-            BLK = 288
-            G0 = _wgrad_cols(dl[:, 0:256], act, 256, 288)                                  # d0^T aux: [256, 32] = [dW0 (3) | db0 | .]
+            AUX, HV = 2048, 2080
+            aux = act[:, AUX:AUX + 32]
+            G0 = wgrad(dl[:, 0:256], aux)                                                   # d0^T aux: [256, 32] = [dW0 (3) | db0 | .]
             out = {0: (G0[:, :3], G0[:, 3])}
             for l in (1, 2, 3, 4, 5, 6, 7):
-                G = _wgrad_cols(dl[:, 256 * l:256 * (l + 1)], act, BLK * (l - 1), BLK * l)  # d_l^T [h_{l-1} | aux]: [256, 288]
+                G = wgrad(dl[:, 256 * l:256 * (l + 1)], act[:, 256 * (l - 1):256 * l], aux)   # d_l^T [h_{l-1} | aux]: [256, 288]
                 out[l] = G if l == 5 else (G[:, :256], G[:, 259])
-            Gv = _wgrad_cols(dl[:, 2048:2048 + 160], act, BLK * 7, BLK * 8)               # [dv | g]^T [h7 | aux]: [160, 288]
+            Gv = wgrad(dl[:, 2048:2048 + 160], act[:, 256 * 7:256 * 8], aux)                # [dv | g]^T [h7 | aux]: [160, 288]
             gMv, gwa, gba = Gv[:128], Gv[131:132, :256], Gv[131, 259].reshape(1)
             gbr = Gv[128:131, 259]
-            gWr = _wgrad_cols(dl[:, 2048 + 128:2048 + 160], act, BLK * 8, BLK * 8 + 128)[:3]   # g^T hv: [3, 128]
+            gWr = wgrad(dl[:, 2048 + 128:2048 + 160], act[:, HV:HV + 128])[:3]              # g^T hv: [3, 128]
         w_dt, b_dt, m5_dt, mv_dt, wa_dt, ba_dt, wr_dt, br_dt = dts
         res = [None, None, None, None, out[0][0].to(w_dt), out[0][1].to(b_dt)]
         for l in (1, 2, 3, 4, 6, 7):
