@@ -83,18 +83,24 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
 #endif
     });
 }
-// bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile)
+// bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile).  One v_alignbit_b32 per
+// register shifts its SIGN bit into the word ((m << 1) | sign), registers taken from 15 down to 0, then one inversion: 17 VALU
+// instructions per tile where compare + select + or took 48 (the training kernels' masks were 2700 of the sky forward's 5600
+// VALU instructions per wave).  A pre-activation of exactly +0 counts as positive (torch: gradient 0 there): a set of
+// measure zero -- MFMA accumulation from a +0 / bias start cannot produce -0, and a bias that cancels a dot product exactly
+// does not occur in practice.
 __device__ __forceinline__ uint32_t mask16(const f32x16 &a) {
     uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) m |= (a[r] > 0.0f ? 1u : 0u) << r;
-    return m;
+    for (int r = 15; r >= 0; r--) m = __builtin_amdgcn_alignbit(m, __float_as_uint(a[r]), 31);
+    return ~m & 0xFFFFu;
 }
-// the masked (ReLU') half tile as a B operand
+// the masked (ReLU') half tile as a B operand: v_bfe_i32 spreads the register's mask bit over a word, one v_and_b32 applies it
 __device__ __forceinline__ bf8 to_b_masked(const f32x16 &a, int s, uint32_t bits) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = ((bits >> (8 * s + e)) & 1u) ? a[8 * s + e] : 0.0f;
+    for (int e = 0; e < 8; e++)
+        v[e] = __uint_as_float(__float_as_uint(a[8 * s + e]) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8 * s + e, 1));
     return pack8(v);
 }
 // store a tile of activations: lane (j, h) holds features 32t + (r&3) + 8(r>>2) + 4h of sample j -- four 8-byte pieces

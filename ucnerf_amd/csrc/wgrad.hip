@@ -155,14 +155,20 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wgrad_bf16(WgradArgs a) {
     }
 }
 
-// out[i] = sum over the slabs, in slab order (fixed order: bit-reproducible)
+// out[i] = sum over the slabs in a fixed order (bit-reproducible): eight interleaved chains per element keep eight loads in
+// flight per thread (one chain: 61 us per 75 MB of partials, 1.2 TB/s), added together at the end
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, uint32_t n_slabs, uint32_t n,
                                                       float *__restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    float s = 0.0f;
-    for (uint32_t k = 0; k < n_slabs; k++) s += partial[(size_t)k * n + i];
-    out[i] = s;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t k = 0;
+    for (; k + 8 <= n_slabs; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) s[u] += partial[(size_t)(k + u) * n + i];
+    }
+    for (; k < n_slabs; k++) s[k & 7u] += partial[(size_t)k * n + i];
+    out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 uint32_t wgrad_slabs(uint64_t M) {
