@@ -139,8 +139,22 @@ def density_query_ms(model, device, side=256, chunk=1 << 21):
         z = sweep()
         torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
+    # ... and the mesh the reference takes from that lattice (extract.py:452 skimage.measure.marching_cubes on the host after
+    # a device-to-host copy): csrc/mesh.hip on the device, at the median density (a surface through the whole random field)
+    from ucnerf_amd.internal import mesh
+    vol = z.reshape(side, side, side)
+    level = float(vol.median())
+    mesh.marching_cubes(vol, level)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    v, f, n, _ = mesh.marching_cubes(vol, level, spacing=(2 / (side - 1),) * 3)
+    torch.cuda.synchronize()
+    mc_ms = (time.perf_counter() - t0) * 1e3
     return dict(points=pts.shape[0], ms=ms, points_per_s=pts.shape[0] / (ms * 1e-3), finite=bool(torch.isfinite(z).all()),
-                call="nerf_mlp.predict_density(means[:, None], stds[:, None], no_warp=True)  (extract.py:54)")
+                call="nerf_mlp.predict_density(means[:, None], stds[:, None], no_warp=True)  (extract.py:54)",
+                marching_cubes=dict(ms=mc_ms, lattice=f"{side}^3", level=level, vertices=int(v.shape[0]), triangles=int(f.shape[0]),
+                                    cells_per_s=(side - 1) ** 3 / (mc_ms * 1e-3),
+                                    kernel="k_mc_count / k_mc_scan / k_mc_verts / k_mc_faces (indexed mesh, incl. the host read of the two counts)"))
 
 
 def tsdf_fusion_ms(device, resolution=512, views=4):

@@ -442,6 +442,19 @@ uint64_t ucn_wgrad_ws_floats(uint32_t KA, uint32_t KB, uint64_t M);
 int ucn_wgrad_bf16(const void *A, uint32_t lda, uint32_t KA, const void *B1, uint32_t ldb1, uint32_t kb1, const void *B2,
                    uint32_t ldb2, uint32_t kb2, uint64_t M, float *workspace, float *out, ucn_stream_t stream);
 
+/* Iso-surface extraction from a dense lattice of values on the device (ref: skimage.measure.marching_cubes as called by
+ * extract.py:379-383, :420-460 and tsdf.py:98-102): volume [X][Y][Z] float32 (z fastest), inside = value < level.
+ * Two calls around one host read of the two counts (the outputs have to be allocated):
+ *   ucn_marching_cubes_count -> counts_out[0] = vertices, [1] = triangles (DEVICE); workspace ucn_marching_cubes_ws_bytes(X,Y,Z)
+ *   ucn_marching_cubes_emit  -> verts [nv,3] = lattice coordinates x spacing, normals [nv,3] (unit gradient; NULL to skip),
+ *                               faces [nt,3] int32 into verts (NULL to skip); same volume / level / workspace as the count call.
+ * Shared vertices, deterministic order (vertices by owning lattice point then axis, triangles by cell then table order). */
+uint64_t ucn_marching_cubes_ws_bytes(uint32_t X, uint32_t Y, uint32_t Z);
+int ucn_marching_cubes_count(const float *volume, uint32_t X, uint32_t Y, uint32_t Z, float level, void *workspace,
+                             uint32_t *counts_out, ucn_stream_t stream);
+int ucn_marching_cubes_emit(const float *volume, uint32_t X, uint32_t Y, uint32_t Z, float level, float sx, float sy, float sz,
+                            void *workspace, float *verts, float *normals, int32_t *faces, ucn_stream_t stream);
+
 /* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
 int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,
               uint32_t K, uint32_t Nout, int relu, float *y /*[M,Nout]*/, ucn_stream_t stream);

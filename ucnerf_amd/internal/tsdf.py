@@ -3,8 +3,8 @@
 Interface mirror of /root/reference/nerf/tsdf.py:31-219 (`TSDF`): same constructor (config, accelerator), attributes
 (`origin`, `voxel_size`, `resolution`, `voxel_coords`, `voxel_world_coords`, `values`, `weights`, `colors`,
 `truncation`) and `integrate_tsdf(c2w, K, depth_images, color_images=None)`, so tsdf.py's main loop runs on it
-unchanged.  The volume lives on the device; integration is one kernel launch per call.  `export_mesh` needs the same
-third-party marching cubes as upstream (skimage + trimesh) and raises if they are absent."""
+unchanged.  The volume lives on the device; integration is one kernel launch per call; `export_mesh` meshes it on the
+device too (internal/mesh.py, csrc/mesh.hip)."""
 import torch
 
 from .. import _lib
@@ -59,24 +59,54 @@ class TSDF:
                                           self.weights.data_ptr(), None if color is None else self.colors.data_ptr(), _lib.stream()))
 
     def export_mesh(self, path):
-        """tsdf.py:73-113: marching cubes on the gathered volume (third-party, host side, as upstream)."""
-        try:
-            from skimage import measure
-            import trimesh
-        except ImportError as e:                                                   # pragma: no cover
-            raise NotImplementedError("TSDF.export_mesh needs skimage.measure.marching_cubes and trimesh, like the "
-                                      "reference; the fused volume is in .values / .colors") from e
-        import numpy as np
+        """tsdf.py:73-113: marching cubes on the gathered volume, vertex colours from the nearest voxel, vertices back through
+        the inverse contraction, a mesh file.  The reference copies the volume to the host for skimage; here the mesher is
+        `internal.mesh.marching_cubes` (csrc/mesh.hip) on the device, and only the finished mesh crosses PCIe.  Written with
+        trimesh when it is importable (as upstream), else as a binary PLY by this module.  Returns the mesh's sizes."""
+        from . import mesh
         tsdf_values = self.values.clamp(-1, 1)
         mask = self.voxel_world_coords[:, :3].permute(0, 2, 1).norm(p=2, dim=-1) > self.config.tsdf_max_radius
         tsdf_values[mask.reshape(self.values.shape)] = 1.
         r = self.resolution
-        vol = self.accelerator.gather(tsdf_values).cpu().reshape((r, r, r)).numpy()
-        cols = self.accelerator.gather(self.colors).cpu().reshape((r, r, r, 3)).numpy()
-        if self.accelerator.is_main_process:
-            vertices, faces, normals, _ = measure.marching_cubes(vol, level=0, allow_degenerate=False)
-            vi = np.round(vertices).astype(int)
-            colors = cols[vi[:, 0], vi[:, 1], vi[:, 2]]
-            vertices = self.origin.cpu().numpy() + vertices * self.voxel_size
-            vertices = inv_contract(torch.from_numpy(vertices)).numpy()
-            trimesh.Trimesh(vertices=vertices, faces=faces, normals=normals, vertex_colors=colors).export(path)
+        vol = self.accelerator.gather(tsdf_values).reshape(r, r, r)
+        cols = self.accelerator.gather(self.colors).reshape(r, r, r, 3)
+        if not self.accelerator.is_main_process:
+            return None
+        vertices, faces, normals, _ = mesh.marching_cubes(vol, level=0.0, allow_degenerate=False)
+        vi = torch.round(vertices).long().clamp_(0, r - 1)
+        colors = cols[vi[:, 0], vi[:, 1], vi[:, 2]]
+        vertices = inv_contract(self.origin + vertices * self.voxel_size)
+        v, f, n, c = (t.cpu().numpy() for t in (vertices, faces, normals, colors))
+        try:
+            import trimesh
+            trimesh.Trimesh(vertices=v, faces=f, normals=n, vertex_colors=c).export(path)
+        except ImportError:
+            write_ply(path, v, f, n, c)
+        return dict(vertices=int(v.shape[0]), faces=int(f.shape[0]))
+
+
+def write_ply(path, vertices, faces, normals=None, colors=None):
+    """Binary little-endian PLY: float32 positions (+ normals), uint8 colours, int32 triangles."""
+    import numpy as np
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    if normals is not None:
+        fields += [("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4")]
+    if colors is not None:
+        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    vert = np.zeros(len(vertices), dtype=fields)
+    vert["x"], vert["y"], vert["z"] = vertices[:, 0], vertices[:, 1], vertices[:, 2]
+    if normals is not None:
+        vert["nx"], vert["ny"], vert["nz"] = normals[:, 0], normals[:, 1], normals[:, 2]
+    if colors is not None:
+        c8 = np.clip(np.round(np.asarray(colors, np.float64) * 255), 0, 255).astype(np.uint8)
+        vert["red"], vert["green"], vert["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
+    face = np.zeros(len(faces), dtype=[("n", "u1"), ("v", "<i4", (3,))])
+    face["n"], face["v"] = 3, faces
+    names = {"<f4": "float", "u1": "uchar"}
+    head = ["ply", "format binary_little_endian 1.0", f"element vertex {len(vert)}"]
+    head += [f"property {names[t]} {n}" for n, t in fields]
+    head += [f"element face {len(face)}", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(head) + "\n").encode("ascii"))
+        fh.write(vert.tobytes())
+        fh.write(face.tobytes())
