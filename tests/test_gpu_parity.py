@@ -1300,3 +1300,53 @@ def test_fine_level_per_sample_error_is_bracketed_by_the_float32_reference_itsel
     assert float(e_hip.mean()) <= 2.0 * float(e_ref.mean()) + 1e-7, (float(e_hip.mean()), float(e_ref.mean()))
     print(f"fine level, raw density per sample: |reference fp32 - fp64 truth| max {float(e_ref.max()):.2e} mean {float(e_ref.mean()):.2e}; "
           f"|HIP - truth| max {float(e_hip.max()):.2e} mean {float(e_hip.mean()):.2e}")
+
+
+@pytest.mark.parametrize("case", ["default", "tiny_trunk", "huge_trunk", "uneven_layers"])
+def test_sky_split_f16_range(case):
+    """the fp32-class sky kernel (k_sky_mlp, split-f16 operands) carried no layer scales, so the range
+    guard of test_split_f16_range did not cover it.  It now carries statistical power-of-two scales chosen at pack time
+    (sky.hip k_sky_scales): whatever the magnitudes of the trunk's activations -- 1e-4 (low halves would be subnormal),
+    1e5 (f16 operands would overflow to inf), or alternating from layer to layer -- the rendered sky colour must stay
+    fp32-class against a float64 evaluation of the same network (train_graph.sky_forward on a double copy).  With the scales
+    switched off (UCN_SKY_NO_SCALES=1) `tiny_trunk` is 1.8e-5 and `huge_trunk` 6.8e-5 off -- 100x / 400x the float32 reference's
+    own 1.7e-7 -- and both cases fail this test."""
+    import copy
+    from ucnerf_amd.internal import train_graph as tg
+    from ucnerf_amd.internal.sky import NeRF
+    torch.manual_seed(21)
+    net = NeRF(D=8, d_in_view=3, W=256, multires_view=4, output_ch=4, skips=[4])
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+        P = net.pts_linears
+        if case == "tiny_trunk":                       # h0 ~ 1e-4 of its default size; the heads bring the outputs back
+            P[0].weight.mul_(1e-4); P[0].bias.mul_(1e-4)
+            for l in range(1, 8):
+                P[l].bias.mul_(1e-4)
+            P[5].weight[:, :3].mul_(1e-4)
+            net.alpha_linear.weight.mul_(1e4); net.feature_linear.weight.mul_(1e4)
+        elif case == "huge_trunk":
+            P[0].weight.mul_(3e4); P[0].bias.mul_(3e4)
+            for l in range(1, 8):
+                P[l].bias.mul_(3e4)
+            P[5].weight[:, :3].mul_(3e4)
+            net.alpha_linear.weight.mul_(1 / 3e4); net.feature_linear.weight.mul_(1 / 3e4)
+        elif case == "uneven_layers":
+            for l, f in zip(range(1, 8), (300.0, 1 / 300.0, 300.0, 1 / 300.0, 300.0, 1 / 300.0, 300.0)):
+                P[l].weight.mul_(f)
+                if l == 5:
+                    pass
+            net.alpha_linear.weight.mul_(1 / 300.0); net.feature_linear.weight.mul_(1 / 300.0)
+    n = 512
+    rays = rm.synthetic_rays(n, seed=22)
+    o, d, cam, far = rays["origins"], rays["directions"], rays["cam_dirs"], rays["far"]
+    with torch.no_grad():
+        truth = tg.sky_forward(copy.deepcopy(net).double(), o.double(), d.double(), cam.double(), far.double())
+        want32 = tg.sky_forward(net, o, d, cam, far)                       # the reference's own float32 arithmetic
+        got = net.cuda().render(o.cuda(), d.cuda(), cam.cuda(), far.cuda()).cpu().double()
+    assert torch.isfinite(got).all(), "f16 operand overflow"
+    assert float(truth.abs().max()) > 1e-3
+    e_ref, e_hip = float((want32.double() - truth).abs().max()), float((got - truth).abs().max())
+    assert e_hip <= 3 * e_ref + 3e-6, (case, e_hip, e_ref)

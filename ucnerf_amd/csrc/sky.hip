@@ -53,7 +53,12 @@ constexpr int kBWaves = UCN_SKY_BF_WAVES, kBChunk = kBWaves == 4 ? 16 : 2 * kBWa
 constexpr int kBPadded = (kBEnd + kBChunk - 1) / kBChunk * kBChunk;      // 984 (24-fragment chunks) / 992 (16)
 using BRing = Ring<kBPadded, kBChunk, kBWaves, kBSlots, kBLead>;
 constexpr uint64_t kOffBf = kOffMv + 128 * 288;
-constexpr uint64_t kSkyPackedFloats = kOffBf + (uint64_t)kBPadded * 256;
+constexpr uint64_t kOffExp = kOffBf + (uint64_t)kBPadded * 256;          // 9 layer exponents (ints) + report, 32 slots
+constexpr uint64_t kOffScaled = kOffExp + 32;                             // scaled fp32 copies the packers read:
+//   6 x W[256][256] | M5[256][288] | Mv[128][288] | 7 biases[256] | W0[256][3] + b0[256] | w_alpha[256] | W_rgb[3][128]
+constexpr uint64_t kScW = 0, kScM5 = 6 * 65536, kScMv = kScM5 + 256 * 288, kScB = kScMv + 128 * 288, kScW0 = kScB + 7 * 256;
+constexpr uint64_t kScB0 = kScW0 + 768, kScWa = kScB0 + 256, kScWr = kScWa + 256, kScEnd = kScWr + 384;
+constexpr uint64_t kSkyPackedFloats = kOffScaled + kScEnd;
 
 constexpr int kLayerG[7] = {kGL1, kGL2, kGL3, kGL4, kGL5, kGL6, kGL7};
 
@@ -398,6 +403,81 @@ __global__ __launch_bounds__(256) void k_sky_compose(const float *__restrict__ w
     }
 }
 
+// ---- power-of-two layer scales of the split-f16 engine (the field kernel's comment 5, field_mlp_h.hip): f16 operands cover
+// 2^-24 .. 65504 and a low half is exact only while it is a normal f16.  ReLU layers are positively homogeneous, so layer l's
+// activations are carried as 2^e_l h_l: packed weights W 2^(e_l - e_in) (exact), biases b 2^e_l, the two VALU heads undo the
+// last scale.  For this 8-layer trunk a RIGOROUS bound of |h_l| (products of row sums of |W|) sits ~10^9 above what occurs,
+// so e_l is STATISTICAL: the layer's typical magnitude -- second moments propagated through the weights, halved by each
+// ReLU, assuming a second moment of 16 per coordinate of the sample point (|p| <= ~10 on the sky shell) and 1/2 per view
+// encoding entry -- is centred at 2^4, which leaves a factor 2^11 of head room to the f16 maximum and 2^13 to the point
+// where low halves leave the normal range.  Both kernels (split-f16 and bf16) read the same scaled side table, so both streams
+// are packed from the same scaled copies; in bf16 / fp32 the scaling is exact and changes nothing.
+// exps[0..7] = e of h0 .. h7, exps[8] = e of the views layer's hidden units.
+struct SkyPtrs {
+    const float *w[8], *b[8];
+};
+__global__ __launch_bounds__(256) void k_sky_scales(const float *__restrict__ w0, const float *__restrict__ b0, SkyPtrs ptrs,
+                                                    const float *__restrict__ M5, const float *__restrict__ Mv, int *__restrict__ exps) {
+    __shared__ float s_sum[4];
+    __shared__ float s_typ2;
+    const uint32_t t = threadIdx.x;
+    auto layer_typ2 = [&](float row_q, uint32_t rows) {              // 0.5 * mean over the rows of the pre-activation's second moment
+        float q = row_q;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        __syncthreads();
+        if ((t & 63u) == 0u) s_sum[t >> 6] = q;
+        __syncthreads();
+        if (t == 0) s_typ2 = 0.5f * (s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / (float)rows;
+        __syncthreads();
+        return s_typ2;
+    };
+    auto expo = [](float typ2) {
+        const float typ = sqrtf(typ2);
+        if (!(typ > 0.0f) || !(typ < 3.0e38f)) return 0;
+        const int e = 4 - ilogbf(typ);
+        return e < -60 ? -60 : (e > 60 ? 60 : e);
+    };
+    const float p2 = 16.0f;
+    float q = ((w0[t * 3] * w0[t * 3] + w0[t * 3 + 1] * w0[t * 3 + 1]) + w0[t * 3 + 2] * w0[t * 3 + 2]) * p2 + b0[t] * b0[t];
+    float typ2 = layer_typ2(q, 256u);
+    if (t == 0) exps[0] = expo(typ2);
+    for (int l = 1; l <= 7; l++) {
+        float s2 = 0.0f;
+        if (l == 5) {
+            for (uint32_t k = 0; k < 256u; k++) { const float w = M5[t * 288 + k]; s2 += w * w; }
+            float sp = 0.0f;
+            for (uint32_t k = 256u; k < 259u; k++) { const float w = M5[t * 288 + k]; sp += w * w; }
+            q = s2 * typ2 + sp * p2 + M5[t * 288 + 259] * M5[t * 288 + 259];
+        } else {
+            const float *W = ptrs.w[l], *b = ptrs.b[l];
+            for (uint32_t k = 0; k < 256u; k++) { const float w = W[t * 256 + k]; s2 += w * w; }
+            q = s2 * typ2 + b[t] * b[t];
+        }
+        typ2 = layer_typ2(q, 256u);
+        if (t == 0) exps[l] = expo(typ2);
+    }
+    q = 0.0f;
+    if (t < 128u) {
+        float s2 = 0.0f, sv = 0.0f;
+        for (uint32_t k = 0; k < 256u; k++) { const float w = Mv[t * 288 + k]; s2 += w * w; }
+        for (uint32_t k = 260u; k < 287u; k++) { const float w = Mv[t * 288 + k]; sv += w * w; }
+        q = s2 * typ2 + 0.5f * sv + Mv[t * 288 + 259] * Mv[t * 288 + 259];
+    }
+    typ2 = layer_typ2(q, 128u);
+    if (t == 0) exps[8] = expo(typ2);
+}
+
+// dst[i] = src[i] * 2^(e_out - e_in), e_out = exps[ia] (0 if ia < 0), e_in = exps[ib] for columns below `split` (0 beyond / if ib < 0)
+__global__ __launch_bounds__(256) void k_sky_scaled_copy(const float *__restrict__ src, uint32_t n, uint32_t cols, uint32_t split, int ia,
+                                                         int ib, const int *__restrict__ exps, float *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = i % cols;
+    const int x = (ia >= 0 ? exps[ia] : 0) - ((c < split && ib >= 0) ? exps[ib] : 0);
+    dst[i] = ldexpf(src[i], x);
+}
+
 __global__ __launch_bounds__(256) void k_sky_side_scalars(const float *__restrict__ b_alpha, const float *__restrict__ b_rgb,
                                                           float *__restrict__ side) {
     if (threadIdx.x == 0) side[kSAlpha + 256] = b_alpha[0];
@@ -451,34 +531,54 @@ extern "C" int ucn_sky_pack(const ucn_sky_t *s, ucn_stream_t stream) {
     hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up(kOffM5, 256)), dim3(256), 0, st, s->packed, (uint32_t)kOffM5);
     hipLaunchKernelGGL(k_sky_compose, dim3(ucn_div_up(256 * 288, 256)), dim3(256), 0, st, s->w_pts[5], s->b_pts[5], s->w_view,
                        s->b_view, s->w_feat, s->b_feat, M5, Mv);
+    // ---- layer scales, then fp32 copies of every matrix / bias scaled by exact powers of two: what the packers read
+    int *exps = reinterpret_cast<int *>(s->packed + kOffExp);
+    float *sc = s->packed + kOffScaled;
+    SkyPtrs ptrs;
+    for (int i = 0; i < 8; i++) { ptrs.w[i] = s->w_pts[i]; ptrs.b[i] = s->b_pts[i]; }
+    // UCN_SKY_NO_SCALES=1 (tests / experiments): every exponent 0, i.e. round 2's unscaled operands
+    static const bool no_scales = getenv("UCN_SKY_NO_SCALES") && atoi(getenv("UCN_SKY_NO_SCALES")) != 0;
+    if (no_scales) hipLaunchKernelGGL(k_fill_zero, dim3(1), dim3(256), 0, st, reinterpret_cast<float *>(exps), 16u);
+    else hipLaunchKernelGGL(k_sky_scales, dim3(1), dim3(256), 0, st, s->w_pts[0], s->b_pts[0], ptrs, M5, Mv, exps);
+    auto scaled = [&](const float *src, uint32_t n, uint32_t cols, uint32_t split, int ia, int ib, float *dst) {
+        hipLaunchKernelGGL(k_sky_scaled_copy, dim3(ucn_div_up(n, 256)), dim3(256), 0, st, src, n, cols, split, ia, ib, exps, dst);
+        return (const float *)dst;
+    };
     auto chainpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t group) {
         hipLaunchKernelGGL(k_pack_chain_h, dim3(ucn_div_up((uint64_t)nto * nti * 2048, 256)), dim3(256), 0, st, W, ld, 0u,
                            0u, nto, nti, (const float *)nullptr, reinterpret_cast<_Float16 *>(s->packed + group * 256));
     };
+    __bf16 *bs = reinterpret_cast<__bf16 *>(s->packed + kOffBf);
+    if (kBPadded > kBEnd)      // the mixed-precision kernel's stream: zero padding
+        hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up((uint64_t)(kBPadded - kBEnd) * 256, 256)), dim3(256), 0, st,
+                           s->packed + kOffBf + (uint64_t)kBEnd * 256, (uint32_t)((kBPadded - kBEnd) * 256));
+    auto bfpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t frag) {
+        hipLaunchKernelGGL(k_pack_chain_bf, dim3(ucn_div_up((uint64_t)nto * nti * 1024, 256)), dim3(256), 0, st, W, ld, nto, nti,
+                           bs + frag * 512);
+    };
     const int plain[6] = {1, 2, 3, 4, 6, 7};
     const int plain_g[6] = {kGL1, kGL2, kGL3, kGL4, kGL6, kGL7};
     for (int i = 0; i < 6; i++) {
-        chainpack(s->w_pts[plain[i]], 256, 8, 8, plain_g[i]);
-        hipLaunchKernelGGL(k_pack_bias_h, dim3(1), dim3(256), 0, st, s->b_pts[plain[i]], 8u, side + kSB + i * 256);
+        const int l = plain[i];
+        const float *W = scaled(s->w_pts[l], 65536u, 256u, 256u, l, l - 1, sc + kScW + (uint64_t)i * 65536);      // W_l 2^(e_l - e_{l-1})
+        const float *bias = scaled(s->b_pts[l], 256u, 1u, 0u, l, -1, sc + kScB + (uint64_t)i * 256);               // b_l 2^e_l
+        chainpack(W, 256, 8, 8, plain_g[i]);
+        bfpack(W, 256, 8, 8, kBL[l - 1]);
+        hipLaunchKernelGGL(k_pack_bias_h, dim3(1), dim3(256), 0, st, bias, 8u, side + kSB + i * 256);
     }
-    chainpack(M5, 288, 8, 9, kGL5);
-    chainpack(Mv, 288, 4, 9, kGV);
-    {   // the mixed-precision kernel's stream (its zero padding comes from the fill below)
-        __bf16 *bs = reinterpret_cast<__bf16 *>(s->packed + kOffBf);
-        if (kBPadded > kBEnd)
-            hipLaunchKernelGGL(k_fill_zero, dim3(ucn_div_up((uint64_t)(kBPadded - kBEnd) * 256, 256)), dim3(256), 0, st,
-                               s->packed + kOffBf + (uint64_t)kBEnd * 256, (uint32_t)((kBPadded - kBEnd) * 256));
-        auto bfpack = [&](const float *W, uint32_t ld, uint32_t nto, uint32_t nti, uint64_t frag) {
-            hipLaunchKernelGGL(k_pack_chain_bf, dim3(ucn_div_up((uint64_t)nto * nti * 1024, 256)), dim3(256), 0, st, W, ld, nto, nti,
-                               bs + frag * 512);
-        };
-        for (int i = 0; i < 6; i++) bfpack(s->w_pts[plain[i]], 256, 8, 8, kBL[plain[i] - 1]);
-        bfpack(M5, 288, 8, 9, kBL[4]);
-        bfpack(Mv, 288, 4, 9, kBV);
-    }
-    hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, s->w_pts[0], 3u, s->b_pts[0], 256u, side + kSL0);
-    hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, s->w_alpha, 256u, 0u, 256u, 1u, 1u, side + kSAlpha);
-    hipLaunchKernelGGL(k_pack_head, dim3(2), dim3(256), 0, st, s->w_rgb, 128u, 0u, 128u, 3u, 4u, side + kSRgb);
+    // the two 9-tile layers: hidden columns against the layer below, the auxiliary tile (point, 1, view encoding) unscaled
+    const float *M5s = scaled(M5, 256u * 288u, 288u, 256u, 5, 4, sc + kScM5);
+    const float *Mvs = scaled(Mv, 128u * 288u, 288u, 256u, 8, 7, sc + kScMv);
+    chainpack(M5s, 288, 8, 9, kGL5);
+    chainpack(Mvs, 288, 4, 9, kGV);
+    bfpack(M5s, 288, 8, 9, kBL[4]);
+    bfpack(Mvs, 288, 4, 9, kBV);
+    const float *W0s = scaled(s->w_pts[0], 768u, 3u, 0u, 0, -1, sc + kScW0), *b0s = scaled(s->b_pts[0], 256u, 1u, 0u, 0, -1, sc + kScB0);
+    const float *was = scaled(s->w_alpha, 256u, 256u, 256u, -1, 7, sc + kScWa);                                     // heads undo the last scale
+    const float *wrs = scaled(s->w_rgb, 384u, 128u, 128u, -1, 8, sc + kScWr);
+    hipLaunchKernelGGL(k_pack_in3, dim3(4), dim3(256), 0, st, W0s, 3u, b0s, 256u, side + kSL0);
+    hipLaunchKernelGGL(k_pack_head, dim3(1), dim3(256), 0, st, was, 256u, 0u, 256u, 1u, 1u, side + kSAlpha);
+    hipLaunchKernelGGL(k_pack_head, dim3(2), dim3(256), 0, st, wrs, 128u, 0u, 128u, 3u, 4u, side + kSRgb);
     hipLaunchKernelGGL(k_sky_side_scalars, dim3(1), dim3(64), 0, st, s->b_alpha, s->b_rgb, side);
     UCN_LAUNCH_CHECK("sky_pack");
     return 0;
