@@ -857,10 +857,21 @@ def _sky_fusable(net, origins):
 
 
 def brightness_forward(bc, idx, which="latent_code"):
-    x = getattr(bc, which)[idx.reshape(-1).long()]
+    """extrinsic_optimizer.py:4-48 as models.py:341-349 calls it: the reference looks the latent code up per RAY and runs the
+    4 -> 256 -> 256 -> 256 -> 12 MLP on 8192 rows that repeat at most `training_views` distinct codes.  A row's result depends
+    only on its code, so the MLP runs on the code table (210 rows) and the rays gather their affine map: same values, same
+    gradients (autograd's gather backward sums a code's rays), 40x fewer rows through six GEMMs forward + backward."""
+    codes = getattr(bc, which)
+    idx = idx.reshape(-1).long()
+    if codes.shape[0] > 2 * idx.shape[0]:                           # more codes than rays: the per-ray form is the smaller one
+        x = codes[idx]
+        for lin in bc.brightness_MLP.pts_linears:
+            x = F.relu(lin(x))
+        return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)
+    x = codes
     for lin in bc.brightness_MLP.pts_linears:
         x = F.relu(lin(x))
-    return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)
+    return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)[idx]
 
 
 def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
