@@ -455,6 +455,12 @@ int ucn_marching_cubes_count(const float *volume, uint32_t X, uint32_t Y, uint32
 int ucn_marching_cubes_emit(const float *volume, uint32_t X, uint32_t Y, uint32_t Z, float level, float sx, float sy, float sz,
                             void *workspace, float *verts, float *normals, int32_t *faces, ucn_stream_t stream);
 
+/* PSNR and SSIM of a rendered frame against the ground truth with the reference's conventions (ref: internal/image.py:114-133
+ * MetricHarness: uint8 quantisation, skimage PSNR with data_range 255, skimage SSIM defaults on OpenCV's 8-bit grey images):
+ * pred, gt [H, W, 3] float32 in [0, 1] (DEVICE) -> out[0] = psnr (dB), out[1] = ssim, out[2] = mse on the uint8 scale (DEVICE doubles). */
+uint64_t ucn_image_metrics_ws_bytes(uint32_t H, uint32_t W);
+int ucn_image_metrics(const float *pred, const float *gt, uint32_t H, uint32_t W, void *workspace, double *out, ucn_stream_t stream);
+
 /* generic small dense layer y = act(x W^T + b), used for the brightness MLP (4->256->256->256->12) */
 int ucn_dense(const float *x /*[M,K]*/, const float *w /*[Nout,K]*/, const float *b, uint32_t M,
               uint32_t K, uint32_t Nout, int relu, float *y /*[M,Nout]*/, ucn_stream_t stream);

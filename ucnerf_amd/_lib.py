@@ -120,13 +120,15 @@ SIGNATURES = {
     "ucn_marching_cubes_ws_bytes": [c_u32, c_u32, c_u32],
     "ucn_marching_cubes_count": [c_vp, c_u32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp],
     "ucn_marching_cubes_emit": [c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_image_metrics_ws_bytes": [c_u32, c_u32],
+    "ucn_image_metrics": [c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp],
     "ucn_dense": [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp],
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64,
-             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
+             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_image_metrics_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
              "ucn_sky_train_grad_ld": c_u32}
 
 _lib = None
