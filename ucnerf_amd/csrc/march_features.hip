@@ -799,6 +799,7 @@ struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
     uint8_t coarse[UCN_MAX_LEVELS];
     uint32_t n_planes, shift;
+    uint32_t wg_target;                    // workgroups per level of the compacted kernel (bwd_sample_split)
 };
 static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     uint32_t shift = 0;
@@ -806,6 +807,7 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     if ((1u << shift) != rpb) return false;
     mp->shift = shift;
     mp->n_planes = 0;
+    mp->wg_target = 128u;
     for (uint32_t l = 0; l < lv.L; l++) {
         if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
         // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
@@ -904,8 +906,8 @@ __device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, float *_
     }
 }
 
-__host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level) {
-    return blocks_in_level >= 128u ? 1u : 128u / blocks_in_level;        // ~128 workgroups per level
+__host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
+    return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
 }
 
 template <uint32_t C>
@@ -1125,7 +1127,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
     uint32_t task = blockIdx.x, lvl = 0, nb = 1, split = 1;
     for (;; lvl++) {
         nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
-        split = bwd_sample_split(nb);
+        split = bwd_sample_split(nb, plan.wg_target);
         if (task < nb * split || lvl + 1 == lvls.L) break;
         task -= nb * split;
     }
@@ -1341,6 +1343,13 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
         }
         MaskPlan plan;
         if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
+            static const uint32_t wg_target = getenv("UCN_BWD_WGS") ? (uint32_t)atoi(getenv("UCN_BWD_WGS")) : 128u;   // experiment knob
+            plan.wg_target = wg_target ? wg_target : 128u;
+            tasks = 0;
+            for (uint32_t l = 0; l < lv.L; l++) {
+                const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
+                tasks += nb * bwd_sample_split(nb, plan.wg_target);
+            }
             // compacting variant: block masks next to the geometry planes, dense items from a per-wave ring in LDS
             uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
             float *glm = layout == 0 ? nullptr : workspace + (24ull + plan.n_planes) * B;     // level-major copy
