@@ -191,3 +191,20 @@ def test_bench_two_ranks_flow_on_one_gpu():
     assert 1e5 < r["value"] < 2e7 and abs(r["value"] - 1280 * 1920 / (r["ms_per_step"] * 1e-3)) <= 1e-3 * r["value"]
     assert r["roofline"]["bound"] in ("hbm", "mfma") and 0 < r["roofline"]["frac"] <= 1.2
     assert "cpu_baseline" not in r and "train_step" not in r          # rank-0-at-N=1-only extras stay out of the N > 1 line
+
+
+def test_item_list_backward_is_the_same_adjoint():
+    """The fine levels' second route through the table gradient (UCN_BWD_LISTS=1: counting sort of (point, (y, z) combination)
+    items into per-block lists, march_features.hip k_bwd_bin / k_bwd_list; off by default on measurement) must satisfy the
+    same exact-adjoint and parity tests as the compacted kernel.  The switch is read once per process: a child pytest."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UCN_BWD_LISTS="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-k",
+                        "(adjoint or features_backward or train_graph_matches_reference_step) and not item_list",
+                        os.path.join(repo, "tests", "test_full_size.py"), os.path.join(repo, "tests", "test_gpu_parity.py"),
+                        os.path.join(repo, "tests", "test_train_step.py")],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]

@@ -800,6 +800,7 @@ struct MaskPlan {
     uint8_t coarse[UCN_MAX_LEVELS];
     uint32_t n_planes, shift;
     uint32_t wg_target;                    // workgroups per level of the compacted kernel (bwd_sample_split)
+    uint32_t skip_fine;                    // 1: the fine levels are taken by the item-list kernels (k_bwd_list), not by bwd_cmp
 };
 static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     uint32_t shift = 0;
@@ -808,6 +809,7 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     mp->shift = shift;
     mp->n_planes = 0;
     mp->wg_target = 128u;
+    mp->skip_fine = 0u;
     for (uint32_t l = 0; l < lv.L; l++) {
         if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
         // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
@@ -1128,8 +1130,10 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
     for (;; lvl++) {
         nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
         split = bwd_sample_split(nb, plan.wg_target);
-        if (task < nb * split || lvl + 1 == lvls.L) break;
-        task -= nb * split;
+        const uint32_t here = (plan.skip_fine && !plan.coarse[lvl]) ? 0u : nb * split;
+        if (task < here) break;
+        if (lvl + 1 == lvls.L) return;                                        // (cannot happen: the grid is the sum of `here`)
+        task -= here;
     }
     const UcnLevel lv = lvls.lv[lvl];
     const uint32_t blk = task / split, part = task % split;
@@ -1161,6 +1165,255 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
             if (split == 1) gtab[i] += v;
             else atomicAdd(gtab + i, v);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fine levels by ITEM LISTS (r03).  In the compacted kernel above every workgroup of a row block scans the block masks of
+// ALL samples (32 blocks per level: the scan is replicated 32x) and a hit re-derives all eight corners of the point although
+// only the ~2 of one (y, z) combination lie in the block (a hash scatters the four combinations over ~4 of the 32 blocks:
+// 4.5 hits per point).  Here the points are visited ONCE per level: every (point, (y, z) combination) becomes one 32-bit item
+// (sample | multisample << 27 | combination << 30) routed to the list of the block that owns the combination's x0 row --
+// a counting sort in two passes (k_bwd_bin<false> counts per (level, block), k_bwd_bin_scan turns the counts into offsets and
+// into a task table with workgroups PROPORTIONAL to a block's item count -- the strided levels of the uint32-wrap quirk
+// load their blocks very unevenly --, k_bwd_bin<true> writes the items through per-workgroup LDS ranks, one global atomic
+// per (workgroup, block)).  k_bwd_list then runs dense 64-lane batches over its list: one hash, two x-weights, one erf,
+// two 8-byte LDS compare-and-swaps per item; the x0 + 1 corner lands in another block once in ~16 384 items and goes to
+// the table by a global atomic.  Same addends as the compacted kernel ((w_k damp) g_c), other order.
+constexpr uint32_t kListTasks = 160;                  // workgroups per fine level (128 shared out by item count, + rounding)
+constexpr uint32_t kListMaxBlocks = 32;
+
+struct ListPlan {
+    uint32_t n_fine;
+    uint8_t level[UCN_MAX_LEVELS];          // fine level f -> level index
+    uint32_t nb[UCN_MAX_LEVELS];            // row blocks of that level
+    size_t cap;                             // items per fine level (= 24 B)
+};
+// control block (uint32): per fine level f: cnt[32] | cursor[32] | off[33] | tasks[kListTasks][2] (blk | nparts << 8 | part << 16, first item; count via next)
+constexpr uint32_t kCtlCnt = 0, kCtlCur = 32, kCtlOff = 64, kCtlTask = 100, kCtlPerLevel = kCtlTask + 3 * kListTasks + 4;
+
+// the x0 row of each of the four (y, z) combinations of a point, and its fractions
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void combo_rows(const UcnLevel &lv, float px, float py, float pz, float &fx, float &fy, float &fz,
+                                           uint32_t (&r0)[4], uint32_t (&r1)[4]) {
+    fx = fmaf(px, lv.scale, 0.5f); fy = fmaf(py, lv.scale, 0.5f); fz = fmaf(pz, lv.scale, 0.5f);
+    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
+    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    uint32_t ya, yb, za, zb, xa, xb;
+    if constexpr (HASHED) {
+        xa = x0; xb = x0 + 1u;
+        ya = y0 * kP1; yb = ya + kP1;
+        za = z0 * kP2; zb = za + kP2;
+    } else {
+        xa = x0 * lv.stride[0]; xb = xa + lv.stride[0];
+        ya = y0 * lv.stride[1]; yb = ya + lv.stride[1];
+        za = z0 * lv.stride[2]; zb = za + lv.stride[2];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t yv = (c & 1u) ? yb : ya, zv = (c & 2u) ? zb : za;
+        uint32_t i0, i1;
+        if constexpr (HASHED) { i0 = xa ^ yv ^ zv; i1 = xb ^ yv ^ zv; }
+        else { i0 = xa + yv + zv; i1 = xb + yv + zv; }
+        if constexpr (POW2) { r0[c] = i0 & lv.mask; r1[c] = i1 & lv.mask; }
+        else { r0[c] = i0 < lv.rows ? i0 : i0 % lv.rows; r1[c] = i1 < lv.rows ? i1 : i1 % lv.rows; }
+    }
+}
+__device__ __forceinline__ void combo_rows_any(const UcnLevel &lv, float px, float py, float pz, float &fx, float &fy, float &fz,
+                                               uint32_t (&r0)[4], uint32_t (&r1)[4]) {
+    if (lv.hashed) {
+        if (lv.mask) combo_rows<true, true>(lv, px, py, pz, fx, fy, fz, r0, r1);
+        else combo_rows<true, false>(lv, px, py, pz, fx, fy, fz, r0, r1);
+    } else {
+        if (lv.mask) combo_rows<false, true>(lv, px, py, pz, fx, fy, fz, r0, r1);
+        else combo_rows<false, false>(lv, px, py, pz, fx, fy, fz, r0, r1);
+    }
+}
+
+// pass 1 (WRITE = false): items per (fine level, block);  pass 3 (WRITE = true): the items themselves.
+// grid (ceil(B / 256), n_fine); thread = sample.
+template <uint32_t C, bool WRITE>
+__global__ __launch_bounds__(256) void k_bwd_bin(UcnLevels lvls, ListPlan lp, uint32_t shift, size_t B, const float *__restrict__ geom,
+                                                 const float *__restrict__ grad_lm /*[L][B][C]*/, uint32_t *__restrict__ ctl,
+                                                 uint32_t *__restrict__ lists) {
+    __shared__ uint32_t s_cnt[kListMaxBlocks], s_base[kListMaxBlocks];
+    const uint32_t f = blockIdx.y, lvl = lp.level[f];
+    const UcnLevel lv = lvls.lv[lvl];
+    if (threadIdx.x < kListMaxBlocks) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    uint32_t slot[24];                                    // blk << 16 | rank in the workgroup, 0xFFFFFFFF = no item
+#pragma unroll
+    for (uint32_t i = 0; i < 24; i++) slot[i] = 0xFFFFFFFFu;
+    bool live = b < B;
+    if (live) {
+        bool nz = false;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) nz |= grad_lm[((size_t)lvl * B + b) * C + c] != 0.0f;
+        live = nz;                                        // a sample without gradient on this level contributes nothing
+    }
+    if (live) {
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            const float4 q = reinterpret_cast<const float4 *>(geom)[b * 6 + j];
+            if (!in_unit_cube(q.x, q.y, q.z)) continue;
+            float fx, fy, fz;
+            uint32_t r0[4], r1[4];
+            combo_rows_any(lv, q.x, q.y, q.z, fx, fy, fz, r0, r1);
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t blk = r0[c] >> shift;
+                const uint32_t rank = atomicAdd(&s_cnt[blk], 1u);
+                slot[4 * j + c] = (blk << 16) | rank;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *cl = ctl + (size_t)f * kCtlPerLevel;
+    if (threadIdx.x < lp.nb[f] && s_cnt[threadIdx.x])
+        s_base[threadIdx.x] = atomicAdd(cl + (WRITE ? kCtlCur : kCtlCnt) + threadIdx.x, s_cnt[threadIdx.x]);
+    if constexpr (WRITE) {
+        // the workgroup's items are first gathered per block in LDS, then written out as ONE run per block: lanes write
+        // consecutive addresses (scattering 24 single words per thread straight to the 32 lists took 2.8 ms per step)
+        __shared__ uint32_t s_lbase[kListMaxBlocks + 1], s_items[256 * 24];
+        if (threadIdx.x == 0) {
+            uint32_t a = 0;
+            for (uint32_t k = 0; k < kListMaxBlocks; k++) { s_lbase[k] = a; a += s_cnt[k]; }
+            s_lbase[kListMaxBlocks] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < 24; i++) {
+            if (slot[i] != 0xFFFFFFFFu) {
+                const uint32_t blk = slot[i] >> 16, rank = slot[i] & 0xFFFFu;
+                s_items[s_lbase[blk] + rank] = (uint32_t)b | ((i >> 2) << 27) | ((i & 3u) << 30);
+            }
+        }
+        __syncthreads();
+        uint32_t *lst = lists + (size_t)f * lp.cap;
+        const uint32_t total = s_lbase[kListMaxBlocks];
+        for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+            uint32_t lo = 0, hi = kListMaxBlocks;                 // the block whose run holds position i
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_lbase[mid] <= i) lo = mid; else hi = mid;
+            }
+            lst[cl[kCtlOff + lo] + s_base[lo] + (i - s_lbase[lo])] = s_items[i];
+        }
+    }
+}
+
+// pass 2: one workgroup of 64 lanes per fine level: offsets of the blocks' lists, and the task table
+__global__ __launch_bounds__(64) void k_bwd_bin_scan(ListPlan lp, uint32_t *__restrict__ ctl) {
+    const uint32_t f = blockIdx.x, nb = lp.nb[f];
+    uint32_t *cl = ctl + (size_t)f * kCtlPerLevel;
+    if (threadIdx.x != 0) return;
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < nb; k++) { cl[kCtlOff + k] = total; total += cl[kCtlCnt + k]; }
+    cl[kCtlOff + nb] = total;
+    // parts per block proportional to its share of the items (>= 1 where there are any), 128 in all (+ rounding)
+    uint32_t t = 0;
+    for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t cnt = cl[kCtlCnt + k];
+        if (!cnt) continue;
+        uint32_t parts = total ? (uint32_t)(((uint64_t)cnt * 128u + total / 2) / total) : 1u;
+        parts = parts < 1u ? 1u : parts;
+        if (t + parts > kListTasks) parts = kListTasks - t;   // (never: sum of max(1, round(128 share)) over <= 32 blocks <= 160)
+        if (!parts) break;
+        const uint32_t per = (cnt + parts - 1) / parts;
+        for (uint32_t p = 0; p < parts && t < kListTasks; p++) {
+            const uint32_t lo = p * per, hi = lo + per < cnt ? lo + per : cnt;
+            if (lo >= hi) break;
+            cl[kCtlTask + 3 * t + 0] = k | (parts << 8);
+            cl[kCtlTask + 3 * t + 1] = cl[kCtlOff + k] + lo;
+            cl[kCtlTask + 3 * t + 2] = hi - lo;
+            t++;
+        }
+        if (t >= kListTasks) break;                        // (cannot drop work: parts were clamped so that every block gets >= 1 task
+    }                                                      //  only while t < kListTasks; nb <= 32 and the proportional parts sum to <= 144)
+    for (; t < kListTasks; t++) cl[kCtlTask + 3 * t + 2] = 0u;
+}
+
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void list_item(const UcnLevel &lv, float *__restrict__ s_acc, float *__restrict__ gtab_level, uint32_t row_lo,
+                                          uint32_t nrows, uint32_t item, size_t B, const float *__restrict__ gl, const float *__restrict__ geom) {
+    const uint32_t b = item & 0x07FFFFFFu, j = (item >> 27) & 7u, c = item >> 30;
+    const float4 q = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + j];
+    float g[C];
+#pragma unroll
+    for (uint32_t cc = 0; cc < C; cc++) g[cc] = gl[(size_t)b * C + cc] / 6.0f;              // d(mean over the 6 multisamples)
+    float fx = fmaf(q.x, lv.scale, 0.5f), fy = fmaf(q.y, lv.scale, 0.5f), fz = fmaf(q.z, lv.scale, 0.5f);
+    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
+    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    const uint32_t yy = y0 + (c & 1u), zz = z0 + (c >> 1);
+    uint32_t i0, i1;
+    if constexpr (HASHED) { const uint32_t h = (yy * kP1) ^ (zz * kP2); i0 = x0 ^ h; i1 = (x0 + 1u) ^ h; }
+    else { const uint32_t h = yy * lv.stride[1] + zz * lv.stride[2]; i0 = x0 * lv.stride[0] + h; i1 = i0 + lv.stride[0]; }
+    uint32_t r0, r1;
+    if constexpr (POW2) { r0 = i0 & lv.mask; r1 = i1 & lv.mask; }
+    else { r0 = i0 < lv.rows ? i0 : i0 % lv.rows; r1 = i1 < lv.rows ? i1 : i1 % lv.rows; }
+    // corner weights in the reference's multiplication order ((wx wy) wz), gridencoder.cu:168-180
+    const float wy = (c & 1u) ? fy : 1.0f - fy, wz = (c >> 1) ? fz : 1.0f - fz;
+    const float damp = erf_pos(q.w * lv.inv_gs);
+    const float w0 = ((1.0f - fx) * wy) * wz, w1 = (fx * wy) * wz;
+    float v0[C], v1[C];
+#pragma unroll
+    for (uint32_t cc = 0; cc < C; cc++) { v0[cc] = (w0 * damp) * g[cc]; v1[cc] = (w1 * damp) * g[cc]; }
+    lds_row_add<C, true>(s_acc, r0 - row_lo, v0);              // the item was routed by r0: always in this block
+    const uint32_t l1 = r1 - row_lo;
+    if (l1 < nrows) lds_row_add<C, true>(s_acc, l1, v1);
+    else {
+#pragma unroll
+        for (uint32_t cc = 0; cc < C; cc++) atomicAdd(gtab_level + (size_t)r1 * C + cc, v1[cc]);      // ~1 in 16 384 items
+    }
+}
+
+// grid (kListTasks, n_fine), 1024 threads, the block's accumulators in LDS
+template <uint32_t C>
+__global__ __launch_bounds__(1024) void k_bwd_list(UcnLevels lvls, ListPlan lp, float *__restrict__ grad_table, uint32_t rpb, size_t B,
+                                                   const float *__restrict__ grad_lm, const float *__restrict__ geom,
+                                                   const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ lists) {
+    extern __shared__ float s_acc[];
+    const uint32_t f = blockIdx.y, lvl = lp.level[f];
+    const uint32_t *cl = ctl + (size_t)f * kCtlPerLevel;
+    const uint32_t n_items = cl[kCtlTask + 3 * blockIdx.x + 2];
+    if (!n_items) return;
+    const uint32_t head = cl[kCtlTask + 3 * blockIdx.x + 0], first = cl[kCtlTask + 3 * blockIdx.x + 1];
+    const uint32_t blk = head & 0xFFu;
+    const UcnLevel lv = lvls.lv[lvl];
+    const uint32_t row_lo = blk * rpb;
+    const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) s_acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t *lst = lists + (size_t)f * lp.cap + first;
+    const float *gl = grad_lm + (size_t)lvl * B * C;
+    float *gtab = grad_table + (size_t)lv.first_row * C;
+    // two items per lane and round: both items' loads are in flight before the first update
+    for (uint32_t i = threadIdx.x; i < n_items; i += 2048u) {
+        const uint32_t it0 = lst[i], i1 = i + 1024u;
+        const bool has1 = i1 < n_items;
+        const uint32_t it1 = has1 ? lst[i1] : 0u;
+        if (lv.hashed) {
+            if (lv.mask) {
+                list_item<C, true, true>(lv, s_acc, gtab, row_lo, nrows, it0, B, gl, geom);
+                if (has1) list_item<C, true, true>(lv, s_acc, gtab, row_lo, nrows, it1, B, gl, geom);
+            } else {
+                list_item<C, true, false>(lv, s_acc, gtab, row_lo, nrows, it0, B, gl, geom);
+                if (has1) list_item<C, true, false>(lv, s_acc, gtab, row_lo, nrows, it1, B, gl, geom);
+            }
+        } else if (lv.mask) {
+            list_item<C, false, true>(lv, s_acc, gtab, row_lo, nrows, it0, B, gl, geom);
+            if (has1) list_item<C, false, true>(lv, s_acc, gtab, row_lo, nrows, it1, B, gl, geom);
+        } else {
+            list_item<C, false, false>(lv, s_acc, gtab, row_lo, nrows, it0, B, gl, geom);
+            if (has1) list_item<C, false, false>(lv, s_acc, gtab, row_lo, nrows, it1, B, gl, geom);
+        }
+    }
+    __syncthreads();
+    float *dst = gtab + (size_t)row_lo * C;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
+        const float v = s_acc[i];
+        if (v != 0.0f) atomicAdd(dst + i, v);      // several workgroups share a block, and the rare cross-block corners of others land here too
     }
 }
 
@@ -1302,13 +1555,42 @@ extern "C" int ucn_contract_probe(const float *means, const float *stds, uint32_
     return 0;
 }
 
+static bool make_list_plan(const UcnLevels &lv, const MaskPlan &plan, uint32_t rpb, size_t B, ListPlan *lp) {
+    lp->n_fine = 0;
+    lp->cap = 24ull * B;
+    if (B >= (1ull << 27)) return false;                     // 27 bits of an item hold the sample
+    for (uint32_t l = 0; l < lv.L; l++)
+        if (!plan.coarse[l]) {
+            lp->level[lp->n_fine] = (uint8_t)l;
+            lp->nb[lp->n_fine] = ucn_div_up(lv.lv[l].rows, rpb);
+            lp->n_fine++;
+        }
+    return lp->n_fine > 0;
+}
+// UCN_BWD_LISTS=1 turns the item-list path on for the fine levels.  OFF by default on measurement (8192 x 128 samples,
+// config B, profiles/r03/bwd_lists.txt): the list kernel takes 1.86 ms for the ten fine levels where the compacted kernel
+// takes 2.9 -- but the counting sort in front of it costs 0.35 (count) + 2.2 ms (scatter: 250 M items = 1 GB written), and the
+// list kernel itself is bound by its three gathers per item (item, 16-byte geometry, 8-byte gradient: 7 GB through the
+// texture-address path), which is what the recomputing kernel avoids: 4.4 ms against 2.9.  Kept as a cross-check of the
+// compacted kernel (same addends, other route; tests/test_full_size.py runs the adjoint test on it).
+static bool bwd_lists_enabled() {
+    static const bool on = getenv("UCN_BWD_LISTS") && atoi(getenv("UCN_BWD_LISTS")) != 0;
+    return on;
+}
+
 extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S) {
     UcnLevels lv;
     if (field_levels(f, &lv)) return 0;
     MaskPlan plan;
-    const bool masks = make_mask_plan(lv, 128u * 1024u / (lv.C * 4u), &plan);
+    const uint32_t rpb = 128u * 1024u / (lv.C * 4u);
+    const bool masks = make_mask_plan(lv, rpb, &plan);
+    const size_t B = (size_t)N * S;
     // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
-    return (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * N * S;
+    uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B;
+    ListPlan lp;
+    if (masks && make_list_plan(lv, plan, rpb, B, &lp))      // + the item lists of the fine levels and their control block
+        n += (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
+    return n;
 }
 
 extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
@@ -1355,9 +1637,38 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             float *glm = layout == 0 ? nullptr : workspace + (24ull + plan.n_planes) * B;     // level-major copy
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
                                grad_features, gs, lv.C, workspace, masks, glm);
+            const float *glv = glm ? glm : grad_features;                                       // [L][B][C]
+            ListPlan lp;
+            const bool lists = bwd_lists_enabled() && make_list_plan(lv, plan, rpb, B, &lp);
+            uint32_t *ctl = nullptr, *items = nullptr;
+            if (lists) {
+                // fine levels: counting sort of (point, (y, z) combination) items into per-block lists, then k_bwd_list
+                ctl = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
+                items = ctl + (((size_t)lp.n_fine * kCtlPerLevel + 63u) & ~(size_t)63u);
+                if (hipMemsetAsync(ctl, 0, (size_t)lp.n_fine * kCtlPerLevel * sizeof(uint32_t), st) != hipSuccess)
+                    return ucn_fail("march_features_backward: hipMemsetAsync failed");
+                plan.skip_fine = 1u;
+                tasks = 0;
+                for (uint32_t l = 0; l < lv.L; l++) {
+                    const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
+                    if (plan.coarse[l]) tasks += nb * bwd_sample_split(nb, plan.wg_target);
+                }
+            }
 #define UCN_MBC(CC)                                                                                              \
-    hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, \
-                       lv, grad_embeddings, N, S, rpb, plan, glm ? glm : grad_features, workspace, masks)
+    do {                                                                                                         \
+        const dim3 bg(ucn_div_up(B, 256), lists ? lp.n_fine : 1u);                                               \
+        if (lists) {                                                                                             \
+            hipLaunchKernelGGL((k_bwd_bin<CC, false>), bg, dim3(256), 0, st, lv, lp, plan.shift, B, workspace, glv, ctl, items); \
+            hipLaunchKernelGGL(k_bwd_bin_scan, dim3(lp.n_fine), dim3(64), 0, st, lp, ctl);                       \
+            hipLaunchKernelGGL((k_bwd_bin<CC, true>), bg, dim3(256), 0, st, lv, lp, plan.shift, B, workspace, glv, ctl, items); \
+        }                                                                                                        \
+        if (tasks)                                                                                               \
+            hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, \
+                               lv, grad_embeddings, N, S, rpb, plan, glv, workspace, masks);                      \
+        if (lists)                                                                                               \
+            hipLaunchKernelGGL(k_bwd_list<CC>, dim3(kListTasks, lp.n_fine), dim3(1024), (size_t)rpb * CC * 4, st, lv, lp, \
+                               grad_embeddings, rpb, B, glv, workspace, ctl, items);                              \
+    } while (0)
             switch (lv.C) {
                 case 1: UCN_MBC(1); break;
                 case 2: UCN_MBC(2); break;
