@@ -228,6 +228,10 @@ def build_model(device, heads=False):
     if heads:                                        # zero latent codes would make every camera's affine map the same
         model.brightness_corr.latent_code.data.normal_(0, 0.1)
         model.brightness_corr.sky_latent_code.data.normal_(0, 0.1)
+        # a default-initialised sky NeRF is DEAD on these rays (alpha_linear's output is negative for every sample: relu(sigma) = 0,
+        # the layer renders exactly 0 and receives exactly zero gradients): lift its density head so that the layer contributes
+        # to the pixels the CPU oracle checks and to the gradients the training step computes
+        model.skynerf.alpha_linear.bias.data.fill_(0.05)
     sd = {k: v.clone() for k, v in model.state_dict().items()}       # CPU copy for the CPU baseline
     return model.to(device).eval(), cfg, sd
 

@@ -319,7 +319,7 @@ class Model(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ('_side_stream', '_prof', '_alive_idx', '_alive_cnt', '_alive_stats', '_mixed_cache'):
+        for k in ('_side_stream', '_sky_stream', '_prof', '_alive_idx', '_alive_cnt', '_alive_stats', '_mixed_cache'):
             state.pop(k, None)
         return state
 
@@ -370,6 +370,7 @@ class Model(nn.Module):
     #                                      model call in accelerator.autocast(), models.py:957) run in the reference's mixed
     #                                      precision: half tables in the gather, dense layers as bf16 MFMAs (the training
     #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
+    sky_side_stream: bool = True         # (with fused_sky_train) the sky branch of a training step on a second HIP stream
     fused_sky_train: bool = True         # training under bf16 autocast runs the sky NeRF on csrc/sky_train.hip (False: eager torch)
     march_route: str = 'auto'            # which march Model.forward runs: 'auto' = the training graph iff self.training and
     #                                      autograd is enabled, else the fused inference march; 'train' / 'inference' force it

@@ -418,7 +418,7 @@ def wgrad(A, B1, B2=None):
     for t in (A, B1) + ((B2,) if B2 is not None else ()):
         assert t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.shape[0] == M and t.shape[1] % 32 == 0, (t.dtype, t.stride(), t.shape)
     n = lib.ucn_wgrad_ws_floats(KA, kb1 + kb2, M)
-    key = str(A.device)
+    key = (str(A.device), torch.cuda.current_stream().cuda_stream)      # one split-K workspace per stream: the sky branch runs beside the field
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = _WGRAD_WS[key] = torch.empty(max(n, 256 * 256 * 288), device=A.device)
@@ -896,6 +896,19 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
     renderings, ray_history = [], []
     sdist_prev = weights_prev = None
     n_prev, prod = 0, 1
+    # The sky NeRF depends on the rays only, not on the field: with `Model.sky_side_stream` its fused forward is issued FIRST, on
+    # a second HIP stream, and joins at the colour-correction step.  Autograd runs a node's backward on the stream of its
+    # forward, so the sky's compositing backward, dgrad kernel and weight-gradient passes (HBM-bound: 4.4 GB of stores, 9 GB of
+    # reads) run beside the field's featurisation backward (VALU / LDS-bound) as well.
+    _sky_pending = None
+    if (getattr(cfg, 'model_sky', False) and model.sky_side_stream and model.fused_sky_train and _sky_fusable(model.skynerf, o)):
+        if getattr(model, '_sky_stream', None) is None:
+            model._sky_stream = torch.cuda.Stream()
+        model._sky_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(model._sky_stream):
+            _sky_pending = sky_forward_fused(model.skynerf, o, d, cam, far)
+        for t in (o, d, cam, far):
+            t.record_stream(model._sky_stream)
     for i_level in range(model.num_levels):
         is_prop = i_level < model.num_levels - 1
         S = model.num_prop_samples if is_prop else model.num_nerf_samples
@@ -970,7 +983,11 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
     with_sky = getattr(cfg, 'model_sky', False)
     if with_sky:
         # under bf16 autocast (what train.py:165 runs): the hand-written sky kernels; else the eager fp32 form (the G10 parity path)
-        sky = (sky_forward_fused if (model.fused_sky_train and _sky_fusable(model.skynerf, o)) else sky_forward)(model.skynerf, o, d, cam, far)
+        sky = _sky_pending if _sky_pending is not None else (
+            sky_forward_fused if (model.fused_sky_train and _sky_fusable(model.skynerf, o)) else sky_forward)(model.skynerf, o, d, cam, far)
+        if _sky_pending is not None:
+            torch.cuda.current_stream().wait_stream(model._sky_stream)
+            sky.record_stream(torch.cuda.current_stream())
         for r in renderings:
             r['sky_rgbs'] = sky
     if getattr(cfg, 'brightness_correction', False):
