@@ -409,6 +409,8 @@ def model_forward(spec: PathSpec, sd, batch, noise: List[LevelNoise], train_frac
                                             batch['cam_dirs'], batch['radii'], nz.rand_vec,
                                             spec.std_scale, nz.flip, nz.spin)
         res = field_forward(fs, sd, means, stds, batch['viewdirs'])
+        if spec.brightness_correction:                                               # models.py:232-235
+            res['rgb'], res['density'] = _GradientScaler.apply(res['rgb'], res['density'], ts.mean(dim=-1))
         weights = alpha_weights(res['density'], tdist, batch['directions'], spec.opaque_background)
         rendering = composite(res['rgb'], weights, tdist, spec.bg_intensity, far, compute_extras)
         rendering['weights'] = weights
@@ -453,6 +455,24 @@ def model_forward(spec: PathSpec, sd, batch, noise: List[LevelNoise], train_frac
             if spec.model_sky:
                 r['affine_trans_sky'] = A_sky
     return renderings, history
+
+
+class _GradientScaler(torch.autograd.Function):
+    """train_utils.py:101-111 `GradientScaler`: identity forward; the gradients of colours and densities are scaled by
+    clamp(mean t of the sample's multisamples ^ 2, 0, 1).  The reference applies it at every level whenever
+    `config.brightness_correction` is on (models.py:232-235) -- found missing here in round 3, when the sky + colour-head
+    training fixture was first compared with this restatement's autograd (field gradients were 7-23 % too large)."""
+
+    @staticmethod
+    def forward(ctx, colors, sigmas, ray_dist):
+        ctx.save_for_backward(ray_dist)
+        return colors.view_as(colors), sigmas.view_as(sigmas)
+
+    @staticmethod
+    def backward(ctx, g_colors, g_sigmas):
+        (ray_dist,) = ctx.saved_tensors
+        scaling = torch.square(ray_dist).clamp(0, 1)
+        return g_colors * scaling[..., None], g_sigmas * scaling, None
 
 
 # ------------------------------------------------------------------- parameter factory

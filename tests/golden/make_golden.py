@@ -262,11 +262,16 @@ def grad_digest(name, g, out, gen):
         out[f'{name}.sample'] = g[rows]
 
 
-def gen_train_step(ref, name, spec, seed):
+def gen_train_step(ref, name, spec, seed, sky_alpha_bias=None):
     """G10: one training step of the REFERENCE -- Model.forward(rand=True) with autograd, the
     reference's own loss functions (train.py:173-216 / train_utils.py), backward -- with every random
-    draw captured.  Stores loss terms and gradient digests."""
+    draw captured.  Stores loss terms and gradient digests.
+    sky_alpha_bias: added to skynerf.alpha_linear.bias before the step (stored in the fixture, helpers.state_for applies it):
+    with the default initialisation the sky NeRF's density head is negative for every sample of these rays, relu(sigma) = 0,
+    and the reference's own step hands the whole sky network EXACTLY ZERO gradients -- a fixture that pins nothing about it."""
     sd = rm.init_state(spec, seed=seed)
+    if sky_alpha_bias is not None:
+        sd['skynerf.alpha_linear.bias'] = sd['skynerf.alpha_linear.bias'] + sky_alpha_bias
     model, cfg = ref_import.build_reference_model(ref, spec, sd)
     model.train()
     n = 96
@@ -294,6 +299,10 @@ def gen_train_step(ref, name, spec, seed):
     total.backward()
     out = dict(seed=torch.tensor(seed), checksum=torch.tensor(state_checksum(sd), dtype=torch.float64),
                train_frac=torch.tensor(train_frac), mse=torch.tensor(stats['mses']))
+    if sky_alpha_bias is not None:
+        out['sky_alpha_bias'] = torch.tensor(float(sky_alpha_bias))
+        alive = {n_: float(p.grad.abs().sum()) for n_, p in model.named_parameters() if n_.startswith('skynerf') and p.grad is not None}
+        assert alive and min(alive.values()) > 0, alive           # the sky network does receive gradients in this fixture
     out.update({'ray_' + k: v for k, v in rays.items()})
     assert len(cap.draws) == 4 * spec.num_levels
     for lvl in range(spec.num_levels):
@@ -326,7 +335,7 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         gen_train_step(ref, 'train_step.npz', rm.make_spec('tiny'), 71)
-        gen_train_step(ref, 'train_step_sky.npz', rm.make_spec('tiny', model_sky=True, brightness_correction=True), 81)
+        gen_train_step(ref, 'train_step_sky.npz', rm.make_spec('tiny', model_sky=True, brightness_correction=True), 81, sky_alpha_bias=0.5)
         sys.exit(0)
     gen_stepfun(ref)
     gen_cast(ref)

@@ -25,6 +25,8 @@ def state_checksum(sd):
 def state_for(fx, spec):
     """Regenerate the fixture's weights from its seed and verify the checksum it recorded."""
     sd = rm.init_state(spec, seed=int(fx["seed"]))
+    if "sky_alpha_bias" in fx:               # fixtures whose sky density head was lifted so that the sky network is alive (make_golden.py)
+        sd["skynerf.alpha_linear.bias"] = sd["skynerf.alpha_linear.bias"] + float(fx["sky_alpha_bias"])
     got = state_checksum(sd)
     want = float(fx["checksum"])
     assert abs(got - want) <= 1e-9 * abs(want), "torch RNG drifted: fixture weights not reproducible"

@@ -72,7 +72,7 @@ def test_loss_functions_match_reference_values(name, over):
         assert abs(0.002 * float(tu.sky_loss(batch, rend)) - float(fx["loss_sky"])) <= 1e-7
 
 
-@pytest.mark.parametrize("name,over", CASES[:1])
+@pytest.mark.parametrize("name,over", CASES)
 def test_oracle_autograd_matches_reference_gradients(name, over):
     fx = H.load(name)
     spec = rm.make_spec("tiny", **over)
