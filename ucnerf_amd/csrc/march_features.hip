@@ -799,25 +799,64 @@ struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
     uint8_t coarse[UCN_MAX_LEVELS];
     uint32_t n_planes, shift;
-    uint32_t wg_target;                    // workgroups per level of the compacted kernel (bwd_sample_split)
+    uint16_t split[UCN_MAX_LEVELS];        // workgroups per row block (cut along the samples): ~128 per level, 256 for the last
     uint32_t skip_fine;                    // 1: the fine levels are taken by the item-list kernels (k_bwd_list), not by bwd_cmp
+    uint8_t order[UCN_MAX_LEVELS];         // levels in the order their workgroups are dispatched: longest workgroups first
 };
+__host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
+    return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
+}
 static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     uint32_t shift = 0;
     while ((1u << shift) < rpb) shift++;
     if ((1u << shift) != rpb) return false;
     mp->shift = shift;
     mp->n_planes = 0;
-    mp->wg_target = 128u;
     mp->skip_fine = 0u;
     for (uint32_t l = 0; l < lv.L; l++) {
         if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
         // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
         // resolution 512, walking consecutive samples in one lane up to 64
-        mp->coarse[l] = lv.lv[l].resolution <= 512u ? 1 : 0;
+        static const uint32_t coarse_res = getenv("UCN_BWD_COARSE_RES") ? (uint32_t)atoi(getenv("UCN_BWD_COARSE_RES")) : 512u;   // experiment knob
+        mp->coarse[l] = lv.lv[l].resolution <= coarse_res ? 1 : 0;
         if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
         mp->plane[l] = (uint16_t)mp->n_planes;
         mp->n_planes += mp->coarse[l] ? 1u : ((lv.lv[l].rows + rpb - 1) / rpb + 3u) / 4u;
+    }
+    // Dispatch order = longest workgroups first, so that the chip drains on short ones (workgroup clocks of the benchmark
+    // grid, tools/bwd_balance.py: in level order the last 1.3 ms of a 4.26 ms kernel ran at 50-85 % occupancy -- the two
+    // finest levels started at 3.1 / 3.4 ms -- where the sum of the workgroup times is 3.70 ms per CU).  Classes by what was
+    // measured per workgroup: unhashed levels of more than two row blocks load their blocks unevenly (the strided fine levels
+    // of the uint32-wrap quirk: 150 ... 1010 us; the dense 65^3 level: 45 ... 890 us) and go first; then the hashed
+    // sample-item levels, finest first (690 / 510 / 420 us); then the hashed point-item levels, coarsest first (600 ... 460 us);
+    // the small dense levels (140 us) fill the tail.
+    uint32_t key[UCN_MAX_LEVELS];
+    for (uint32_t l = 0; l < lv.L; l++) {
+        const uint32_t nb = (lv.lv[l].rows + rpb - 1) / rpb;
+        uint32_t cls, sub;
+        if (!lv.lv[l].hashed && nb > 2u) { cls = 3u; sub = l; }
+        else if (lv.lv[l].hashed && mp->coarse[l]) { cls = 2u; sub = l; }
+        else if (lv.lv[l].hashed) { cls = 1u; sub = UCN_MAX_LEVELS - 1u - l; }
+        else { cls = 0u; sub = l; }
+        key[l] = cls * 256u + sub;
+        mp->order[l] = (uint8_t)l;
+    }
+    for (uint32_t i = 1; i < lv.L; i++)                                    // insertion sort, descending key
+        for (uint32_t j = i; j > 0 && key[mp->order[j]] > key[mp->order[j - 1]]; j--) {
+            const uint8_t t = mp->order[j]; mp->order[j] = mp->order[j - 1]; mp->order[j - 1] = t;
+        }
+    if (getenv("UCN_BWD_LEVEL_ORDER"))                                     // experiment knob: dispatch in level order
+        for (uint32_t l = 0; l < lv.L; l++) mp->order[l] = (uint8_t)l;
+    // ~128 workgroups per level (flat from 128 up, measured); the LAST long level of the order is cut twice as fine: the
+    // chip drains on its workgroups (the small dense levels behind it are 35 ms-CU in all), and half-length ones halve that
+    static const uint32_t wg_target = getenv("UCN_BWD_WGS") && atoi(getenv("UCN_BWD_WGS")) > 0 ? (uint32_t)atoi(getenv("UCN_BWD_WGS")) : 128u;
+    static const bool fine_tail = !getenv("UCN_BWD_NO_FINE_TAIL");       // experiment knobs, both
+    int last_long = -1;
+    for (uint32_t i = 0; i < lv.L; i++)
+        if (key[mp->order[i]] >= 256u) last_long = (int)mp->order[i];
+    for (uint32_t l = 0; l < lv.L; l++) {
+        const uint32_t nb = (lv.lv[l].rows + rpb - 1) / rpb;
+        mp->split[l] = (uint16_t)bwd_sample_split(nb, (fine_tail && (int)l == last_long) ? 2u * wg_target : wg_target);
     }
     return true;
 }
@@ -838,9 +877,11 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
                                                           uint32_t N, uint32_t S, MaskPlan plan,
                                                           const float *__restrict__ grad_features, GradStrides gs, uint32_t C,
                                                           float *__restrict__ geom, uint32_t *__restrict__ masks,
-                                                          float *__restrict__ grad_level_major /*[L][N*S][C] or NULL*/) {
+                                                          float *__restrict__ grad_level_major /*[L][N*S][C] or NULL*/,
+                                                          uint32_t *__restrict__ task_counter) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (b < 8) task_counter[b] = 0u;                      // the compacted kernel's persistent workgroups pull tasks from here
     if (b >= B) return;
     const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
     float u[6][3], rs[6], csum[3], tsum;
@@ -906,10 +947,6 @@ __device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, float *_
             lds_row_add<C, true>(acc, r, v);
         }
     }
-}
-
-__host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
-    return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
 }
 
 template <uint32_t C>
@@ -1119,54 +1156,96 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
     }
 }
 
+#ifdef UCN_WG_CLOCK                                    // tools/bwd_balance.py: start / end time of every workgroup (experiment builds only)
+__device__ uint64_t g_wg_clock[8192][3];
+#endif
+// PERSISTENT workgroups (r03): one per CU, tasks (level, row block, sample part) pulled from a counter in the plan's
+// longest-first order.  With one workgroup per task the hardware dispatcher hands workgroup k to XCD k mod 8 IN ORDER: where
+// task times differ (45 ... 1010 us inside the uneven levels) a full XCD blocks the dispatch for all eight -- the workgroup
+// clocks of the benchmark grid showed 164-208 of 256 CUs busy behind the uneven levels and a 1.3 ms drain at the end
+// (tools/bwd_balance.py: 4.26 ms where the workgroup times sum to 3.70 ms per CU).
 template <uint32_t C>
 __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls, float *__restrict__ grad_table, uint32_t N,
                                                                  uint32_t S, uint32_t rpb, MaskPlan plan,
                                                                  const float *__restrict__ grad_features /*[L][N*S][C]*/,
                                                                  const float *__restrict__ geom,
-                                                                 const uint32_t *__restrict__ masks) {
-    extern __shared__ float s_acc[];
-    uint32_t task = blockIdx.x, lvl = 0, nb = 1, split = 1;
-    for (;; lvl++) {
-        nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
-        split = bwd_sample_split(nb, plan.wg_target);
-        const uint32_t here = (plan.skip_fine && !plan.coarse[lvl]) ? 0u : nb * split;
-        if (task < here) break;
-        if (lvl + 1 == lvls.L) return;                                        // (cannot happen: the grid is the sum of `here`)
-        task -= here;
-    }
-    const UcnLevel lv = lvls.lv[lvl];
-    const uint32_t blk = task / split, part = task % split;
-    const uint32_t row_lo = blk * rpb;
-    const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
-    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) s_acc[i] = 0.0f;
-    __syncthreads();
+                                                                 const uint32_t *__restrict__ masks,
+                                                                 uint32_t *__restrict__ counter, uint32_t total) {
+    extern __shared__ float s_acc[];                      // 128 KiB row block + 16 rings of 2 KiB: all of the CU's 160 KiB
+    for (uint32_t i = threadIdx.x; i < rpb * C; i += 1024u) s_acc[i] = 0.0f;          // a flush leaves zeros behind
     uint32_t *q = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C) + (threadIdx.x >> 6) * kQueue;
+    volatile uint32_t *s_task = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C);   // = wave 0's ring, idle between tasks
     const size_t B = (size_t)N * S;
-    const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? 0u : blk >> 2)) * B;
-    const float *gl = grad_features + (size_t)lvl * B * C;
-#define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
-    if (plan.coarse[lvl] == 2) {                                              // all workgroup-uniform; the coarsest
-        if (lv.mask) UCN_CMP(false, true, true, true);                        // levels are never hashed
-        else UCN_CMP(false, false, true, true);
-    } else if (plan.coarse[lvl]) {
-        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true, false); else UCN_CMP(true, false, true, false); }
-        else { if (lv.mask) UCN_CMP(false, true, true, false); else UCN_CMP(false, false, true, false); }
-    } else {
-        if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false, false); else UCN_CMP(true, false, false, false); }
-        else { if (lv.mask) UCN_CMP(false, true, false, false); else UCN_CMP(false, false, false, false); }
-    }
-#undef UCN_CMP
-    __syncthreads();
-    float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
-    for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
-        const float v = s_acc[i];
-        if (v != 0.0f) {
-            if (split == 1) gtab[i] += v;
-            else atomicAdd(gtab + i, v);
+    // Eight queues, one per XCD: queue y holds the tasks k = y (mod 8), i.e. exactly the workgroups the in-order dispatcher
+    // would have placed on XCD y.  That keeps what the static launch had for free: the `split` parts of all row blocks of a
+    // level that scan the SAME samples (same mask words, geometry, gradients) run on the same XCD and share its L2 -- with one
+    // global queue the point-item levels' workgroups took 650 us instead of 480.  An XCD whose queue is dry steals.
+    const uint32_t home = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (3u << 11)) & 7u;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            uint32_t t = total;
+            for (uint32_t a = 0; a < 8u; a++) {
+                const uint32_t y = (home + a) & 7u;
+                const uint32_t k = atomicAdd(counter + y, 1u) * 8u + y;
+                if (k < total) { t = k; break; }
+            }
+            *s_task = t;
         }
+        __syncthreads();                                                              // (also: zeros / flush of s_acc are done)
+        const uint32_t task0 = __builtin_amdgcn_readfirstlane(*s_task);               // wave-uniform: everything derived stays scalar
+        __syncthreads();                                                              // before wave 0 refills its ring
+        if (task0 >= total) break;
+#ifdef UCN_WG_CLOCK
+        if (threadIdx.x == 0 && task0 < 8192u) g_wg_clock[task0][0] = wall_clock64();
+#endif
+        uint32_t task = task0, lvl = 0, nb = 1, split = 1;
+        for (uint32_t i = 0;; i++) {
+            lvl = plan.order[i];
+            nb = (lvls.lv[lvl].rows + rpb - 1) / rpb;
+            split = plan.split[lvl];
+            const uint32_t here = (plan.skip_fine && !plan.coarse[lvl]) ? 0u : nb * split;
+            if (task < here || i + 1 == lvls.L) break;                               // (`total` is the sum of `here`)
+            task -= here;
+        }
+        const UcnLevel lv = lvls.lv[lvl];
+        const uint32_t blk = task / split, part = task % split;
+        const uint32_t row_lo = blk * rpb;
+        const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
+        const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? 0u : blk >> 2)) * B;
+        const float *gl = grad_features + (size_t)lvl * B * C;
+#define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+        if (plan.coarse[lvl] == 2) {                                          // all workgroup-uniform; the coarsest
+            if (lv.mask) UCN_CMP(false, true, true, true);                    // levels are never hashed
+            else UCN_CMP(false, false, true, true);
+        } else if (plan.coarse[lvl]) {
+            if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true, false); else UCN_CMP(true, false, true, false); }
+            else { if (lv.mask) UCN_CMP(false, true, true, false); else UCN_CMP(false, false, true, false); }
+        } else {
+            if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false, false); else UCN_CMP(true, false, false, false); }
+            else { if (lv.mask) UCN_CMP(false, true, false, false); else UCN_CMP(false, false, false, false); }
+        }
+#undef UCN_CMP
+        __syncthreads();
+        float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
+        for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
+            const float v = s_acc[i];
+            if (v != 0.0f) {
+                s_acc[i] = 0.0f;
+                if (split == 1) gtab[i] += v;
+                else atomicAdd(gtab + i, v);
+            }
+        }
+#ifdef UCN_WG_CLOCK
+        __syncthreads();
+        if (threadIdx.x == 0 && task0 < 8192u) { g_wg_clock[task0][1] = wall_clock64(); g_wg_clock[task0][2] = lvl; }
+#endif
     }
 }
+#ifdef UCN_WG_CLOCK
+extern "C" int ucn_debug_wg_clock(uint64_t *host, uint32_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_clock), (size_t)n * 24u) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fine levels by ITEM LISTS (r03).  In the compacted kernel above every workgroup of a row block scans the block masks of
@@ -1578,6 +1657,21 @@ static bool bwd_lists_enabled() {
     return on;
 }
 
+// CUs of the current device (the persistent backward launches one workgroup per CU)
+static uint32_t device_cu_count() {
+    static thread_local int cached_dev = -1;
+    static thread_local uint32_t cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256u;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached = (uint32_t)n;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S) {
     UcnLevels lv;
     if (field_levels(f, &lv)) return 0;
@@ -1586,7 +1680,7 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     const bool masks = make_mask_plan(lv, rpb, &plan);
     const size_t B = (size_t)N * S;
     // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
-    uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B;
+    uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B + 64u;             // + the task counter
     ListPlan lp;
     if (masks && make_list_plan(lv, plan, rpb, B, &lp))      // + the item lists of the fine levels and their control block
         n += (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
@@ -1625,25 +1719,25 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
         }
         MaskPlan plan;
         if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
-            static const uint32_t wg_target = getenv("UCN_BWD_WGS") ? (uint32_t)atoi(getenv("UCN_BWD_WGS")) : 128u;   // experiment knob
-            plan.wg_target = wg_target ? wg_target : 128u;
             tasks = 0;
             for (uint32_t l = 0; l < lv.L; l++) {
                 const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
-                tasks += nb * bwd_sample_split(nb, plan.wg_target);
+                tasks += nb * plan.split[l];
             }
             // compacting variant: block masks next to the geometry planes, dense items from a per-wave ring in LDS
             uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
             float *glm = layout == 0 ? nullptr : workspace + (24ull + plan.n_planes) * B;     // level-major copy
+            uint32_t *task_counter = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
-                               grad_features, gs, lv.C, workspace, masks, glm);
+                               grad_features, gs, lv.C, workspace, masks, glm, task_counter);
             const float *glv = glm ? glm : grad_features;                                       // [L][B][C]
+            const uint32_t cus = device_cu_count();
             ListPlan lp;
             const bool lists = bwd_lists_enabled() && make_list_plan(lv, plan, rpb, B, &lp);
             uint32_t *ctl = nullptr, *items = nullptr;
             if (lists) {
                 // fine levels: counting sort of (point, (y, z) combination) items into per-block lists, then k_bwd_list
-                ctl = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
+                ctl = task_counter + 64;
                 items = ctl + (((size_t)lp.n_fine * kCtlPerLevel + 63u) & ~(size_t)63u);
                 if (hipMemsetAsync(ctl, 0, (size_t)lp.n_fine * kCtlPerLevel * sizeof(uint32_t), st) != hipSuccess)
                     return ucn_fail("march_features_backward: hipMemsetAsync failed");
@@ -1651,7 +1745,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
                 tasks = 0;
                 for (uint32_t l = 0; l < lv.L; l++) {
                     const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
-                    if (plan.coarse[l]) tasks += nb * bwd_sample_split(nb, plan.wg_target);
+                    if (plan.coarse[l]) tasks += nb * plan.split[l];
                 }
             }
 #define UCN_MBC(CC)                                                                                              \
@@ -1663,8 +1757,9 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             hipLaunchKernelGGL((k_bwd_bin<CC, true>), bg, dim3(256), 0, st, lv, lp, plan.shift, B, workspace, glv, ctl, items); \
         }                                                                                                        \
         if (tasks)                                                                                               \
-            hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks), dim3(1024), (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, \
-                               lv, grad_embeddings, N, S, rpb, plan, glv, workspace, masks);                      \
+            hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks < cus ? tasks : cus), dim3(1024),        \
+                               (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, lv, grad_embeddings, N, S, rpb, plan, glv, \
+                               workspace, masks, task_counter, tasks);                                           \
         if (lists)                                                                                               \
             hipLaunchKernelGGL(k_bwd_list<CC>, dim3(kListTasks, lp.n_fine), dim3(1024), (size_t)rpb * CC * 4, st, lv, lp, \
                                grad_embeddings, rpb, B, glv, workspace, ctl, items);                              \
