@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
                                                           uint32_t N, uint32_t S, MaskPlan plan,
                                                           const float *__restrict__ grad_features, GradStrides gs, uint32_t C,
                                                           float *__restrict__ geom, uint32_t *__restrict__ masks,
-                                                          float *__restrict__ grad_level_major /*[L][N*S][C] or NULL*/,
+                                                          float *__restrict__ grad_level_major /*[L][N*S][C], / 6*/,
                                                           uint32_t *__restrict__ task_counter) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -904,8 +904,10 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         for (uint32_t c = 0; c < C; c++) {
             const float g = grad_features[lvl * gs.level + b * gs.sample + c * gs.chan];
             nz |= g != 0.0f;
-            // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample
-            if (grad_level_major) grad_level_major[((size_t)lvl * B + b) * C + c] = g;
+            // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample,
+            // already divided by the 6 multisamples of the mean (an IEEE division is ~13 VALU instructions per channel;
+            // an item stage would repeat it ~27 times per sample and level)
+            grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
         }
         if (!nz) {
 #pragma unroll
@@ -1036,7 +1038,7 @@ __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, c
                                           const float *__restrict__ geom, float (&u)[6][3], float (&rs)[6], float (&gout)[C]) {
     const uint32_t b = valid ? item & 0x1FFFFFFFu : 0u, j = valid ? item >> 29 : 0u;
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++) gout[c] = gl[(size_t)b * C + c] / 6.0f;               // d(mean over the 6 multisamples)
+    for (uint32_t c = 0; c < C; c++) gout[c] = gl[(size_t)b * C + c];                      // d(mean over the 6 multisamples): / 6 done by k_cast_cache_masks
     if constexpr (COARSE) {
 #pragma unroll
         for (uint32_t jj = 0; jj < 6; jj++) {
@@ -1420,7 +1422,7 @@ __device__ __forceinline__ void list_item(const UcnLevel &lv, float *__restrict_
     const float4 q = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + j];
     float g[C];
 #pragma unroll
-    for (uint32_t cc = 0; cc < C; cc++) g[cc] = gl[(size_t)b * C + cc] / 6.0f;              // d(mean over the 6 multisamples)
+    for (uint32_t cc = 0; cc < C; cc++) g[cc] = gl[(size_t)b * C + cc];                     // d(mean over the 6 multisamples), / 6 by k_cast_cache_masks
     float fx = fmaf(q.x, lv.scale, 0.5f), fy = fmaf(q.y, lv.scale, 0.5f), fz = fmaf(q.z, lv.scale, 0.5f);
     const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
     fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
@@ -1726,11 +1728,11 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             }
             // compacting variant: block masks next to the geometry planes, dense items from a per-wave ring in LDS
             uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
-            float *glm = layout == 0 ? nullptr : workspace + (24ull + plan.n_planes) * B;     // level-major copy
+            float *glm = workspace + (24ull + plan.n_planes) * B;                               // level-major copy, / 6
             uint32_t *task_counter = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
                                grad_features, gs, lv.C, workspace, masks, glm, task_counter);
-            const float *glv = glm ? glm : grad_features;                                       // [L][B][C]
+            const float *glv = glm;                                                             // [L][B][C]
             const uint32_t cus = device_cu_count();
             ListPlan lp;
             const bool lists = bwd_lists_enabled() && make_list_plan(lv, plan, rpb, B, &lp);
