@@ -499,6 +499,12 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # communicator set-up (RCCL builds its rings lazily, seconds on a cold node) stays out of the timed region
+        # even with --warmup 0: one collective of each kind the frame uses
+        w = torch.zeros(8, device=device)
+        dist.all_reduce(w)
+        dist.all_gather_into_tensor(torch.empty(8 * world, device=device), w)
+        torch.cuda.synchronize()
     from ucnerf_amd.internal import models, dist as udist
     if args.mlp_mode is not None:
         models.MLP.mlp_mode = args.mlp_mode
