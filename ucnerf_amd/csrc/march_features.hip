@@ -27,6 +27,7 @@
 //     (correctly-rounded div/sqrt, no contraction), so positions -- and the interpolated features
 //     for given positions -- stay bit-identical to the oracle.
 #include "ucn_common.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -802,6 +803,7 @@ struct MaskPlan {
     uint16_t split[UCN_MAX_LEVELS];        // workgroups per row block (cut along the samples): ~128 per level, 256 for the last
     uint32_t skip_fine;                    // 1: the fine levels are taken by the item-list kernels (k_bwd_list), not by bwd_cmp
     uint8_t order[UCN_MAX_LEVELS];         // levels in the order their workgroups are dispatched: longest workgroups first
+    uint8_t fine_kind[UCN_MAX_LEVELS];     // point-item levels: 0 = ballot-ordered items + corner walk, 1 = lane-ordered items + corner walk, 2 = lane-ordered + (y, z) combinations
 };
 __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
     return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
@@ -820,6 +822,16 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         static const uint32_t coarse_res = getenv("UCN_BWD_COARSE_RES") ? (uint32_t)atoi(getenv("UCN_BWD_COARSE_RES")) : 512u;   // experiment knob
         mp->coarse[l] = lv.lv[l].resolution <= coarse_res ? 1 : 0;
         if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
+        // Point-item levels, three shapes (workgroup clocks per level, tools/bwd_balance.py, ms-CU per level of the benchmark grid):
+        //   0: items appended point by point (six ballots per step), all 8 corners walked          res 1024: 75, 2048: 62, finer: 60-62, strided: 78
+        //   1: items appended lane by lane (popcount + one DPP prefix sum per step: the scan was a third of a fine level)   1024: 120 (!), 2048: 78, finer: 51-55
+        //   2: 1 + the corners taken by (y, z) combinations (point_scatter_combos)                   1024: 120, 2048: 78, finer: 51-55 (shape 1 alone: 58-60), strided: 60
+        // Lane order puts the six points of a sample next to each other in a batch: where they still share lattice cells
+        // (resolution <= 2048 on these rays) their compare-and-swaps collide and fall back to ds_add_f32.
+        mp->fine_kind[l] = 0;
+        if (!mp->coarse[l]) mp->fine_kind[l] = (!lv.lv[l].hashed || lv.lv[l].resolution >= 4096u) ? 2 : 0;
+        static const int force_kind = getenv("UCN_BWD_FINE_KIND") ? atoi(getenv("UCN_BWD_FINE_KIND")) : -1;      // experiment knob
+        if (!mp->coarse[l] && force_kind >= 0 && force_kind <= 2) mp->fine_kind[l] = (uint8_t)force_kind;
         mp->plane[l] = (uint16_t)mp->n_planes;
         mp->n_planes += mp->coarse[l] ? 1u : ((lv.lv[l].rows + rpb - 1) / rpb + 3u) / 4u;
     }
@@ -926,6 +938,93 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
                 mp[(size_t)k * B] = wk;
             }
         }
+    }
+}
+
+// Two rows of the block at once (the x0 / x0 + 1 corners of one (y, z) combination): both reads, then both compare-and-swaps
+// -- two LDS round trips where two lds_row_add calls make four.  A lane whose row is outside the block skips its half.
+template <uint32_t C>
+__device__ __forceinline__ void lds_row_add_pair(float *acc, uint32_t r0, bool in0, const float (&v0)[C], uint32_t r1, bool in1,
+                                                 const float (&v1)[C]) {
+    if constexpr (C % 2u == 0u) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c += 2) {
+            unsigned long long *p0 = reinterpret_cast<unsigned long long *>(acc + r0 * C + c);
+            unsigned long long *p1 = reinterpret_cast<unsigned long long *>(acc + r1 * C + c);
+            unsigned long long s0 = 0ull, s1 = 0ull;
+            if (in0) s0 = *p0;
+            if (in1) s1 = *p1;
+            float2 t0 = __builtin_bit_cast(float2, s0), t1 = __builtin_bit_cast(float2, s1);
+            t0.x += v0[c]; t0.y += v0[c + 1];
+            t1.x += v1[c]; t1.y += v1[c + 1];
+            bool lost0 = false, lost1 = false;
+            if (in0) lost0 = atomicCAS(p0, s0, __builtin_bit_cast(unsigned long long, t0)) != s0;
+            if (in1) lost1 = atomicCAS(p1, s1, __builtin_bit_cast(unsigned long long, t1)) != s1;   // (r1 == r0: loses, correctly)
+            if (lost0) { atomicAdd(acc + r0 * C + c, v0[c]); atomicAdd(acc + r0 * C + c + 1, v0[c + 1]); }
+            if (lost1) { atomicAdd(acc + r1 * C + c, v1[c]); atomicAdd(acc + r1 * C + c + 1, v1[c + 1]); }
+        }
+    } else {
+        if (in0) lds_row_add<C, true>(acc, r0, v0);
+        if (in1) lds_row_add<C, true>(acc, r1, v1);
+    }
+}
+
+// ONE multisample point of a fine level into the workgroup's row block, by (y, z) COMBINATIONS (r03).  A hash scatters the four
+// combinations of a point over four of the 32 row blocks, the x0 / x0 + 1 pair of a combination stays together: of the 8
+// corners ~2 are this block's.  Walking all 8 with 22 % of the lanes active in each costs 8 x (hash, compare, weight, products,
+// two LDS round trips) per wave; here a lane lists its in-block combinations first (4 row pairs, no weights) and the wave loops
+// over "my next combination" -- as many rounds as the busiest lane has combinations (2-3), each with both corners' update in
+// flight together.  Same addends ((w_k damp) g_c, w_k = ((wx wy) wz)) as point_scatter_block.
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void point_scatter_combos(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+                                                     const float (&p)[3], float rsj, const float (&gout)[C]) {
+    if (!in_unit_cube(p[0], p[1], p[2])) return;
+    float fx = fmaf(p[0], lv.scale, 0.5f), fy = fmaf(p[1], lv.scale, 0.5f), fz = fmaf(p[2], lv.scale, 0.5f);
+    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
+    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    uint32_t ya, yb, za, zb, xa, xb;
+    if constexpr (HASHED) {
+        xa = x0; xb = x0 + 1u;
+        ya = y0 * kP1; yb = ya + kP1;
+        za = z0 * kP2; zb = za + kP2;
+    } else {
+        xa = x0 * lv.stride[0]; xb = xa + lv.stride[0];
+        ya = y0 * lv.stride[1]; yb = ya + lv.stride[1];
+        za = z0 * lv.stride[2]; zb = za + lv.stride[2];
+    }
+    auto row_of = [&](uint32_t xv, uint32_t yzv) -> uint32_t {
+        uint32_t idx;
+        if constexpr (HASHED) idx = xv ^ yzv; else idx = xv + yzv;
+        if constexpr (POW2) return idx & lv.mask;
+        else return idx < lv.rows ? idx : idx % lv.rows;
+    };
+    uint32_t pend = 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t yv = (c & 1u) ? yb : ya, zv = (c & 2u) ? zb : za;
+        uint32_t yz;
+        if constexpr (HASHED) yz = yv ^ zv; else yz = yv + zv;
+        const bool hit = (row_of(xa, yz) - row_lo < nrows) || (row_of(xb, yz) - row_lo < nrows);
+        pend |= hit ? 1u << c : 0u;
+    }
+    const float damp = erf_pos(rsj * lv.inv_gs);
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+#ifdef UCN_EXP_NO_UPDATE                                                            // experiment build: everything but the LDS updates
+    if (damp + gx + gy + gz != 12345.0f) pend &= (fx == 77.0f ? 15u : 0u);
+#endif
+    while (pend) {
+        const uint32_t c = (uint32_t)__builtin_ctz(pend);
+        pend &= pend - 1u;
+        const uint32_t yv = (c & 1u) ? yb : ya, zv = (c & 2u) ? zb : za;
+        const float wy = (c & 1u) ? fy : gy, wz = (c & 2u) ? fz : gz;
+        uint32_t yz;
+        if constexpr (HASHED) yz = yv ^ zv; else yz = yv + zv;
+        const uint32_t r0 = row_of(xa, yz) - row_lo, r1 = row_of(xb, yz) - row_lo;
+        const float w0 = ((gx * wy) * wz) * damp, w1 = ((fx * wy) * wz) * damp;
+        float v0[C], v1[C];
+#pragma unroll
+        for (uint32_t cc = 0; cc < C; cc++) { v0[cc] = w0 * gout[cc]; v1[cc] = w1 * gout[cc]; }
+        lds_row_add_pair<C>(acc, r0, r0 < nrows, v0, r1, r1 < nrows, v1);
     }
 }
 
@@ -1051,7 +1150,7 @@ __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, c
     }
 }
 
-template <uint32_t C, bool HASHED, bool POW2, bool COARSE, bool RUNS>
+template <uint32_t C, bool HASHED, bool POW2, bool COARSE, bool RUNS, int FINE = 0>
 __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
                                           uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                           const uint32_t *__restrict__ mp, const float *__restrict__ gl,
@@ -1089,13 +1188,30 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
 #pragma unroll
             for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu] : m;
             m >>= bit0;
+            if constexpr (COARSE || FINE == 0) {
 #pragma unroll
-            for (uint32_t j = 0; j < P; j++) {
-                const bool act = (m >> (4u * j)) & 1u;
-                const uint64_t bal = __ballot(act);
-                const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (act) q[pos & (kQueue - 1u)] = b | (j << 29);
-                tail += (uint32_t)__popcll(bal);
+                for (uint32_t j = 0; j < P; j++) {
+                    const bool act = (m >> (4u * j)) & 1u;
+                    const uint64_t bal = __ballot(act);
+                    const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (act) q[pos & (kQueue - 1u)] = b | (j << 29);
+                    tail += (uint32_t)__popcll(bal);
+                }
+            } else {
+                // a sample hits this block with 0.84 of its 6 points on average: count per lane, one DPP prefix sum per step,
+                // then every lane writes its own items (as many rounds as the busiest lane has hits, ~3) -- six ballot /
+                // mbcnt / predicated-write sections per step were a third of a fine level's time (scan alone: 166 of 490 us)
+                m &= 0x111111u;
+                const uint32_t cnt = (uint32_t)__popc(m);
+                const uint32_t incl = wave_scan_dpp<uint32_t>(cnt);
+                uint32_t pos = tail + incl - cnt;
+                tail += wave_last<uint32_t>(incl);
+                while (m) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    q[pos & (kQueue - 1u)] = b | (bit << 27);                    // bit = 4 j: j lands in bits 29..31
+                    pos++;
+                }
             }
             if (++u == kScan) {
                 u = 0;
@@ -1138,6 +1254,9 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 if (run.have) run_flush<C>(s_acc, row_lo, nrows, run);
             } else {
                 // two items per lane: both items' loads are in flight before the first scatter starts
+#ifdef UCN_EXP_SCAN_ONLY                                                    // experiment build: what the mask scan alone costs
+                if (!COARSE) { head += avail; continue; }
+#endif
                 const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
                 const bool v0 = lane < avail, v1 = lane + 64u < avail;
                 float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
@@ -1145,10 +1264,12 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
                 if (v0) {
                     if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
+                    else if constexpr (FINE == 2) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
                     else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
                 }
                 if (v1) {
                     if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
+                    else if constexpr (FINE == 2) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
                     else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
                 }
             }
@@ -1216,6 +1337,12 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
         const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? 0u : blk >> 2)) * B;
         const float *gl = grad_features + (size_t)lvl * B * C;
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+#define UCN_CMPF(H, P2)                                                                                                      \
+    do {                                                                                                                     \
+        if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom);      \
+        else if (plan.fine_kind[lvl] == 1) cmp_block<C, H, P2, false, false, 1>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom); \
+        else cmp_block<C, H, P2, false, false, 0>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom);           \
+    } while (0)
         if (plan.coarse[lvl] == 2) {                                          // all workgroup-uniform; the coarsest
             if (lv.mask) UCN_CMP(false, true, true, true);                    // levels are never hashed
             else UCN_CMP(false, false, true, true);
@@ -1223,10 +1350,11 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
             if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true, false); else UCN_CMP(true, false, true, false); }
             else { if (lv.mask) UCN_CMP(false, true, true, false); else UCN_CMP(false, false, true, false); }
         } else {
-            if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, false, false); else UCN_CMP(true, false, false, false); }
-            else { if (lv.mask) UCN_CMP(false, true, false, false); else UCN_CMP(false, false, false, false); }
+            if (lv.hashed) { if (lv.mask) UCN_CMPF(true, true); else UCN_CMPF(true, false); }
+            else { if (lv.mask) UCN_CMPF(false, true); else UCN_CMPF(false, false); }
         }
 #undef UCN_CMP
+#undef UCN_CMPF
         __syncthreads();
         float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
         for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
