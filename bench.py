@@ -212,7 +212,7 @@ class Ranks:
         self.num_processes, self.process_index, self.is_main_process = world, rank, rank == 0
 
 
-def build_model(device, heads=False):
+def build_model(device, heads=False, grid="B"):
     """Random-init weights of the reference's architecture (module init laws of models.py:438-483),
     same seed on every rank; hash tables re-drawn ~U(-1,1) so density varies (the
     reference's +-1e-4 table init makes the grid a no-op).  heads=True: BASELINE configs[4] -- the sky NeRF layer
@@ -220,9 +220,12 @@ def build_model(device, heads=False):
     from ucnerf_amd.internal import configs, models
     torch.manual_seed(0)
     cfg = configs.Config(model_sky=True, brightness_correction=True, training_views=210) if heads else configs.Config()
-    kw = dict(grid_level_dim=2, grid_log2_hashmap_size=19)
-    with models.bindings(NerfMLP=dict(grid_disired_resolution=524288, **kw), PropMLP=dict(**kw)):
-        model = models.Model(config=cfg, num_levels=2, num_prop_samples=S_PROP, num_nerf_samples=S_NERF)
+    if grid == "R":                                  # the reference's own waymo.gin: class defaults (L = 10, C = 4, T = 2^21), 128 + 32 samples
+        model = models.Model(config=cfg, num_levels=2, num_prop_samples=128, num_nerf_samples=32)
+    else:
+        kw = dict(grid_level_dim=2, grid_log2_hashmap_size=19)
+        with models.bindings(NerfMLP=dict(grid_disired_resolution=524288, **kw), PropMLP=dict(**kw)):
+            model = models.Model(config=cfg, num_levels=2, num_prop_samples=S_PROP, num_nerf_samples=S_NERF)
     for mlp in (model.nerf_mlp, model.prop_mlp_0):
         mlp.encoder.embeddings.data.uniform_(-1, 1)
     if heads:                                        # zero latent codes would make every camera's affine map the same

@@ -208,3 +208,53 @@ def test_item_list_backward_is_the_same_adjoint():
                         os.path.join(repo, "tests", "test_train_step.py")],
                        capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_backward_of_a_grid_with_more_than_32_row_blocks_per_level():
+    """The reference's own waymo.gin grid (L = 10, C = 4, T = 2^21: 256 row blocks of 8192 rows per hashed level) goes through the
+    row-block kernel as well (multi-word sample masks, march_features.hip `coarse == 3`): same table gradient as the global-atomic
+    kernel (other summation order), and the exact adjoint of the forward, level by level."""
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    model, cfg, sd = bench.build_model(dev, grid="R")
+    rays = bench.frame_rays(dev)
+    n_total = bench.H_IMG * bench.W_IMG
+    flat = {k: v.reshape(n_total, -1) for k, v in rays.items()}
+    n = 4096
+    batch = _pick(flat, n_total, n, seed=11)
+    with torch.no_grad():
+        _, hist = model(False, batch, 1.0, True)
+    for mlp, lvl in ((model.nerf_mlp, -1), (model.prop_mlp_0, 0)):
+        enc = mlp.encoder
+        L, C = enc.num_levels, enc.level_dim
+        assert C == 4 and int(enc._offsets_np[-1] - enc._offsets_np[-2]) == 2 ** 21
+        sdist = hist[lvl]["sdist"].reshape(n, -1).contiguous()
+        S = sdist.shape[1] - 1
+        basis = torch.empty(n, 6, device="cuda")
+        rvec = (batch["rand_vec"][:, 0:3] if lvl == 0 else batch["rand_vec"][:, 3:6]).contiguous()   # (any basis: forward and backward share it)
+        _lib.check(lib.ucn_cone_basis(batch["cam_dirs"].data_ptr(), rvec.data_ptr(), n, basis.data_ptr(), _lib.stream()))
+        near, far, rad = (batch[k].reshape(-1).contiguous() for k in ("near", "far", "radii"))
+        geom = (sdist, near, far, batch["origins"], batch["directions"], basis, rad, None, None)
+        std_scale = float(model.std_scale)
+        g = torch.Generator(device="cuda").manual_seed(12)
+        T2 = torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1
+        d = _lib.UcnField.from_buffer_copy(mlp.field())
+        d.embeddings = T2.data_ptr()
+        f2 = _features(lib, _lib, d, geom, n, S, std_scale, L, C)
+        grad = torch.randn(L, n * S, C, device="cuda", generator=g)
+        grad[:, ::7] = 0.0                                                     # samples without gradient are dropped by the masks
+        ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.field()), n, S), device="cuda")
+        gt, ga = torch.zeros_like(T2), torch.zeros_like(T2)
+        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in geom], std_scale, n, S,
+                                                   0, 0, grad.data_ptr(), gt.data_ptr(), ws.data_ptr(), _lib.stream()))
+        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in geom], std_scale, n, S,
+                                                   1, 0, grad.data_ptr(), ga.data_ptr(), None, _lib.stream()))
+        assert float(gt.abs().max()) > 0
+        assert float((gt - ga).abs().max()) <= 2e-5 * max(1.0, float(ga.abs().max()))
+        off = enc._offsets_np
+        for l in range(L):
+            a = float((grad[l].double() * f2[l].double()).sum())
+            b = float((gt[int(off[l]):int(off[l + 1])].double() * T2[int(off[l]):int(off[l + 1])].double()).sum())
+            s = float((grad[l].double() * f2[l].double()).abs().sum())
+            assert abs(a - b) <= 1e-5 * s, (l, a, b, s)

@@ -9,22 +9,25 @@ _lib.LIB_PATH = os.path.abspath(os.environ["UCN_TOOL_LIB"])
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 dev = torch.device("cuda", 0)
-model, cfg, sd = bench.build_model(dev)
+GRID = os.environ.get("UCN_TOOL_GRID", "B")          # R: the reference's waymo.gin grid (L 10, C 4, T 2^21)
+FIELD = os.environ.get("UCN_TOOL_FIELD", "nerf")      # or prop
+model, cfg, sd = bench.build_model(dev, grid=GRID)
 batch = bench.frame_rays(dev)
-n, S = 8192, 128
+n = 8192
 flat = {k: v.reshape(-1, v.shape[-1])[::(bench.H_IMG * bench.W_IMG) // n][:n].contiguous() for k, v in batch.items()}
 flat["rand_vec"] = torch.randn(n, 6, device=dev)
 with torch.no_grad():
     r, h = model(False, flat, 1.0, True)
-sdist = h[-1]["sdist"].contiguous()
-mlp = model.nerf_mlp
+sdist = h[-1 if FIELD == "nerf" else 0]["sdist"].contiguous()
+S = sdist.shape[-1] - 1
+mlp = model.nerf_mlp if FIELD == "nerf" else model.prop_mlp_0
 enc = mlp.encoder
 basis = torch.empty(n, 6, device=dev)
 _lib.check(lib.ucn_cone_basis(flat["cam_dirs"].data_ptr(), flat["rand_vec"][:, 3:6].contiguous().data_ptr(), n, basis.data_ptr(), _lib.stream()))
 near, far = flat["near"].reshape(-1).contiguous(), flat["far"].reshape(-1).contiguous()
 rad = flat["radii"].reshape(-1).contiguous()
 L = enc.num_levels
-feat = torch.randn(L * n * S * 2, device=dev)
+feat = torch.randn(L * n * S * enc.level_dim, device=dev)
 grad = torch.zeros_like(enc.embeddings)
 fld = mlp.grid_field()
 ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(fld), n, S), device=dev)
@@ -38,9 +41,10 @@ for _ in range(5):
     _lib.check(lib.ucn_march_features_backward(*args))
 e1.record(); torch.cuda.synchronize()
 print(f"whole call (masks + compacted kernel): {e0.elapsed_time(e1) / 5:.3f} ms")
-T = int(os.environ.get("UCN_TOOL_TASKS", "2037"))               # workgroups of the compacted kernel (128 per level, less rounding)
-clk = np.zeros((T, 3), dtype=np.uint64)
-assert raw.ucn_debug_wg_clock(clk.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(T)) == 0
+clk = np.zeros((8192, 3), dtype=np.uint64)                     # one row per task of the compacted kernel; unused rows stay 0
+assert raw.ucn_debug_wg_clock(clk.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(8192)) == 0
+clk = clk[clk[:, 1] > 0]
+T = clk.shape[0]
 t0 = clk[:, 0].min()
 start = (clk[:, 0] - t0).astype(np.float64) / 100.0          # us (100 MHz constant clock)
 end = (clk[:, 1] - t0).astype(np.float64) / 100.0
@@ -49,6 +53,8 @@ print(f"{T} workgroups; kernel span {end.max():.0f} us; sum of workgroup times {
 lv = clk[:, 2].astype(np.int64)
 for l in range(L):
     d = dur[lv == l]
+    if d.size == 0:
+        continue
     print(f"level {l:2d}: {d.size:4d} wgs  mean {d.mean():7.1f} us  max {d.max():7.1f}  min {d.min():7.1f}  sum {d.sum() / 1000:6.2f} ms  first start {start[lv == l].min():7.0f}  last end {end[lv == l].max():7.0f}")
 # how busy the chip is over time: workgroups in flight at 20 sample times
 for q in np.linspace(0, end.max(), 21)[:-1]:

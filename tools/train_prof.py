@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 dev = torch.device("cuda", 0)
 heads = len(sys.argv) > 1 and sys.argv[1] == "heads"
-model, cfg, sd = bench.build_model(dev, heads=heads)
+grid = "R" if len(sys.argv) > 1 and sys.argv[1] == "R" else "B"       # R: the reference's waymo.gin grid (L 10, C 4, T 2^21; 128 + 32 samples)
+model, cfg, sd = bench.build_model(dev, heads=heads, grid=grid)
 batch = bench.frame_rays(dev)
 n = bench.H_IMG * bench.W_IMG
 flat = {k: v.reshape(n, -1) for k, v in batch.items()}

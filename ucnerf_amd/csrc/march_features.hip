@@ -796,6 +796,7 @@ static GradStrides grad_strides(int layout, size_t B, uint32_t L, uint32_t C) {
     return {B * C, C, 1};
 }
 
+constexpr uint32_t kMaxMaskWords = 16;                  // sample-item levels: up to 512 row blocks (16 KiB of LDS in the mask pass)
 struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
     uint8_t coarse[UCN_MAX_LEVELS];
@@ -816,12 +817,19 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     mp->n_planes = 0;
     mp->skip_fine = 0u;
     for (uint32_t l = 0; l < lv.L; l++) {
-        if ((lv.lv[l].rows + rpb - 1) / rpb > 32u) return false;          // 32-bit masks
+        const uint32_t nb_l = (lv.lv[l].rows + rpb - 1) / rpb;
+        if (nb_l > kMaxMaskWords * 32u) return false;                     // (> 512 blocks, e.g. 2^23 rows of C = 4: the atomic fallback)
         // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
         // resolution 512, walking consecutive samples in one lane up to 64
         static const uint32_t coarse_res = getenv("UCN_BWD_COARSE_RES") ? (uint32_t)atoi(getenv("UCN_BWD_COARSE_RES")) : 512u;   // experiment knob
         mp->coarse[l] = lv.lv[l].resolution <= coarse_res ? 1 : 0;
         if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
+        // More than 32 row blocks per level (the reference's own waymo.gin grid: T = 2^21 rows of C = 4 -> 256 blocks of 8192 rows):
+        // the per-point masks of the point-item shapes would need 6 bits x 256 blocks per sample and level, so such a level goes by
+        // SAMPLE items as well -- one bit per (sample, block) in nb / 32 mask words -- with the unmerged per-point scatter (a point's
+        // corners lie in ~4.5 of the 256 blocks: the `any corner in my block` test drops most points before weights and erf).
+        // Before r03 these configurations fell back to the global-atomic kernel: 83.6 of the 88.5 ms of a waymo.gin training step.
+        if (nb_l > 32u && mp->coarse[l] != 2) mp->coarse[l] = 3;         // (the run-merging dense levels keep their shape, with nb / 32 mask words)
         // Point-item levels, three shapes (workgroup clocks per level, tools/bwd_balance.py, ms-CU per level of the benchmark grid):
         //   0: items appended point by point (six ballots per step), all 8 corners walked          res 1024: 75, 2048: 62, finer: 60-62, strided: 78
         //   1: items appended lane by lane (popcount + one DPP prefix sum per step: the scan was a third of a fine level)   1024: 120 (!), 2048: 78, finer: 51-55
@@ -833,7 +841,7 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         static const int force_kind = getenv("UCN_BWD_FINE_KIND") ? atoi(getenv("UCN_BWD_FINE_KIND")) : -1;      // experiment knob
         if (!mp->coarse[l] && force_kind >= 0 && force_kind <= 2) mp->fine_kind[l] = (uint8_t)force_kind;
         mp->plane[l] = (uint16_t)mp->n_planes;
-        mp->n_planes += mp->coarse[l] ? 1u : ((lv.lv[l].rows + rpb - 1) / rpb + 3u) / 4u;
+        mp->n_planes += mp->coarse[l] ? (nb_l + 31u) / 32u : (nb_l + 3u) / 4u;
     }
     // Dispatch order = longest workgroups first, so that the chip drains on short ones (workgroup clocks of the benchmark
     // grid, tools/bwd_balance.py: in level order the last 1.3 ms of a 4.26 ms kernel ran at 50-85 % occupancy -- the two
@@ -846,7 +854,8 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
     for (uint32_t l = 0; l < lv.L; l++) {
         const uint32_t nb = (lv.lv[l].rows + rpb - 1) / rpb;
         uint32_t cls, sub;
-        if (!lv.lv[l].hashed && nb > 2u) { cls = 3u; sub = l; }
+        if (mp->coarse[l] == 3) { cls = 0u; sub = l; }                         // many short workgroups: they fill the tail
+        else if (!lv.lv[l].hashed && nb > 2u) { cls = 3u; sub = l; }
         else if (lv.lv[l].hashed && mp->coarse[l]) { cls = 2u; sub = l; }
         else if (lv.lv[l].hashed) { cls = 1u; sub = UCN_MAX_LEVELS - 1u - l; }
         else { cls = 0u; sub = l; }
@@ -868,6 +877,8 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         if (key[mp->order[i]] >= 256u) last_long = (int)mp->order[i];
     for (uint32_t l = 0; l < lv.L; l++) {
         const uint32_t nb = (lv.lv[l].rows + rpb - 1) / rpb;
+        // (cutting the unevenly loaded levels finer as well was measured -- 2x / 4x / 8x: no gain on either grid; once the order is
+        // longest-first the span follows the SUM of the workgroup times)
         mp->split[l] = (uint16_t)bwd_sample_split(nb, (fine_tail && (int)l == last_long) ? 2u * wg_target : wg_target);
     }
     return true;
@@ -902,16 +913,10 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
     for (uint32_t j = 0; j < 6; j++) {
         reinterpret_cast<float4 *>(geom)[b * 6 + j] = make_float4(u[j][0], u[j][1], u[j][2], rs[j]);
     }
+    __shared__ uint32_t s_words[kMaxMaskWords * 256u];    // [word][thread]: a thread's own column, bank = thread
     for (uint32_t lvl = 0; lvl < lvls.L; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
-        uint32_t m[6];
-#pragma unroll
-        for (uint32_t j = 0; j < 6; j++) {
-            if (lv.hashed) m[j] = lv.mask ? point_block_mask<true, true>(lv, plan.shift, u[j]) : point_block_mask<true, false>(lv, plan.shift, u[j]);
-            else m[j] = lv.mask ? point_block_mask<false, true>(lv, plan.shift, u[j]) : point_block_mask<false, false>(lv, plan.shift, u[j]);
-        }
-        // a sample whose feature gradient on this level is exactly zero contributes nothing: clear its masks here
-        // so that the scanning workgroups never have to look at the gradient
+        const uint32_t nb_l = (lv.rows + (1u << plan.shift) - 1u) >> plan.shift;
         bool nz = false;
         for (uint32_t c = 0; c < C; c++) {
             const float g = grad_features[lvl * gs.level + b * gs.sample + c * gs.chan];
@@ -921,6 +926,37 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             // an item stage would repeat it ~27 times per sample and level)
             grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
         }
+        if (nb_l > 32u) {
+            // one bit per (sample, block) in nb / 32 words: set through the thread's own LDS column (dynamic word index)
+            const uint32_t nw = (nb_l + 31u) / 32u;
+            for (uint32_t k = 0; k < nw; k++) s_words[k * 256u + threadIdx.x] = 0u;
+            if (nz) {
+#pragma unroll
+                for (uint32_t j = 0; j < 6; j++) {
+                    if (!in_unit_cube(u[j][0], u[j][1], u[j][2])) continue;
+                    float fx, fy, fz;
+                    uint32_t rows[8];
+                    if (lv.hashed) { if (lv.mask) corner_rows<true, true>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows); else corner_rows<true, false>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows); }
+                    else { if (lv.mask) corner_rows<false, true>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows); else corner_rows<false, false>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows); }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t blk = rows[k] >> plan.shift;
+                        atomicOr(&s_words[(blk >> 5) * 256u + threadIdx.x], 1u << (blk & 31u));     // ds_or_b32, own column
+                    }
+                }
+            }
+            uint32_t *mpw = masks + (size_t)plan.plane[lvl] * B + b;
+            for (uint32_t k = 0; k < nw; k++) mpw[(size_t)k * B] = s_words[k * 256u + threadIdx.x];
+            continue;
+        }
+        uint32_t m[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6; j++) {
+            if (lv.hashed) m[j] = lv.mask ? point_block_mask<true, true>(lv, plan.shift, u[j]) : point_block_mask<true, false>(lv, plan.shift, u[j]);
+            else m[j] = lv.mask ? point_block_mask<false, true>(lv, plan.shift, u[j]) : point_block_mask<false, false>(lv, plan.shift, u[j]);
+        }
+        // a sample whose feature gradient on this level is exactly zero contributes nothing: clear its masks here
+        // so that the scanning workgroups never have to look at the gradient
         if (!nz) {
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
@@ -1158,7 +1194,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
     // one mask word per sample: coarse levels bit `blk`; fine levels the word of this block's group of four,
     // bit 4 * j + (blk & 3) for multisample j (k_cast_cache_masks)
     constexpr uint32_t P = COARSE ? 1u : 6u;                                  // items a sample can contribute
-    const uint32_t bit0 = COARSE ? blk : (blk & 3u);
+    const uint32_t bit0 = COARSE ? (blk & 31u) : (blk & 3u);
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t head = 0, tail = 0;                                              // wave-uniform ring positions
     const size_t stride = (size_t)split * kScan * 1024u;
@@ -1255,7 +1291,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
             } else {
                 // two items per lane: both items' loads are in flight before the first scatter starts
 #ifdef UCN_EXP_SCAN_ONLY                                                    // experiment build: what the mask scan alone costs
-                if (!COARSE) { head += avail; continue; }
+                if (!RUNS) { head += avail; continue; }
 #endif
                 const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
                 const bool v0 = lane < avail, v1 = lane + 64u < avail;
@@ -1263,12 +1299,12 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0);
                 cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
                 if (v0) {
-                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
+                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, FINE == 0>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
                     else if constexpr (FINE == 2) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
                     else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
                 }
                 if (v1) {
-                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, true>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
+                    if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, FINE == 0>(lv, s_acc, row_lo, nrows, u1, rs1, g1);
                     else if constexpr (FINE == 2) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
                     else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
                 }
@@ -1277,6 +1313,197 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Levels of MORE THAN 32 ROW BLOCKS (the reference's own waymo.gin grid: T = 2^21 rows of C = 4 = 256 blocks of 8192 rows).
+// The masks are one bit per (sample, block); a hit sample has a corner pair in this block with only ~1 of its 6 points
+// (a point's four (y, z) pairs lie in ~4.5 of the 256 blocks), so walking all 48 corners of every hit sample keeps 17 % of the
+// lanes busy in the expensive part (measured: 500 us per workgroup of 262 144 samples, 75 of them the scan).  Two rings per wave
+// instead: ring 1 takes the hit SAMPLES from the scan; stage 1 runs 64 of them, point by point -- geometry, cell, the four
+// pair rows, which of them are mine -- and appends (sample, pair, point set) items to ring 2 (popcount + one DPP prefix sum);
+// stage 2 runs dense batches of ring 2: per point of the set one hash, two weights, one erf; one paired compare-and-swap update per item.
+// Same addends as everywhere ((w_k damp) g_c, w_k = ((wx wy) wz)).
+constexpr uint32_t kRing1 = 128, kRing2 = kQueue - kRing1;                    // 128 + 384 words of a wave's 2 KiB
+
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void wide_pair_rows(const UcnLevel &lv, const float4 &g, float &fx, float &fy, float &fz,
+                                               uint32_t &xa, uint32_t &xb, uint32_t (&yz)[4]) {
+    fx = fmaf(g.x, lv.scale, 0.5f); fy = fmaf(g.y, lv.scale, 0.5f); fz = fmaf(g.z, lv.scale, 0.5f);
+    const uint32_t x0 = (uint32_t)floorf(fx), y0 = (uint32_t)floorf(fy), z0 = (uint32_t)floorf(fz);
+    fx -= (float)x0; fy -= (float)y0; fz -= (float)z0;
+    uint32_t ya, yb, za, zb;
+    if constexpr (HASHED) {
+        xa = x0; xb = x0 + 1u;
+        ya = y0 * kP1; yb = ya + kP1;
+        za = z0 * kP2; zb = za + kP2;
+        yz[0] = ya ^ za; yz[1] = yb ^ za; yz[2] = ya ^ zb; yz[3] = yb ^ zb;
+    } else {
+        xa = x0 * lv.stride[0]; xb = xa + lv.stride[0];
+        ya = y0 * lv.stride[1]; yb = ya + lv.stride[1];
+        za = z0 * lv.stride[2]; zb = za + lv.stride[2];
+        yz[0] = ya + za; yz[1] = yb + za; yz[2] = ya + zb; yz[3] = yb + zb;
+    }
+}
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ uint32_t wide_row(const UcnLevel &lv, uint32_t xv, uint32_t yzv) {
+    uint32_t idx;
+    if constexpr (HASHED) idx = xv ^ yzv; else idx = xv + yzv;
+    if constexpr (POW2) return idx & lv.mask;
+    else return idx < lv.rows ? idx : idx % lv.rows;
+}
+
+// stage 2 of wide_block: dense (sample | pair << 24 | point set << 26) items of ring 2: the points of the set share ONE lattice cell,
+// so the pair's two rows are theirs in common -- their addends are summed in registers and go to the block in one paired update
+// (on the coarser levels all six points of a sample share the cell: six times fewer LDS updates, and none of the same-row
+// collisions that consecutive points of a sample would cause).  (A function, force-inlined at its two call sites: a lambda
+// called from several sites gets outlined by hipcc -- see cmp_block.)
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void wide_drain(const UcnLevel &lv, float *__restrict__ s_acc, const uint32_t *__restrict__ q2, uint32_t &head2,
+                                           uint32_t tail2, uint32_t thr, uint32_t lane, uint32_t row_lo, uint32_t nrows,
+                                           const float *__restrict__ gl, const float *__restrict__ geom) {
+    while (tail2 - head2 >= thr && tail2 != head2) {
+        const uint32_t avail = tail2 - head2 < 64u ? tail2 - head2 : 64u;
+        const bool v = lane < avail;
+        const uint32_t it = v ? q2[(head2 + lane) % kRing2] : 0u;
+        const uint32_t b = it & 0xFFFFFFu, c = (it >> 24) & 3u;
+        uint32_t pts = it >> 26;
+        float gout[C], v0[C], v1[C];
+#pragma unroll
+        for (uint32_t cc = 0; cc < C; cc++) { gout[cc] = gl[(size_t)b * C + cc]; v0[cc] = 0.0f; v1[cc] = 0.0f; }
+        uint32_t r0 = 0u, r1 = 0u;
+        while (pts) {
+            const uint32_t j = (uint32_t)__builtin_ctz(pts);
+            pts &= pts - 1u;
+            const float4 g = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + j];
+            float fx, fy, fz;
+            uint32_t xa, xb, yz[4];
+            wide_pair_rows<C, HASHED, POW2>(lv, g, fx, fy, fz, xa, xb, yz);
+            const uint32_t h = c == 0u ? yz[0] : c == 1u ? yz[1] : c == 2u ? yz[2] : yz[3];
+            const float wy = (c & 1u) ? fy : 1.0f - fy, wz = (c & 2u) ? fz : 1.0f - fz;
+            r0 = wide_row<HASHED, POW2>(lv, xa, h) - row_lo; r1 = wide_row<HASHED, POW2>(lv, xb, h) - row_lo;   // (the same for every point of the set)
+            const float damp = erf_pos(g.w * lv.inv_gs);
+            const float w0 = (((1.0f - fx) * wy) * wz) * damp, w1 = ((fx * wy) * wz) * damp;
+#pragma unroll
+            for (uint32_t cc = 0; cc < C; cc++) { v0[cc] += w0 * gout[cc]; v1[cc] += w1 * gout[cc]; }
+        }
+        if (v) lds_row_add_pair<C>(s_acc, r0, r0 < nrows, v0, r1, r1 < nrows, v1);
+        head2 += avail;
+    }
+}
+
+template <uint32_t C, bool HASHED, bool POW2>
+__device__ __forceinline__ void wide_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
+                                           uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
+                                           const uint32_t *__restrict__ mp, const float *__restrict__ gl,
+                                           const float *__restrict__ geom) {
+    uint32_t *q1 = q, *q2 = q + kRing1;
+    const uint32_t bit0 = blk & 31u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t head1 = 0, tail1 = 0, head2 = 0, tail2 = 0;                      // wave-uniform ring positions
+    const size_t stride = (size_t)split * kScan * 1024u;
+    size_t base = (size_t)part * kScan * 1024u;
+    uint32_t cur[kScan], nxt[kScan];
+#pragma unroll
+    for (uint32_t u = 0; u < kScan; u++) {
+        const size_t b = base + u * 1024u + threadIdx.x;
+        cur[u] = b < B ? mp[b] : 0u;
+    }
+    uint32_t u = 0;
+    bool more = base < B;
+    while (more || tail1 != head1) {
+        if (more) {
+            if (u == 0) {
+                const size_t nb = base + stride;
+#pragma unroll
+                for (uint32_t uu = 0; uu < kScan; uu++) {
+                    const size_t b = nb + uu * 1024u + threadIdx.x;
+                    nxt[uu] = b < B ? mp[b] : 0u;
+                }
+            }
+            const uint32_t b = (uint32_t)(base + u * 1024u + threadIdx.x);
+            uint32_t m = cur[0];
+#pragma unroll
+            for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu] : m;
+            const bool act = (m >> bit0) & 1u;
+            const uint64_t bal = __ballot(act);
+            const uint32_t pos = tail1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (act) q1[pos % kRing1] = b;
+            tail1 += (uint32_t)__popcll(bal);
+            if (++u == kScan) {
+                u = 0;
+                base += stride;
+                more = base < B;
+#pragma unroll
+                for (uint32_t uu = 0; uu < kScan; uu++) cur[uu] = nxt[uu];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // stage 1: <= 63 samples left over + <= 64 appended per scan step <= kRing1
+        const uint32_t thr1 = more ? 64u : 1u;
+        while (tail1 - head1 >= thr1 && tail1 != head1) {
+            const uint32_t avail = tail1 - head1 < 64u ? tail1 - head1 : 64u;
+#ifdef UCN_EXP_SCAN_ONLY                                                        // experiment build: the mask scan alone
+            head1 += avail;
+            continue;
+#endif
+            const bool v = lane < avail;
+            const uint32_t b = v ? q1[(head1 + lane) % kRing1] : 0u;
+            // the next point's geometry is requested before this one is tested (a round is otherwise one exposed load latency).
+            // Consecutive points in one lattice cell form a RUN: its in-block pairs become items only when the cell changes
+            // (or after the sixth point: round 6 flushes), carrying the set of its points.
+            float4 gn = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6];
+            uint32_t run_x = 0u, run_y = 0u, run_z = 0u, run_pend = 0u, run_pts = 0u;
+#pragma unroll 1
+            for (uint32_t j = 0; j < 7; j++) {
+                const float4 g = gn;
+                if (j + 1u < 6u) gn = reinterpret_cast<const float4 *>(geom)[(size_t)b * 6 + j + 1u];
+                uint32_t flush = j == 6u ? run_pend : 0u;
+                if (j < 6u && v && in_unit_cube(g.x, g.y, g.z)) {
+                    float fx, fy, fz;
+                    uint32_t xa, xb, yz[4];
+                    wide_pair_rows<C, HASHED, POW2>(lv, g, fx, fy, fz, xa, xb, yz);
+                    const uint32_t cx = (uint32_t)floorf(fmaf(g.x, lv.scale, 0.5f)), cy = (uint32_t)floorf(fmaf(g.y, lv.scale, 0.5f)),
+                                   cz = (uint32_t)floorf(fmaf(g.z, lv.scale, 0.5f));
+                    if (run_pts != 0u && cx == run_x && cy == run_y && cz == run_z) {
+                        run_pts |= 1u << j;
+                    } else {
+                        flush = run_pend;                                       // (0 for the first point)
+                        uint32_t pend = 0u;
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; c++) {
+                            const bool hit = (wide_row<HASHED, POW2>(lv, xa, yz[c]) - row_lo < nrows) || (wide_row<HASHED, POW2>(lv, xb, yz[c]) - row_lo < nrows);
+                            pend |= hit ? 1u << c : 0u;
+                        }
+                        // the items of the run that ends here carry ITS point set: emit below, then start the new run
+                        const uint32_t old_pts = run_pts;
+                        run_x = cx; run_y = cy; run_z = cz; run_pend = pend;
+                        run_pts = (1u << j) | (old_pts << 8);                   // bits 8..13: the ended run's points, until the emit
+                    }
+                }
+                const uint32_t emit_pts = j == 6u ? run_pts & 63u : run_pts >> 8;
+                run_pts &= 63u;
+                const uint32_t cnt = (uint32_t)__popc(flush);
+                const uint32_t incl = wave_scan_dpp<uint32_t>(cnt);
+                uint32_t pos = tail2 + incl - cnt;
+                tail2 += wave_last<uint32_t>(incl);
+                while (flush) {
+                    const uint32_t c = (uint32_t)__builtin_ctz(flush);
+                    flush &= flush - 1u;
+                    q2[pos % kRing2] = b | (c << 24) | (emit_pts << 26);
+                    pos++;
+                }
+                __builtin_amdgcn_wave_barrier();
+#ifdef UCN_EXP_NO_UPDATE                                                        // experiment build: scan + stage 1, no stage 2
+                head2 = tail2;
+#endif
+                // ring 2: <= 63 left over + <= 256 appended per round <= kRing2
+                wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 64u, lane, row_lo, nrows, gl, geom);
+            }
+            head1 += avail;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 1u, lane, row_lo, nrows, gl, geom);
 }
 
 #ifdef UCN_WG_CLOCK                                    // tools/bwd_balance.py: start / end time of every workgroup (experiment builds only)
@@ -1334,7 +1561,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
         const uint32_t blk = task / split, part = task % split;
         const uint32_t row_lo = blk * rpb;
         const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
-        const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? 0u : blk >> 2)) * B;
+        const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? blk >> 5 : blk >> 2)) * B;
         const float *gl = grad_features + (size_t)lvl * B * C;
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
 #define UCN_CMPF(H, P2)                                                                                                      \
@@ -1346,6 +1573,11 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
         if (plan.coarse[lvl] == 2) {                                          // all workgroup-uniform; the coarsest
             if (lv.mask) UCN_CMP(false, true, true, true);                    // levels are never hashed
             else UCN_CMP(false, false, true, true);
+        } else if (plan.coarse[lvl] == 3) {                                   // > 32 row blocks: sample items, unmerged scatter
+#define UCN_CMPW(H, P2) wide_block<C, H, P2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+            if (lv.hashed) { if (lv.mask) UCN_CMPW(true, true); else UCN_CMPW(true, false); }
+            else { if (lv.mask) UCN_CMPW(false, true); else UCN_CMPW(false, false); }
+#undef UCN_CMPW
         } else if (plan.coarse[lvl]) {
             if (lv.hashed) { if (lv.mask) UCN_CMP(true, true, true, false); else UCN_CMP(true, false, true, false); }
             else { if (lv.mask) UCN_CMP(false, true, true, false); else UCN_CMP(false, false, true, false); }
@@ -1764,6 +1996,11 @@ extern "C" int ucn_contract_probe(const float *means, const float *stds, uint32_
     return 0;
 }
 
+static bool plan_has_wide(const UcnLevels &lv, const MaskPlan &plan) {      // wide_block items hold the sample in 24 bits
+    for (uint32_t l = 0; l < lv.L; l++)
+        if (plan.coarse[l] == 3) return true;
+    return false;
+}
 static bool make_list_plan(const UcnLevels &lv, const MaskPlan &plan, uint32_t rpb, size_t B, ListPlan *lp) {
     lp->n_fine = 0;
     lp->cap = 24ull * B;
@@ -1848,7 +2085,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             tasks += nb * bwd_sample_split(nb);
         }
         MaskPlan plan;
-        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan)) {
+        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) {
             tasks = 0;
             for (uint32_t l = 0; l < lv.L; l++) {
                 const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
