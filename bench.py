@@ -695,7 +695,14 @@ def main():
                 # what the reference's shipped launch trains: sky NeRF + colour-correction head on (train_waymo.sh:11-12)
                 hmodel, _, _ = build_model(device, heads=True)
                 res["train_step_sky"] = train_step_ms(hmodel, flat, device, heads=True)
-                del hmodel, flat
+                del hmodel
+                torch.cuda.empty_cache()
+                # the same step on the reference's OWN grid (waymo.gin / class defaults: L = 10, C = 4, T = 2^21 -- 256 row blocks
+                # per hashed level -- and 128 + 32 samples): not a BASELINE config, but what a user of the reference trains
+                rmodel, _, _ = build_model(device, grid="R")
+                res["train_step_waymo_gin_grid"] = dict(train_step_ms(rmodel, flat, device, steps=8),
+                                                        grid="L 10, C 4, T 2^21 (240 + 106 MB tables), 128 + 32 samples")
+                del rmodel, flat
                 torch.cuda.empty_cache()
                 # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
                 res["configs"] = {
