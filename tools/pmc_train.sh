@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 PMC passes over bench.py's training step (tools/train_prof.py); same recipe as pmc_passes.sh.
+# rocprofv3 PMC passes over bench.py's training step (tools/train_prof.py [heads | R] as $2); same recipe as pmc_passes.sh.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-pmc_train}
 OUT=$R/gpurun_out/$TAG
@@ -11,7 +11,7 @@ for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_AC
            "SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_INST_CYCLES_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- python $R/tools/train_prof.py > $OUT/pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- python $R/tools/train_prof.py $2 > $OUT/pmc_$i.log 2>&1
   echo "pass $i ($set): rc=$?"
   rm -f $OUT/pmc_$i/p_kernel_trace.csv
 done
