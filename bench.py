@@ -239,12 +239,12 @@ def build_model(device, heads=False, grid="B"):
     return model.to(device).eval(), cfg, sd
 
 
-def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192, heads=False, eval_camidx=None):
+def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192, heads=False, eval_camidx=None, grid="B"):
     """The reference's path on the host cores: oracle/raymarch.py (== reference Python, bit-exact in
     the authoring container) + oracle/grid_oracle.c for the CUDA-only grid op, same rays / weights.
     This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check)."""
     from oracle import raymarch as rm
-    spec = rm.make_spec("B", model_sky=True, brightness_correction=True, training_views=210) if heads else rm.make_spec("B")
+    spec = rm.make_spec(grid, model_sky=True, brightness_correction=True, training_views=210) if heads else rm.make_spec(grid)
     # torch-CPU eager ops stop scaling (and regress) beyond a few dozen threads on these small tensors:
     # 256 threads measured 82 rays/s on the MI355X host; 32 is the better configuration for the baseline.
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -271,12 +271,12 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192
                 rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
 
 
-def render_config(device, cameras, heads, autocast, n_cpu=8192):
+def render_config(device, cameras, heads, autocast, n_cpu=8192, grid="B"):
     """One more BASELINE config through exactly the headline's code path (render_image on a full frame resident in HBM,
     one warm-up frame + one timed frame), with its own CPU-oracle check on n_cpu rays of that frame -- so that the
     driver's bench line carries rays/s AND the RGB L-inf for configs[3] / configs[4], not only builder-run files."""
     from ucnerf_amd.internal import models
-    model, cfg, sd = build_model(device, heads=heads)
+    model, cfg, sd = build_model(device, heads=heads, grid=grid)
     cfg.render_ray_tile = 8
     cfg.render_gather_weights = False
     batch = frame_rays(device, cameras, virtual=heads)
@@ -296,7 +296,7 @@ def render_config(device, cameras, heads, autocast, n_cpu=8192):
     dt = time.perf_counter() - t0
     flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
     cpu = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=heads,
-                       eval_camidx=eval_camidx if heads else None, n_sample=n_cpu)
+                       eval_camidx=eval_camidx if heads else None, n_sample=n_cpu, grid=grid)
     res = dict(rays=n_rays, cameras=cameras, ms_per_frame=dt * 1e3, rays_per_s=n_rays / dt, steps=1, warmup=1,
                dtype=DTYPE_MIXED if autocast else DTYPE_F32_CLASS,
                rgb_linf_gpu_vs_cpu=cpu["rgb_linf_gpu_vs_cpu"], psnr_gpu_vs_cpu=cpu["psnr_gpu_vs_cpu"],
@@ -709,6 +709,8 @@ def main():
                     "configs[3] 5-camera frame, fp32-class": render_config(device, 5, heads=False, autocast=False),
                     "configs[4] 5 cameras virtual poses + sky + colour head, fp32-class": render_config(device, 5, heads=True, autocast=False),
                     "configs[4] same, mixed bf16/fp32 (autocast)": render_config(device, 5, heads=True, autocast=True),
+                    # not a BASELINE config: one frame on the reference's own waymo.gin grid (L 10, C 4, T 2^21; 128 + 32 samples)
+                    "waymo.gin grid, 1 camera, fp32-class": render_config(device, 1, heads=False, autocast=False, grid="R"),
                 }
         print(json.dumps(res))
     if world > 1:
