@@ -404,7 +404,8 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False)
     cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
                                 anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
                                 hash_decay_mults=0.1, disable_multiscale_loss=False, sky_weight=0.002, idt_weight=0.002)
-    g = torch.Generator(device=device).manual_seed(2)
+    seed = 2 + (torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0)
+    g = torch.Generator(device=device).manual_seed(seed)        # every rank its own rays (datasets.py:278)
     opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)   # = create_optimizer (train_utils.py:347)
     model.train()
     times = []
@@ -712,9 +713,37 @@ def main():
                     # not a BASELINE config: one frame on the reference's own waymo.gin grid (L 10, C 4, T 2^21; 128 + 32 samples)
                     "waymo.gin grid, 1 camera, fp32-class": render_config(device, 1, heads=False, autocast=False, grid="R"),
                 }
+    if world > 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
+        # every rank takes part (collectives in the backward); after the timed render, outside it
+        flat_t = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+        ddp_res = ddp_train_step(device, flat_t, world, rank)
+        if rank == 0:
+            res["train_step_ddp"] = ddp_res
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def ddp_train_step(device, flat, world, rank, steps=8):
+    """BASELINE's second metric at N > 1: the training step under DistributedDataParallel (what accelerator.prepare hands to
+    train.py:95), 8192 rays per step over ALL ranks (each rank draws its 8192 / N, datasets.py:278), dense gradients
+    all-reduced over RCCL in one 128 MB bucket (internal/dist.py wrap_ddp).  Every rank calls this; the MAX over ranks of the
+    median step time is reported.  Never raises: a failure comes back as {"error": ...} so that the headline line survives."""
+    try:
+        from ucnerf_amd.internal import dist as udist
+        model, _, _ = build_model(device)
+        ddp = udist.wrap_ddp(model, device_ids=[device.index])
+        r = train_step_ms(ddp, flat, device, n_rays=8192 // world, steps=steps)
+        t = torch.tensor([r["ms"]], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        del ddp, model
+        torch.cuda.empty_cache()
+        return dict(ms=float(t.item()), rays=8192 // world * world, rays_per_rank=8192 // world, n_gpus=world, steps=steps,
+                    rays_per_s=(8192 // world * world) / (float(t.item()) * 1e-3),
+                    gradients="dense all-reduce, one 128 MB bucket, gradient_as_bucket_view (wrap_ddp)", autocast=r["autocast"])
+    except Exception as e:                                        # noqa: BLE001 -- reported, not raised (see docstring)
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
 if __name__ == "__main__":

@@ -191,6 +191,9 @@ def test_bench_two_ranks_flow_on_one_gpu():
     assert 1e5 < r["value"] < 2e7 and abs(r["value"] - 1280 * 1920 / (r["ms_per_step"] * 1e-3)) <= 1e-3 * r["value"]
     assert r["roofline"]["bound"] in ("hbm", "mfma") and 0 < r["roofline"]["frac"] <= 1.2
     assert "cpu_baseline" not in r and "train_step" not in r          # rank-0-at-N=1-only extras stay out of the N > 1 line
+    d = r["train_step_ddp"]                                            # BASELINE's second metric at N > 1: the DDP training step
+    assert "error" not in d, d
+    assert d["n_gpus"] == 2 and d["rays"] == 8192 and d["rays_per_rank"] == 4096 and 1.0 < d["ms"] < 2000.0
 
 
 def test_item_list_backward_is_the_same_adjoint():
