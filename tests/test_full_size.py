@@ -261,3 +261,16 @@ def test_backward_of_a_grid_with_more_than_32_row_blocks_per_level():
             b = float((gt[int(off[l]):int(off[l + 1])].double() * T2[int(off[l]):int(off[l + 1])].double()).sum())
             s = float((grad[l].double() * f2[l].double()).abs().sum())
             assert abs(a - b) <= 1e-5 * s, (l, a, b, s)
+
+
+def test_table_gradient_over_random_grid_shapes():
+    """tools/fuzz_backward_grids.py: the row-block table gradient (persistent workgroups; point items, sample items, the path for
+    levels of more than 32 row blocks) == the global-atomic kernel over random (L, C, T, resolutions, N, S): C = 1 / 2 / 4 / 8, 1 to 256
+    blocks per level, dense / hashed / strided levels, N * S from 1 to 640 000, zero-gradient samples, rays outside the unit cube."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_backward_grids.py"), "32"], capture_output=True, text=True,
+                       timeout=900, cwd=repo)
+    assert p.returncode == 0 and "mismatches: 0" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
