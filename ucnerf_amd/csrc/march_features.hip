@@ -809,7 +809,7 @@ struct MaskPlan {
 __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
     return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
 }
-static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
+static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan *mp) {
     uint32_t shift = 0;
     while ((1u << shift) < rpb) shift++;
     if ((1u << shift) != rpb) return false;
@@ -841,7 +841,13 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         static const int force_kind = getenv("UCN_BWD_FINE_KIND") ? atoi(getenv("UCN_BWD_FINE_KIND")) : -1;      // experiment knob
         if (!mp->coarse[l] && force_kind >= 0 && force_kind <= 2) mp->fine_kind[l] = (uint8_t)force_kind;
         mp->plane[l] = (uint16_t)mp->n_planes;
-        mp->n_planes += mp->coarse[l] ? (nb_l + 31u) / 32u : (nb_l + 3u) / 4u;
+        if (mp->coarse[l] == 3) {
+            // bit planes: [block][ceil(B / 64)] 64-bit words (one bit per sample) = nb x 2 x ceil(B / 64) 32-bit words, in units of B
+            const uint64_t words = (uint64_t)nb_l * 2u * ((B + 63u) / 64u);
+            mp->n_planes += (uint32_t)((words + B - 1u) / (B ? B : 1u));
+        } else {
+            mp->n_planes += mp->coarse[l] ? (nb_l + 31u) / 32u : (nb_l + 3u) / 4u;
+        }
     }
     // Dispatch order = longest workgroups first, so that the chip drains on short ones (workgroup clocks of the benchmark
     // grid, tools/bwd_balance.py: in level order the last 1.3 ms of a 4.26 ms kernel ran at 50-85 % occupancy -- the two
@@ -877,9 +883,11 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, MaskPlan *mp) {
         if (key[mp->order[i]] >= 256u) last_long = (int)mp->order[i];
     for (uint32_t l = 0; l < lv.L; l++) {
         const uint32_t nb = (lv.lv[l].rows + rpb - 1) / rpb;
-        // (cutting the unevenly loaded levels finer as well was measured -- 2x / 4x / 8x: no gain on either grid; once the order is
-        // longest-first the span follows the SUM of the workgroup times)
-        mp->split[l] = (uint16_t)bwd_sample_split(nb, (fine_tail && (int)l == last_long) ? 2u * wg_target : wg_target);
+        // ... and the unevenly loaded levels finer as well: their hottest block sets the longest workgroup of the call (waymo.gin's
+        // proposal grid, 1 M samples: one 4.7 ms workgroup of the dense 65^3 level against 2.4 ms-CU of work per CU)
+        static const uint32_t uneven_mult = getenv("UCN_BWD_UNEVEN_MULT") ? (uint32_t)atoi(getenv("UCN_BWD_UNEVEN_MULT")) : 2u;   // experiment knob (1 / 2 / 4 / 8 measured: 2)
+        const uint32_t mult = key[l] >= 3u * 256u ? (uneven_mult ? uneven_mult : 1u) : ((fine_tail && (int)l == last_long) ? 2u : 1u);
+        mp->split[l] = (uint16_t)bwd_sample_split(nb, mult * wg_target);
     }
     return true;
 }
@@ -905,13 +913,17 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b < 8) task_counter[b] = 0u;                      // the compacted kernel's persistent workgroups pull tasks from here
-    if (b >= B) return;
-    const uint32_t ray = (uint32_t)(b / S), s = (uint32_t)(b - (size_t)ray * S);
+    if ((b & ~(size_t)63) >= B) return;                   // whole waves only: the bit planes below are built by wave ballots
+    const bool valid = b < B;
+    const size_t bb = valid ? b : B - 1;                  // lanes past the end recompute the last sample and store nothing
+    const uint32_t ray = (uint32_t)(bb / S), s = (uint32_t)(bb - (size_t)ray * S);
     float u[6][3], rs[6], csum[3], tsum;
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
+    if (valid) {
 #pragma unroll
-    for (uint32_t j = 0; j < 6; j++) {
-        reinterpret_cast<float4 *>(geom)[b * 6 + j] = make_float4(u[j][0], u[j][1], u[j][2], rs[j]);
+        for (uint32_t j = 0; j < 6; j++) {
+            reinterpret_cast<float4 *>(geom)[b * 6 + j] = make_float4(u[j][0], u[j][1], u[j][2], rs[j]);
+        }
     }
     __shared__ uint32_t s_words[kMaxMaskWords * 256u];    // [word][thread]: a thread's own column, bank = thread
     for (uint32_t lvl = 0; lvl < lvls.L; lvl++) {
@@ -919,12 +931,12 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         const uint32_t nb_l = (lv.rows + (1u << plan.shift) - 1u) >> plan.shift;
         bool nz = false;
         for (uint32_t c = 0; c < C; c++) {
-            const float g = grad_features[lvl * gs.level + b * gs.sample + c * gs.chan];
-            nz |= g != 0.0f;
+            const float g = grad_features[lvl * gs.level + bb * gs.sample + c * gs.chan];
+            nz |= valid && g != 0.0f;
             // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample,
             // already divided by the 6 multisamples of the mean (an IEEE division is ~13 VALU instructions per channel;
             // an item stage would repeat it ~27 times per sample and level)
-            grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
+            if (valid) grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
         }
         if (nb_l > 32u) {
             // one bit per (sample, block) in nb / 32 words: set through the thread's own LDS column (dynamic word index)
@@ -945,8 +957,34 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
                     }
                 }
             }
-            uint32_t *mpw = masks + (size_t)plan.plane[lvl] * B + b;
-            for (uint32_t k = 0; k < nw; k++) mpw[(size_t)k * B] = s_words[k * 256u + threadIdx.x];
+            if (plan.coarse[lvl] == 3) {
+                // wide_block's layout: BIT PLANES [block][ceil(B / 64)] x 64 bits, one bit per sample -- the scanning workgroup of
+                // a block then reads B / 8 bytes instead of 4 B (measured in place with phase clocks: the word-per-sample scan
+                // was HALF of such a workgroup's time, one exposed load latency per 4096 samples).  A wave = 64 consecutive
+                // samples: 32 ballots per mask word, lane i keeps the ballot of block 32 w + i.
+                const uint32_t lane = threadIdx.x & 63u;
+                const size_t B64 = (B + 63u) / 64u, wave_global = b >> 6;
+                uint32_t *T = masks + (size_t)plan.plane[lvl] * B;
+                for (uint32_t w = 0; w < nw; w++) {
+                    const uint32_t word = s_words[w * 256u + threadIdx.x];
+                    uint32_t keep_lo = 0u, keep_hi = 0u;
+#pragma unroll
+                    for (uint32_t bit = 0; bit < 32u; bit++) {
+                        const uint64_t bal = __ballot((word >> bit) & 1u);
+                        if (lane == bit) { keep_lo = (uint32_t)bal; keep_hi = (uint32_t)(bal >> 32); }
+                    }
+                    const uint32_t blk = w * 32u + lane;
+                    if (lane < 32u && blk < nb_l) {
+                        T[((size_t)blk * B64 + wave_global) * 2u] = keep_lo;
+                        T[((size_t)blk * B64 + wave_global) * 2u + 1u] = keep_hi;
+                    }
+                }
+                continue;
+            }
+            if (valid) {
+                uint32_t *mpw = masks + (size_t)plan.plane[lvl] * B + b;
+                for (uint32_t k = 0; k < nw; k++) mpw[(size_t)k * B] = s_words[k * 256u + threadIdx.x];
+            }
             continue;
         }
         uint32_t m[6];
@@ -961,6 +999,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
         }
+        if (!valid) continue;
         uint32_t *mp = masks + (size_t)plan.plane[lvl] * B + b;
         if (plan.coarse[lvl]) {
             mp[0] = m[0] | m[1] | m[2] | m[3] | m[4] | m[5];
@@ -1391,54 +1430,71 @@ __device__ __forceinline__ void wide_drain(const UcnLevel &lv, float *__restrict
     }
 }
 
+template <uint32_t K>
+__device__ __forceinline__ void wide_load_group(const uint32_t *__restrict__ T, size_t first, size_t wstride, size_t B64,
+                                                uint32_t (&lo)[K], uint32_t (&hi)[K]) {
+#pragma unroll
+    for (uint32_t i = 0; i < K; i++) {
+        const size_t w = first + i * wstride;
+        lo[i] = w < B64 ? T[w * 2u] : 0u;
+        hi[i] = w < B64 ? T[w * 2u + 1u] : 0u;
+    }
+}
+
 template <uint32_t C, bool HASHED, bool POW2>
 __device__ __forceinline__ void wide_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
                                            uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                            const uint32_t *__restrict__ mp, const float *__restrict__ gl,
                                            const float *__restrict__ geom) {
     uint32_t *q1 = q, *q2 = q + kRing1;
-    const uint32_t bit0 = blk & 31u;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t head1 = 0, tail1 = 0, head2 = 0, tail2 = 0;                      // wave-uniform ring positions
-    const size_t stride = (size_t)split * kScan * 1024u;
-    size_t base = (size_t)part * kScan * 1024u;
-    uint32_t cur[kScan], nxt[kScan];
-#pragma unroll
-    for (uint32_t u = 0; u < kScan; u++) {
-        const size_t b = base + u * 1024u + threadIdx.x;
-        cur[u] = b < B ? mp[b] : 0u;
-    }
-    uint32_t u = 0;
-    bool more = base < B;
+    // the block's bit plane (k_cast_cache_masks): bit i of 64-bit word w = sample 64 w + i.  A lane takes the words
+    // part + split (1024 k + thread), k = 0, 1, ...: kWords of them are loaded together, the next group is requested before this
+    // one is searched.  One round = every lane with bits left hands over its lowest one (<= 64 samples into ring 1).
+    constexpr uint32_t kWords = 4;
+    const size_t B64 = (B + 63u) / 64u;
+    const uint32_t *T = mp + (size_t)blk * B64 * 2u;
+    const size_t wstride = (size_t)split * 1024u, w0 = (size_t)part + (size_t)split * threadIdx.x;
+    uint32_t clo[kWords], chi[kWords], nlo[kWords], nhi[kWords];
+    size_t gfirst = w0;                                                        // this lane's first word of the current group
+    wide_load_group<kWords>(T, gfirst, wstride, B64, clo, chi);
+    bool more = (size_t)part + (size_t)split * (threadIdx.x & ~63u) < B64;     // wave-uniform: the wave's first word exists
+    uint32_t wi = 0;                                                           // word of the group being searched
+    uint32_t lo = 0u, hi = 0u;
+    bool fresh = true;                                                         // take the next word of the group
     while (more || tail1 != head1) {
         if (more) {
-            if (u == 0) {
-                const size_t nb = base + stride;
+            if (fresh) {
+                if (wi == 0) wide_load_group<kWords>(T, gfirst + kWords * wstride, wstride, B64, nlo, nhi);
+                lo = clo[0]; hi = chi[0];
 #pragma unroll
-                for (uint32_t uu = 0; uu < kScan; uu++) {
-                    const size_t b = nb + uu * 1024u + threadIdx.x;
-                    nxt[uu] = b < B ? mp[b] : 0u;
-                }
+                for (uint32_t i = 1; i < kWords; i++) { lo = wi == i ? clo[i] : lo; hi = wi == i ? chi[i] : hi; }
+                fresh = false;
             }
-            const uint32_t b = (uint32_t)(base + u * 1024u + threadIdx.x);
-            uint32_t m = cur[0];
-#pragma unroll
-            for (uint32_t uu = 1; uu < kScan; uu++) m = u == uu ? cur[uu] : m;
-            const bool act = (m >> bit0) & 1u;
+            const bool act = (lo | hi) != 0u;
+            uint32_t bit = lo ? (uint32_t)__builtin_ctz(lo) : 32u + (uint32_t)__builtin_ctz(hi | 0x80000000u * (hi == 0u));
+            const size_t w = gfirst + wi * wstride;
+            const uint32_t b = (uint32_t)(w * 64u + bit);
+            if (lo) lo &= lo - 1u; else hi &= hi - 1u;
             const uint64_t bal = __ballot(act);
             const uint32_t pos = tail1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             if (act) q1[pos % kRing1] = b;
             tail1 += (uint32_t)__popcll(bal);
-            if (++u == kScan) {
-                u = 0;
-                base += stride;
-                more = base < B;
+            if (__ballot((lo | hi) != 0u) == 0ull) {                           // every lane is through with its word
+                fresh = true;
+                if (++wi == kWords) {
+                    wi = 0;
+                    gfirst += kWords * wstride;
 #pragma unroll
-                for (uint32_t uu = 0; uu < kScan; uu++) cur[uu] = nxt[uu];
+                    for (uint32_t i = 0; i < kWords; i++) { clo[i] = nlo[i]; chi[i] = nhi[i]; }
+                    // the first lane's first word of the new group decides for the wave (its words come first)
+                    more = (size_t)part + (size_t)split * (threadIdx.x & ~63u) + (gfirst - w0) < B64;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // stage 1: <= 63 samples left over + <= 64 appended per scan step <= kRing1
+        // stage 1: <= 63 samples left over + <= 64 appended per round <= kRing1
         const uint32_t thr1 = more ? 64u : 1u;
         while (tail1 - head1 >= thr1 && tail1 != head1) {
             const uint32_t avail = tail1 - head1 < 64u ? tail1 - head1 : 64u;
@@ -1574,7 +1630,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
             if (lv.mask) UCN_CMP(false, true, true, true);                    // levels are never hashed
             else UCN_CMP(false, false, true, true);
         } else if (plan.coarse[lvl] == 3) {                                   // > 32 row blocks: sample items, unmerged scatter
-#define UCN_CMPW(H, P2) wide_block<C, H, P2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+#define UCN_CMPW(H, P2) wide_block<C, H, P2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, masks + (size_t)plan.plane[lvl] * B, gl, geom)
             if (lv.hashed) { if (lv.mask) UCN_CMPW(true, true); else UCN_CMPW(true, false); }
             else { if (lv.mask) UCN_CMPW(false, true); else UCN_CMPW(false, false); }
 #undef UCN_CMPW
@@ -2044,8 +2100,8 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     if (field_levels(f, &lv)) return 0;
     MaskPlan plan;
     const uint32_t rpb = 128u * 1024u / (lv.C * 4u);
-    const bool masks = make_mask_plan(lv, rpb, &plan);
     const size_t B = (size_t)N * S;
+    const bool masks = make_mask_plan(lv, rpb, B, &plan);
     // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
     uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B + 64u;             // + the task counter
     ListPlan lp;
@@ -2085,7 +2141,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             tasks += nb * bwd_sample_split(nb);
         }
         MaskPlan plan;
-        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, &plan) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) {
+        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, B, &plan) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) {
             tasks = 0;
             for (uint32_t l = 0; l < lv.L; l++) {
                 const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
