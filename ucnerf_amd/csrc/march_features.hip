@@ -1205,7 +1205,10 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
 // a global load + vmcnt(0) in front of every point -- and the LDS base came from the dynamic-LDS offset table,
 // an s_load per corner; that version spent 80 % of its time waiting on those.)
 constexpr uint32_t kQueue = 512;                               // items per wave; 16 waves x 2 KiB beside the 128 KiB block
-constexpr uint32_t kScan = 4;                                  // samples per thread and scan step
+#ifndef UCN_KSCAN
+#define UCN_KSCAN 4
+#endif
+constexpr uint32_t kScan = UCN_KSCAN;                          // samples per thread and scan step (8 measured: see DESIGN)
 
 template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
 __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, const float *__restrict__ gl,
