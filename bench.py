@@ -703,6 +703,12 @@ def main():
                 rmodel, _, _ = build_model(device, grid="R")
                 res["train_step_waymo_gin_grid"] = dict(train_step_ms(rmodel, flat, device, steps=8),
                                                         grid="L 10, C 4, T 2^21 (240 + 106 MB tables), 128 + 32 samples")
+                del rmodel
+                torch.cuda.empty_cache()
+                # ... and that grid WITH the sky NeRF + colour head: scripts/train_waymo.sh as shipped (waymo.gin + model_sky + brightness_correction)
+                rmodel, _, _ = build_model(device, heads=True, grid="R")
+                res["train_step_waymo_gin_launch"] = dict(train_step_ms(rmodel, flat, device, steps=8, heads=True),
+                                                          grid="L 10, C 4, T 2^21, 128 + 32 samples; sky NeRF + colour-correction head on")
                 del rmodel, flat
                 torch.cuda.empty_cache()
                 # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
