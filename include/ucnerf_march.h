@@ -470,6 +470,31 @@ int ucn_apply_affine(const float *rgb_in /*[N,3]*/, const float *affine /*[M,12]
                      uint32_t S, const float *sky_rgb /*[N,3]|NULL*/, const float *affine_sky /*[M,12]|NULL*/,
                      uint32_t N, float *rgb_out /*[N,3]*/, ucn_stream_t stream);
 
+/* ---- the tail of the TRAINING step with the colour-correction head and the sky layer on (r03; csrc/heads_train.hip).
+ * Each call is one launch; g == NULL selects the forward, g != NULL the backward of the same entry point.
+ *
+ * ucn_affine_blend: rgb' = A rgb + t (+ (1 - acc_last) (A_sky sky + t_sky)) with PER-RAY affine maps [N,12] (row-major [3,4] = [A | t];
+ * models.py:339-363, the training form where every ray carries its camera's map).  Forward (g_out NULL): out_or_g_rgb = rgb'.
+ * Backward: out_or_g_rgb = d/d rgb; g_affine / g_acc / g_sky / g_affine_sky receive (accumulate = 0) or add up (accumulate = 1:
+ * the same maps, sky colours and acc serve every level's call) the other gradients. */
+int ucn_affine_blend(const float *g_out /*[N,3]|NULL*/, const float *rgb /*[N,3]*/, const float *affine /*[N,12]*/,
+                     const float *acc_last /*[N]|NULL*/, const float *sky_rgb /*[N,3]|NULL*/, const float *affine_sky /*[N,12]|NULL*/,
+                     uint32_t N, int accumulate, float *out_or_g_rgb /*[N,3]*/, float *g_affine /*[N,12]*/, float *g_acc /*[N]*/,
+                     float *g_sky /*[N,3]*/, float *g_affine_sky /*[N,12]*/, ucn_stream_t stream);
+/* ucn_data_loss (train_utils.py:171-230): per level l mse_l = sum(m r^2) / sum(m), charb_l = sum(m sqrt(r^2 + pad^2)) / sum(m), r = rgb_l -
+ * target, m = lossmult per ray (NULL = 1); fwd_out = [L][2] {mse, charb}, sum(m) at [2 L], loss = sum_l w_mse[l] mse_l + w_charb[l] charb_l
+ * at [2 L + 1].  Backward (g = d / d loss, [1] on the device): g_rgb_levels[l] = d loss / d rgb_l.  L <= 4; fixed-order sums. */
+int ucn_data_loss(const float *const *rgb_levels_host /*[L] device pointers, each [N,3]*/, uint32_t L, const float *w_mse_host /*[L]*/,
+                  const float *w_charb_host /*[L]*/, const float *target /*[N,3]*/, const float *lossmult /*[N]|NULL*/, uint32_t N,
+                  float charb_padding, float *fwd_out /*[2 L + 2]*/, const float *g /*[1]|NULL*/, float *const *g_rgb_levels_host,
+                  ucn_stream_t stream);
+/* ucn_sky_loss (train_utils.py:149-157): sum_l mean BCE(clip(acc_l, 1e-3, 0.999), 1 - sky_segs) */
+int ucn_sky_loss(const float *const *acc_levels_host /*[L] device pointers, each [N]*/, uint32_t L, const float *sky_segs /*[N]*/, uint32_t N,
+                 float *loss_out /*[1]*/, const float *g /*[1]|NULL*/, float *const *g_acc_levels_host, ucn_stream_t stream);
+/* ucn_identity_loss (train_utils.py:159-169): mean over [N,3,4] of |eye - A| (+ |eye - A_sky|), accumulated in float64 like the reference */
+int ucn_identity_loss(const float *affine /*[N,12]*/, const float *affine_sky /*[N,12]|NULL*/, uint32_t N, double *loss_out /*[1]*/,
+                      const double *g /*[1]|NULL*/, float *g_affine /*[N,12]*/, float *g_affine_sky /*[N,12]|NULL*/, ucn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -875,3 +875,61 @@ def test_heads_training_step_with_the_sky_branch_on_a_side_stream():
             # deterministic kernels on both routes (fixed-order split-K); the upstream gradient passes through the field's weights
             # only through the loss value, so these agree to rounding
             assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * float(g0[k].abs().max()) + 1e-9, k
+
+
+@pytest.mark.gpu
+def test_fused_heads_tail_matches_the_eager_form():
+    """csrc/heads_train.hip: per-ray affine correction + sky blend, data loss, sky loss, identity loss as single HIP nodes against the
+    eager torch expressions they replace (models.py:339-363, train_utils.py:149-230): values and every gradient."""
+    import types
+    from ucnerf_amd.internal import train_graph as tg, train_utils as tu
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, S = 1000, 16                                                              # (ragged against the 256- / 1024-thread launches)
+
+    def leaf(*shape, scale=1.0, shift=0.0):
+        return (torch.rand(*shape, device=dev, generator=g) * scale + shift).requires_grad_(True)
+    rgb0, rgb1, sky = leaf(N, 3), leaf(N, 3), leaf(N, 3)
+    A = (torch.eye(4, device=dev)[:3].expand(N, 3, 4) + 0.2 * torch.randn(N, 3, 4, device=dev, generator=g)).requires_grad_(True)
+    A_sky = (torch.eye(4, device=dev)[:3].expand(N, 3, 4) + 0.2 * torch.randn(N, 3, 4, device=dev, generator=g)).requires_grad_(True)
+    acc0, acc1 = leaf(N, scale=1.2, shift=-0.1), leaf(N, scale=1.2, shift=-0.1)           # some outside the clip range
+    target = torch.rand(N, 1, 1, 3, device=dev, generator=g)
+    mult = torch.rand(N, 1, 1, 1, device=dev, generator=g) + 0.5
+    segs = (torch.rand(N, 1, 1, device=dev, generator=g) > 0.6).float()
+    leaves = [rgb0, rgb1, sky, A, A_sky, acc0, acc1]
+
+    def run(fused):
+        for t in leaves:
+            t.grad = None
+        affine = lambda M, v: (M[:, :3, :3] * v.reshape(N, 1, 3)).sum(dim=-1, keepdim=True) + M[:, :3, 3:]
+        rend = []
+        for rgb, acc in ((rgb0, acc0), (rgb1, acc1)):
+            if fused:
+                out = tg._AffineBlend.apply(rgb, A.reshape(N, 12), acc1, sky, A_sky.reshape(N, 12)).reshape(N, 1, 1, 3)
+            else:
+                out = (affine(A, rgb) + (1 - acc1)[:, None, None] * affine(A_sky, sky)).reshape(N, 1, 1, 3)
+            rend.append(dict(rgb=out, acc=acc.reshape(N, 1, 1), weights=(acc / S)[:, None].expand(N, S).reshape(N, 1, 1, S),
+                             affine_trans=A, affine_trans_sky=A_sky))
+        cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.3,
+                                    disable_multiscale_loss=False)
+        batch = dict(rgb=target, lossmult=mult, sky_segs=segs)
+        if fused:
+            l_data, stats = tu.compute_data_loss(batch, rend, cfg)
+            l_sky, l_idt = tu.sky_loss(batch, rend), tu.transformIdentityLoss(rend)
+        else:                                                                     # the eager forms: no 'acc' key, CPU-style code path
+            eager = [{k: v for k, v in r.items() if k != 'acc'} for r in rend]
+            saved = tu._f32_cuda
+            tu._f32_cuda = lambda *a: False
+            try:
+                l_data, stats = tu.compute_data_loss(batch, eager, cfg)
+                l_sky, l_idt = tu.sky_loss(batch, eager), tu.transformIdentityLoss(eager)
+            finally:
+                tu._f32_cuda = saved
+        (l_data + 0.7 * l_sky + 0.3 * l_idt).backward()
+        return ([float(l_data), float(l_sky), float(l_idt)] + [float(x) for x in np.asarray(stats['mses']).reshape(-1)],
+                [t.grad.detach().clone() for t in leaves])
+    v_f, g_f = run(True)
+    v_e, g_e = run(False)
+    assert np.allclose(v_f, v_e, rtol=2e-6, atol=1e-7), (v_f, v_e)
+    for name, a, b in zip(("rgb0", "rgb1", "sky", "A", "A_sky", "acc0", "acc1"), g_f, g_e):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
@@ -124,6 +124,10 @@ SIGNATURES = {
     "ucn_image_metrics": [c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp],
     "ucn_dense": [c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp],
     "ucn_apply_affine": [c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_u32, c_vp, c_vp],
+    "ucn_affine_blend": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "ucn_data_loss": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, ctypes.c_float, c_vp, c_vp, c_vp, c_vp],
+    "ucn_sky_loss": [c_vp, c_u32, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_identity_loss": [c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,

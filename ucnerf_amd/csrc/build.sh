@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
 mkdir -p _obj
 pids=()
-for f in grid_op march_ray march_features field_mlp field_mlp_h heads sky sky_train wgrad rays train_ops warp field_train prop_train tsdf mesh metrics; do
+for f in grid_op march_ray march_features field_mlp field_mlp_h heads heads_train sky sky_train wgrad rays train_ops warp field_train prop_train tsdf mesh metrics; do
   stale=0
   for h in "$f.hip" *.h ../../include/ucnerf_march.h; do
     if [ ! -f "_obj/$f.o" ] || [ "$h" -nt "_obj/$f.o" ]; then stale=1; fi

@@ -372,6 +372,7 @@ class Model(nn.Module):
     #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
     sky_side_stream: bool = True         # (with fused_sky_train) the sky branch of a training step on a second HIP stream
     fused_sky_train: bool = True         # training under bf16 autocast runs the sky NeRF on csrc/sky_train.hip (False: eager torch)
+    fused_heads_tail: bool = True        # training: per-ray colour correction + sky blend as one HIP node per level (False: eager torch)
     march_route: str = 'auto'            # which march Model.forward runs: 'auto' = the training graph iff self.training and
     #                                      autograd is enabled, else the fused inference march; 'train' / 'inference' force it
     sky_min_background: float = 0.0      # > 0: inference marches evaluate the sky layer only for rays whose background

@@ -856,6 +856,59 @@ def _sky_fusable(net, origins):
             and origins.shape[0] * 120 % 8192 == 0 and all(p.dtype == torch.float32 for p in net.parameters()))
 
 
+def _ptr_array(tensors):
+    """host array of device pointers (kept alive by the caller for the duration of the call)"""
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def _tail_fusable(*tensors):
+    """the fused tail kernels (csrc/heads_train.hip) take contiguous float32 device tensors"""
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+
+
+class _AffineBlend(torch.autograd.Function):
+    """models.py:339-363 for one level: rgb' = A rgb + t (+ (1 - acc_last) (A_sky sky + t_sky)) with per-ray maps [N, 3, 4]:
+    one launch forward, one backward (`ucn_affine_blend`) where the broadcast-multiply form took ~12 + ~25 eager launches per level."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rgb, A, acc_last, sky, A_sky):
+        lib = _lib.load()
+        N = rgb.shape[0]
+        rgb, A = rgb.contiguous(), A.contiguous()
+        with_sky = sky is not None
+        if with_sky:
+            acc_last, sky, A_sky = acc_last.contiguous(), sky.contiguous(), A_sky.contiguous()
+        out = torch.empty(N, 3, device=rgb.device)
+        _lib.check(lib.ucn_affine_blend(None, rgb.data_ptr(), A.data_ptr(), _lib.ptr(acc_last) if with_sky else None,
+                                        _lib.ptr(sky) if with_sky else None, _lib.ptr(A_sky) if with_sky else None, N, 0,
+                                        out.data_ptr(), None, None, None, None, _lib.stream()))
+        ctx.save_for_backward(rgb, A, *( (acc_last, sky, A_sky) if with_sky else () ))
+        ctx.with_sky = with_sky
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        rgb, A = saved[0], saved[1]
+        N = rgb.shape[0]
+        g = g.float().contiguous()
+        g_rgb, g_A = torch.empty_like(rgb), torch.empty_like(A)
+        if ctx.with_sky:
+            acc_last, sky, A_sky = saved[2:]
+            g_acc, g_sky, g_As = torch.empty_like(acc_last), torch.empty_like(sky), torch.empty_like(A_sky)
+            _lib.check(lib.ucn_affine_blend(g.data_ptr(), rgb.data_ptr(), A.data_ptr(), acc_last.data_ptr(), sky.data_ptr(),
+                                            A_sky.data_ptr(), N, 0, g_rgb.data_ptr(), g_A.data_ptr(), g_acc.data_ptr(), g_sky.data_ptr(),
+                                            g_As.data_ptr(), _lib.stream()))
+            return g_rgb, g_A, g_acc, g_sky, g_As
+        _lib.check(lib.ucn_affine_blend(g.data_ptr(), rgb.data_ptr(), A.data_ptr(), None, None, None, N, 0, g_rgb.data_ptr(),
+                                        g_A.data_ptr(), None, None, None, _lib.stream()))
+        return g_rgb, g_A, None, None, None
+
+
 def brightness_forward(bc, idx, which="latent_code"):
     """extrinsic_optimizer.py:4-48 as models.py:341-349 calls it: the reference looks the latent code up per RAY and runs the
     4 -> 256 -> 256 -> 256 -> 12 MLP on 8192 rows that repeat at most `training_views` distinct codes.  A row's result depends
@@ -999,7 +1052,19 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         # tiny matrices costs 1.3 ms of HOST time per call on this stack (12 calls per step forward + backward: the GPU idled
         # 45 ms of a 66 ms step, tools/train_cpu.py)
         affine = lambda M, v: (M[:, :3, :3] * v.reshape(N, 1, 3)).sum(dim=-1, keepdim=True) + M[:, :3, 3:]
+        fused_tail = model.fused_heads_tail and _tail_fusable(A, A_sky, renderings[-1]['rgb'])
+        acc_last = renderings[-1]['acc'].reshape(N) if (fused_tail and with_sky) else None   # = sum of the last level's weights
         for r in renderings:
+            if fused_tail:
+                # one launch forward + one backward per level (csrc/heads_train.hip); acc of the last level stands for the
+                # sum of its weights (render.py:199: the same sum, in the compositing kernel's order)
+                rgb = _AffineBlend.apply(r['rgb'].reshape(N, 3), A.reshape(N, 12), acc_last,
+                                         r['sky_rgbs'].reshape(N, 3) if with_sky else None, A_sky.reshape(N, 12) if with_sky else None)
+                r['rgb'] = rgb.reshape(N, 1, 1, 3) if eval_camidx is None else rgb.reshape(N, 3)
+                r['affine_trans'] = A
+                if with_sky:
+                    r['affine_trans_sky'] = A_sky
+                continue
             rgb = affine(A, r['rgb'])
             if with_sky:
                 opac = 1 - last_w.sum(dim=-1, keepdim=True)

@@ -12,6 +12,7 @@ tensors already resident in HBM; formulations differ where the reference is quad
 """
 import collections
 import collections.abc
+import ctypes
 
 import numpy as np
 import torch
@@ -151,18 +152,123 @@ class LazyStats(collections.abc.MutableMapping):
         return repr(dict(self.items()))
 
 
+class _DataLoss(torch.autograd.Function):
+    """train_utils.py:171-230 for all levels in ONE launch forward + one backward (`ucn_data_loss`): the weighted loss and the
+    per-level mse statistics; ~10 + ~15 eager launches otherwise."""
+
+    @staticmethod
+    def forward(ctx, target, mult, pad, w_mse, w_charb, *levels):
+        lib = _lib.load()
+        N = target.shape[0]
+        L = len(levels)
+        levels = [l.contiguous() for l in levels]
+        out = torch.empty(2 * L + 2, device=target.device)
+        wm, wc = (ctypes.c_float * L)(*w_mse), (ctypes.c_float * L)(*w_charb)
+        ptrs = (ctypes.c_void_p * L)(*[l.data_ptr() for l in levels])
+        _lib.check(lib.ucn_data_loss(ptrs, L, wm, wc, target.data_ptr(), _lib.ptr(mult), N, float(pad), out.data_ptr(), None, None, _lib.stream()))
+        ctx.save_for_backward(target, out, *levels)
+        ctx.mult, ctx.pad, ctx.w = mult, float(pad), (list(w_mse), list(w_charb))
+        ctx.mark_non_differentiable(out)
+        return out[2 * L + 1], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        lib = _lib.load()
+        target, out, *levels = ctx.saved_tensors
+        N, L = target.shape[0], len(levels)
+        g = g_loss.reshape(1).float().contiguous()
+        grads = [torch.empty_like(l) for l in levels]
+        wm, wc = (ctypes.c_float * L)(*ctx.w[0]), (ctypes.c_float * L)(*ctx.w[1])
+        ptrs = (ctypes.c_void_p * L)(*[l.data_ptr() for l in levels])
+        gptrs = (ctypes.c_void_p * L)(*[x.data_ptr() for x in grads])
+        _lib.check(lib.ucn_data_loss(ptrs, L, wm, wc, target.data_ptr(), _lib.ptr(ctx.mult), N, ctx.pad, out.data_ptr(), g.data_ptr(), gptrs,
+                                     _lib.stream()))
+        return (None, None, None, None, None, *grads)
+
+
+class _SkyLoss(torch.autograd.Function):
+    """train_utils.py:149-157 over all levels: one launch forward, one backward (`ucn_sky_loss`)."""
+
+    @staticmethod
+    def forward(ctx, sky_segs, *accs):
+        lib = _lib.load()
+        accs = [a.contiguous() for a in accs]
+        N, L = accs[0].shape[0], len(accs)
+        out = torch.empty(1, device=sky_segs.device)
+        ptrs = (ctypes.c_void_p * L)(*[a.data_ptr() for a in accs])
+        _lib.check(lib.ucn_sky_loss(ptrs, L, sky_segs.data_ptr(), N, out.data_ptr(), None, None, _lib.stream()))
+        ctx.save_for_backward(sky_segs, *accs)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        sky_segs, *accs = ctx.saved_tensors
+        N, L = accs[0].shape[0], len(accs)
+        g = g.reshape(1).float().contiguous()
+        grads = [torch.empty_like(a) for a in accs]
+        ptrs = (ctypes.c_void_p * L)(*[a.data_ptr() for a in accs])
+        gptrs = (ctypes.c_void_p * L)(*[x.data_ptr() for x in grads])
+        _lib.check(lib.ucn_sky_loss(ptrs, L, sky_segs.data_ptr(), N, None, g.data_ptr(), gptrs, _lib.stream()))
+        return (None, *grads)
+
+
+class _IdentityLoss(torch.autograd.Function):
+    """train_utils.py:159-169: mean |eye - A| (+ |eye - A_sky|) in float64 like the reference: one launch each way (`ucn_identity_loss`)."""
+
+    @staticmethod
+    def forward(ctx, A, A_sky):
+        lib = _lib.load()
+        A = A.contiguous()
+        A_sky = A_sky.contiguous() if A_sky is not None else None
+        N = A.numel() // 12
+        out = torch.empty(1, device=A.device, dtype=torch.float64)
+        _lib.check(lib.ucn_identity_loss(A.data_ptr(), _lib.ptr(A_sky), N, out.data_ptr(), None, None, None, _lib.stream()))
+        ctx.save_for_backward(A, *([A_sky] if A_sky is not None else []))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        A, *rest = ctx.saved_tensors
+        A_sky = rest[0] if rest else None
+        N = A.numel() // 12
+        g = g.reshape(1).double().contiguous()
+        gA = torch.empty_like(A)
+        gB = torch.empty_like(A_sky) if A_sky is not None else None
+        _lib.check(lib.ucn_identity_loss(A.data_ptr(), _lib.ptr(A_sky), N, None, g.data_ptr(), gA.data_ptr(), _lib.ptr(gB), _lib.stream()))
+        return gA, gB
+
+
+def _f32_cuda(*tensors):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
 def compute_data_loss(batch, renderings, config):
     """ref train_utils.py:171-230 ('mse' and 'charb').  All levels in one set of elementwise / reduce launches (the
     levels' rgb stacked), the per-level mse statistics handed back as LazyStats."""
     target = batch['rgb'][..., :3]
-    lossmult = torch.broadcast_to(batch['lossmult'], target.shape)
-    if getattr(config, 'disable_multiscale_loss', False):
-        lossmult = torch.ones_like(lossmult)
-    denom = lossmult.sum()
     kind = getattr(config, 'data_loss_type', 'charb')
     if kind not in ('mse', 'charb'):
         raise NotImplementedError(f"data_loss_type={kind!r}")
     n_lvl = len(renderings)
+    coarse = getattr(config, 'data_coarse_loss_mult', 0.)
+    levels = [r['rgb'] for r in renderings]
+    if (n_lvl <= 4 and target.shape[-1] == 3 and _f32_cuda(target, *levels) and all(l.numel() == target.numel() for l in levels)
+            and batch['lossmult'].numel() * 3 == target.numel()):
+        # the whole function as ONE HIP node (csrc/heads_train.hip): weighted loss + the mse statistics
+        N = target.numel() // 3
+        mult = None if getattr(config, 'disable_multiscale_loss', False) else batch['lossmult'].reshape(N).float().contiguous()
+        w_level = [coarse if (coarse != 0 and n_lvl > 1) else 0.0] * (n_lvl - 1) + [getattr(config, 'data_loss_mult', 1.0)]
+        w_mse = w_level if kind == 'mse' else [0.0] * n_lvl
+        w_charb = [0.0] * n_lvl if kind == 'mse' else w_level
+        loss, out = _DataLoss.apply(target.reshape(N, 3).contiguous(), mult, getattr(config, 'charb_padding', 0.001), w_mse, w_charb,
+                                    *[l.reshape(N, 3) for l in levels])
+        return loss, LazyStats(mses=out[0:2 * n_lvl:2])
+    lossmult = torch.broadcast_to(batch['lossmult'], target.shape)
+    if getattr(config, 'disable_multiscale_loss', False):
+        lossmult = torch.ones_like(lossmult)
+    denom = lossmult.sum()
     dims = tuple(range(1, target.dim() + 1))
     resid_sq = (torch.stack([r['rgb'] for r in renderings]) - target) ** 2                # [levels, ...]
     mses = (lossmult * resid_sq).sum(dim=dims) / denom
@@ -170,7 +276,6 @@ def compute_data_loss(batch, renderings, config):
         per_level = mses
     else:
         per_level = (lossmult * torch.sqrt(resid_sq + getattr(config, 'charb_padding', 0.001) ** 2)).sum(dim=dims) / denom
-    coarse = getattr(config, 'data_coarse_loss_mult', 0.)
     loss = getattr(config, 'data_loss_mult', 1.0) * per_level[-1]
     if coarse != 0 and n_lvl > 1:
         loss = loss + coarse * per_level[:-1].sum()
@@ -210,6 +315,10 @@ def hash_decay_loss(ray_history, config):
 
 def sky_loss(batch, renderings):
     """ref train_utils.py:149-157."""
+    if len(renderings) <= 4 and all('acc' in r for r in renderings) and _f32_cuda(batch['sky_segs'], *[r['acc'] for r in renderings]):
+        # one HIP node for all levels (csrc/heads_train.hip); `acc` IS the sum of the level's weights (render.py:199)
+        N = batch['sky_segs'].numel()
+        return _SkyLoss.apply(batch['sky_segs'].reshape(N).contiguous(), *[r['acc'].reshape(N) for r in renderings])
     loss = 0
     target = 1 - batch['sky_segs']
     for r in renderings:
@@ -221,6 +330,9 @@ def sky_loss(batch, renderings):
 def transformIdentityLoss(renderings):
     """ref train_utils.py:159-169."""
     A = renderings[0]['affine_trans']
+    A_sky = renderings[0].get('affine_trans_sky')
+    if _f32_cuda(A, *([A_sky] if A_sky is not None else [])) and A.shape[-2:] == (3, 4):
+        return _IdentityLoss.apply(A, A_sky)                          # one HIP node (csrc/heads_train.hip)
     eye = torch.eye(4, dtype=torch.float64, device=A.device)[:3].unsqueeze(0).expand(A.shape[0], 3, 4)
     loss = torch.abs(eye - A)
     if 'affine_trans_sky' in renderings[0]:
