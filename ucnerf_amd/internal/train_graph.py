@@ -823,10 +823,13 @@ class _SkyFused(torch.autograd.Function):
             gbr = Gv[128:131, 259]
             gWr = wgrad(dl[:, 2048 + 128:2048 + 160], act[:, HV:HV + 128])[:3]              # g^T hv: [3, 128]
         w_dt, b_dt, m5_dt, mv_dt, wa_dt, ba_dt, wr_dt, br_dt = dts
-        res = [None, None, None, None, out[0][0].to(w_dt), out[0][1].to(b_dt)]
+        # (contiguous: these are column blocks of the weight-gradient kernel's [., 288] outputs; autograd's accumulation would
+        #  clone a strided gradient anyway, and DistributedDataParallel's bucket views warn about the stride mismatch)
+        c = lambda t, dt: t.to(dt).clone(memory_format=torch.contiguous_format)      # (clone: a [1, 256] view keeps its row stride through .contiguous())
+        res = [None, None, None, None, c(out[0][0], w_dt), c(out[0][1], b_dt)]
         for l in (1, 2, 3, 4, 6, 7):
-            res += [out[l][0].to(w_dt), out[l][1].to(b_dt)]
-        res += [out[5].to(m5_dt), gMv.to(mv_dt), gwa.to(wa_dt), gba.to(ba_dt), gWr.to(wr_dt), gbr.to(br_dt)]
+            res += [c(out[l][0], w_dt), c(out[l][1], b_dt)]
+        res += [c(out[5], m5_dt), c(gMv, mv_dt), c(gwa, wa_dt), c(gba, ba_dt), c(gWr, wr_dt), c(gbr, br_dt)]
         return tuple(res)
 
 
