@@ -265,7 +265,7 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192
     rgb = torch.cat(rgb)
     linf = float((rgb - gpu_rgb[idx].cpu()).abs().max())
     mse = float(((rgb - gpu_rgb[idx].cpu()) ** 2).mean())
-    return dict(value=n_sample / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=n_sample / dt, unit="rays/s", cores=torch.get_num_threads(), host_cpu_count=os.cpu_count(), kind="port",
                 sample=f"{n_sample} rays strided over the same frame, same weights and rand_vec, "
                        f"{-(-n_sample // per_call)} calls of {per_call}, {dt:.1f} s",
                 rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
@@ -441,7 +441,27 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False)
                 graph="HIP resample, fused featurisation fwd / bwd (LDS row blocks, no global atomics), NeRF-field dense forward and "
                       "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd, two workgroups per CU), proposal field as VALU "
                       "kernels, compositing fwd / bwd, distortion + interlevel + hash-decay losses, Adam (tables and small "
-                      "parameters); one library GEMM per layer for weight + bias gradients")
+                      "parameters); weight + bias gradients by wgrad.hip (ds_read_b64_tr_b16 operand transposes + bf16 MFMA, split-K)")
+
+
+def self_launch(n):
+    """Re-run this command line as N ranks: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <the same arguments>`.  Returns the launcher's exit code.  RCCL wants one GPU per rank:
+    fewer visible GPUs than ranks is an error here, not a silent N = 1 run (UCN_DIST_BACKEND=gloo is the functional
+    check that lets ranks share a device)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("UCN_DIST_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs for RCCL (one rank per GPU), found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), UCN_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -488,9 +508,16 @@ def main():
         args.cameras = 5
     if args.pmc_child:
         args.steps, args.warmup, args.no_cpu_baseline, args.no_train, args.no_extras = 1, 0, True, True, True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher.  One rank per GPU under
+        # torch.distributed.run (the same form the driver uses for N > 1); rank 0's JSON line passes through on stdout.
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.pmc_child and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); "
+                         "the line's n_gpus must be the number of ranks that really ran")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists)"
     # UCN_DIST_BACKEND=gloo lets two ranks share one GPU: a functional check of the multi-rank flow on a 1-GPU box
     backend = os.environ.get("UCN_DIST_BACKEND", "nccl")             # nccl == RCCL on ROCm
@@ -561,12 +588,14 @@ def main():
         out = step()
     fence()
     model._prof = []
+    udist.EXCHANGE_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
     prof, model._prof = model._prof, None
+    exch, udist.EXCHANGE_EVENTS = udist.EXCHANGE_EVENTS, None
     t = torch.tensor([dt], device=device)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -673,9 +702,33 @@ def main():
                                     {0: "fp32-input MFMA", 1: "split-f16 MFMA (hi/lo operands, fp32 accumulate)"}[model.nerf_mlp.mlp_mode]),
                        **({"autocast": "bf16"} if args.autocast else {})},
             "roofline": dominant, "roofline_secondary": other,
+            # whole-path fraction: value / (N x the rate at which ONE GPU could stream the path's algorithmic gather bytes at the HBM
+            # spec peak); the MFMA-bound rate of the arithmetic actually issued is higher (the binding roof is HBM), both stated
+            "end_to_end": dict(
+                frac=n_rays * args.steps / dt / (world * PEAK_HBM_GBS * 1e9 / ((GATHER_BYTES_NERF + GATHER_BYTES_PROP) // (2 if args.autocast else 1) + 84)),
+                hbm_bound_rays_per_s_per_gpu=PEAK_HBM_GBS * 1e9 / ((GATHER_BYTES_NERF + GATHER_BYTES_PROP) // (2 if args.autocast else 1) + 84),
+                mfma_bound_rays_per_s_per_gpu=(PEAK_F16_MFMA_TF * 1e12 / (S_NERF * 276 * 32768 / 32) if args.autocast else
+                                               PEAK_F16_MFMA_TF * 1e12 / (3 * S_NERF * 2 * MAC_NERF_SPLIT) if split else
+                                               PEAK_F32_MFMA_TF * 1e12 / FLOP_NERF_RAY),
+                note="frac = value / (n_gpus x min(HBM-bound, MFMA-bound) rate), SURVEY.md 8(d); gather and MLP kernels run back to back, "
+                     "so 1 / (1 / hbm + 1 / mfma) is the serial ceiling"),
+            "launch": ("self-launched: bench.py re-executed itself under torch.distributed.run" if os.environ.get("UCN_BENCH_SELF_LAUNCHED")
+                       else ("torch.distributed.run (external launcher)" if world > 1 else "single process")),
             "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / args.steps, "mlp_prop": mlp_ms[0] / args.steps,
                                          "features_nerf": feat_ms[1] / args.steps, "mlp_nerf": mlp_ms[1] / args.steps},
         }
+        if world > 1:
+            # proof that the collective library saw N ranks, and what the frame's one exchange cost on rank 0
+            res["dist_backend"] = torch.distributed.get_backend()
+            res["rccl_ranks"] = torch.distributed.get_world_size() if res["dist_backend"] == "nccl" else 0
+            res["dist_ranks"] = torch.distributed.get_world_size()
+            if exch:
+                ms = [a.elapsed_time(b) for a, b, _ in exch]
+                res["all_gather"] = dict(ms_per_frame=sum(ms) / len(ms), bytes_sent_per_rank=exch[0][2], frames=len(ms),
+                                         bytes_received_per_rank=exch[0][2] * world,
+                                         algbw_GBps=exch[0][2] * world / (sum(ms) / len(ms) * 1e-3) / 1e9,
+                                         note="HIP events around the frame's one packed all_gather_into_tensor on rank 0 (includes waiting "
+                                              "for the slowest rank's shard)")
         if world == 1 and not args.no_cpu_baseline:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=args.cfg5,

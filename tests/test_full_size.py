@@ -169,8 +169,9 @@ def test_coresident_launch_shapes_give_identical_pixels():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_flow_on_one_gpu():
-    """The driver's multi-GPU launch of bench.py (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) end
-    to end on what a 1-GPU box allows: two ranks sharing the device with UCN_DIST_BACKEND=gloo (RCCL refuses two ranks on one
+    """`python bench.py --gpus 2` with no launcher around it (the driver's N = 1 command form; bench.py re-executes itself under
+    `python -m torch.distributed.run --nproc-per-node 2 ...`, which is also the driver's N > 1 form, and refuses a WORLD_SIZE that
+    differs from --gpus) end to end on what a 1-GPU box allows: two ranks sharing the device with UCN_DIST_BACKEND=gloo (RCCL refuses two ranks on one
     GPU; its collective is covered by test_the_frame_exchange_runs_on_rccl).  Rank 0 prints ONE JSON line whose value is
     the whole job's rays/s, n_gpus = 2, scaling = strong; the frame each rank returns is the single-process frame."""
     import json
@@ -179,14 +180,17 @@ def test_bench_two_ranks_flow_on_one_gpu():
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UCN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = str(33500 + os.getpid() % 2000)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", port, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+    env.pop("WORLD_SIZE", None)
+    # the driver's N = 1 command form with N = 2: plain `python bench.py --gpus 2`, NO launcher -- bench.py must start the ranks itself
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 1 and r["scaling"] == "strong" and r["unit"] == "rays/s"
+    assert r["launch"].startswith("self-launched") and r["dist_ranks"] == 2 and r["dist_backend"] == "gloo" and r["rccl_ranks"] == 0
+    assert r["all_gather"]["frames"] == 1 and r["all_gather"]["ms_per_frame"] > 0
+    assert r["all_gather"]["bytes_sent_per_rank"] == 1280 * 1920 // 2 * 36
     assert r["config"]["rays_per_step"] == 1280 * 1920 and "x2" in r["config"]["parallelism"]
     assert 1e5 < r["value"] < 2e7 and abs(r["value"] - 1280 * 1920 / (r["ms_per_step"] * 1e-3)) <= 1e-3 * r["value"]
     assert r["roofline"]["bound"] in ("hbm", "mfma") and 0 < r["roofline"]["frac"] <= 1.2

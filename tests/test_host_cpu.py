@@ -327,3 +327,33 @@ def test_tile_order_is_a_permutation_of_the_frame_in_blocks():
         assert bool((block[1:] >= block[:-1]).all())                      # blocks are contiguous runs
         first = perm[:min(T, Ww)]
         assert first.tolist() == list(range(min(T, Ww)))                 # row-major inside the first block
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (no launcher): bench.py starts N ranks itself with the driver's own launcher form; a launcher
+    that started a different number of ranks than --gpus says is refused (the line's n_gpus is never a flag echoed back);
+    fewer GPUs than RCCL ranks is an error, not a silent one-rank run.  CPU-only: the launcher is intercepted."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["UCN_BENCH_SELF_LAUNCHED"] == "1"
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("UCN_DIST_BACKEND", raising=False)
+    assert bench.self_launch(4) == 2                                  # RCCL: one GPU per rank
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "launcher started 1 rank" in p.stderr

@@ -877,6 +877,65 @@ def test_heads_training_step_with_the_sky_branch_on_a_side_stream():
             assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * float(g0[k].abs().max()) + 1e-9, k
 
 
+def _graph_node_names(t):
+    seen, names, todo = set(), set(), [t.grad_fn]
+    while todo:
+        f = todo.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        names.add(type(f).__name__)
+        todo.extend(n for n, _ in f.next_functions)
+    return names
+
+
+@pytest.mark.gpu
+def test_fused_heads_tail_engages_under_bf16_autocast():
+    """under train.py:165's autocast the colour-correction Linear layers return bf16 affine maps; the fused tail
+    (`_AffineBlend`, `_IdentityLoss`) must still be the route taken (the maps are upcast exactly), and equal the eager tail."""
+    import types
+    import bench
+    from ucnerf_amd.internal import train_utils as tu
+    dev = torch.device("cuda", 0)
+    model, _, _ = bench.build_model(dev, heads=True)
+    model.train()
+    n = 1024
+    rays = {k: v.to(dev) for k, v in rm.synthetic_rays(n, seed=21).items()}
+    g = torch.Generator(device=dev).manual_seed(22)
+    batch = {k: v[:, None, None, :] for k, v in rays.items()}
+    batch['rgb'] = torch.rand(n, 1, 1, 3, device=dev, generator=g)
+    batch['lossmult'] = torch.ones(n, 1, 1, 1, device=dev)
+    batch['cam_idx'] = torch.randint(0, 210, (n, 1, 1, 1), device=dev, generator=g)
+    batch['sky_segs'] = (torch.rand(n, 1, 1, device=dev, generator=g) > 0.7).float()
+    batch['rand_vec'] = torch.randn(n, 6, device=dev, generator=g)
+    batch['march_noise'] = [dict(jitter=torch.rand(n, 1, device=dev, generator=g), flip=torch.rand(n, S, device=dev, generator=g),
+                                 spin=torch.rand(n, S, device=dev, generator=g)) for S in (64, 128)]
+    cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                                disable_multiscale_loss=False)
+
+    def step(fused):
+        model.fused_heads_tail = fused
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            rend, _ = model(True, batch, 0.5, False, zero_glo=False)
+        assert rend[0]['affine_trans'].dtype == torch.bfloat16               # what the reference's own head returns under autocast
+        l_idt = tu.transformIdentityLoss(rend) if fused else (torch.abs(torch.eye(4, dtype=torch.float64, device=dev)[:3] - rend[0]['affine_trans'])
+                                                              + torch.abs(torch.eye(4, dtype=torch.float64, device=dev)[:3] - rend[0]['affine_trans_sky'])).mean()
+        loss = tu.compute_data_loss(batch, rend, cfg)[0] + 0.5 * l_idt
+        names = _graph_node_names(loss)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), names, {k: p.grad.float().clone() for k, p in model.brightness_corr.named_parameters()}, rend[-1]['rgb'].detach().float()
+    l1, names1, g1, rgb1 = step(True)
+    l0, names0, g0, rgb0 = step(False)
+    model.fused_heads_tail = True
+    assert any("_AffineBlend" in x for x in names1) and any("_IdentityLoss" in x for x in names1), sorted(names1)
+    assert not any("_AffineBlend" in x or "_IdentityLoss" in x for x in names0)
+    assert float((rgb1 - rgb0).abs().max()) <= 2e-6 and abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    for k in g0:      # the gradient returns to the bf16 maps through one rounding on either route; the sums in front differ in order
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-2 * float(g0[k].abs().max()) + 1e-9, (k, float((g1[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
+
+
 @pytest.mark.gpu
 def test_fused_heads_tail_matches_the_eager_form():
     """csrc/heads_train.hip: per-ray affine correction + sky blend, data loss, sky loss, identity loss as single HIP nodes against the
@@ -919,7 +978,7 @@ def test_fused_heads_tail_matches_the_eager_form():
         else:                                                                     # the eager forms: no 'acc' key, CPU-style code path
             eager = [{k: v for k, v in r.items() if k != 'acc'} for r in rend]
             saved = tu._f32_cuda
-            tu._f32_cuda = lambda *a: False
+            tu._f32_cuda = lambda *a, **k: False
             try:
                 l_data, stats = tu.compute_data_loss(batch, eager, cfg)
                 l_sky, l_idt = tu.sky_loss(batch, eager), tu.transformIdentityLoss(eager)

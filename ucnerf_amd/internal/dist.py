@@ -14,6 +14,9 @@ import torch
 import torch.distributed as dist
 
 
+EXCHANGE_EVENTS = None          # a list while bench.py times frames: (start event, end event, bytes sent) per frame exchange
+
+
 def rows_per_rank(num_rays, world):
     return (num_rays + world - 1) // world
 
@@ -83,7 +86,14 @@ def all_gather_rows(local, num_rays, world, rank):
         col += w
     if n_loc < rp:
         mine[n_loc:].zero_()                          # padding rows of the last shard(s), stripped below
-    _exchange(out, mine, rank, rp)                    # one collective per frame
+    if EXCHANGE_EVENTS is not None:                   # bench.py: the collective's own duration, on the stream it runs on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _exchange(out, mine, rank, rp)
+        e1.record()
+        EXCHANGE_EVENTS.append((e0, e1, mine.numel() * mine.element_size()))
+    else:
+        _exchange(out, mine, rank, rp)                # one collective per frame
     out = out[:num_rays]
     res, col = {}, 0
     for k, w in zip(keys, widths):

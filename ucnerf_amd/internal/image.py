@@ -41,15 +41,16 @@ class MetricHarness:
         try:
             import lpips
             self._lpips = lpips.LPIPS(net="vgg")
-        except Exception:                                   # noqa: BLE001  (package or weights absent: no LPIPS, as documented)
+        except (ImportError, OSError):                      # package or weights absent: 'lpips' is reported as nan (key always present)
             self._lpips = None
 
     def __call__(self, rgb_pred, rgb_gt, name_fn=lambda s: s):
         psnr, ssim = image_metrics(rgb_pred, rgb_gt)
         res = {name_fn('psnr'): float(psnr), name_fn('ssim'): float(ssim)}
+        res[name_fn('lpips')] = float('nan')                  # the reference always returns the key (image.py:127-133)
         if self._lpips is not None:
-            q = lambda x: (torch.as_tensor(x).float().cpu().clamp(0, 1) * 255).to(torch.uint8).float() / 255
-            gt_ = q(rgb_gt).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
-            pr_ = q(rgb_pred).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
+            # image.py:119-120: the prediction is clipped before quantisation, the ground truth is quantised as it is
+            gt_ = ((torch.as_tensor(rgb_gt).float().cpu() * 255).to(torch.uint8).float() / 255).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
+            pr_ = ((torch.as_tensor(rgb_pred).float().cpu().clamp(0, 1) * 255).to(torch.uint8).float() / 255).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
             res[name_fn('lpips')] = float(self._lpips(gt_, pr_).detach().item())
         return res

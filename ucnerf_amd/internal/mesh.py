@@ -26,6 +26,8 @@ def marching_cubes(volume, level=0.0, spacing=(1.0, 1.0, 1.0), allow_degenerate=
     st = _lib.stream()
     _lib.check(lib.ucn_marching_cubes_count(vol.data_ptr(), X, Y, Z, float(level), ws.data_ptr(), counts.data_ptr(), st))
     nv, nt = (int(v) for v in counts.cpu())                    # the one host read: the outputs have to be allocated
+    if nv >= 1 << 29:         # csrc/mesh.hip packs a lattice point's first vertex id into 29 bits beside 3 flag bits
+        raise RuntimeError(f"marching_cubes: {nv} vertices do not fit the kernel's 29-bit vertex ids; extract the volume in blocks")
     verts = torch.empty(nv, 3, device=dev)
     normals = torch.empty(nv, 3, device=dev) if with_normals else None
     faces = torch.empty(nt, 3, dtype=torch.int32, device=dev)

@@ -372,6 +372,7 @@ class Model(nn.Module):
     #                                      forward kernels without their stores), fp32 compositing.  False: fp32-class always
     sky_side_stream: bool = True         # (with fused_sky_train) the sky branch of a training step on a second HIP stream
     fused_sky_train: bool = True         # training under bf16 autocast runs the sky NeRF on csrc/sky_train.hip (False: eager torch)
+    _warned_eval_route = False
     fused_heads_tail: bool = True        # training: per-ray colour correction + sky blend as one HIP node per level (False: eager torch)
     march_route: str = 'auto'            # which march Model.forward runs: 'auto' = the training graph iff self.training and
     #                                      autograd is enabled, else the fused inference march; 'train' / 'inference' force it
@@ -418,6 +419,11 @@ class Model(nn.Module):
         if route == 'train' or (route == 'auto' and self.training and torch.is_grad_enabled()):
             from . import train_graph
             return train_graph.march_train(self, rand, batch, train_frac, compute_extras, eval_camidx)
+        if route == 'auto' and torch.is_grad_enabled() and not self.training and not Model._warned_eval_route:
+            Model._warned_eval_route = True
+            import warnings
+            warnings.warn("ucnerf_amd Model: eval-mode call with autograd enabled takes the inference route (detached outputs); "
+                          "call model.train() before a training step, or set Model.march_route = 'train'", stacklevel=2)
         with torch.no_grad():
             return self._march(rand, batch, train_frac, compute_extras, eval_camidx, want_history=True)
 
@@ -802,57 +808,59 @@ def render_image(model, accelerator, batch, rand, train_frac, config, verbose=Tr
     replicated, so no other communication exists on the path."""
     from . import dist as udist
     model.eval()
-    # the reference hands over the `accelerator.prepare`d model (train.py:95,330, render.py:119,146, eval.py:103,140):
-    # a DistributedDataParallel wrapper when num_processes > 1.  The march itself is a method of the bare Model.
-    core = unwrap_model(model)
-    height, width = batch['origins'].shape[:2]
-    num_rays = height * width
-    flat = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None and torch.is_tensor(v)}
-    # Rays are marched in TILE-major order (8 x 8 pixel blocks): a wave's 64 lanes are then the rays of one block, whose
-    # samples at one depth index sit within ~8 pixel footprints of each other in BOTH image directions -- on the hash
-    # grid's coarse and middle levels they share lattice cells, i.e. cache lines, and the gather's requests coalesce
-    # (a 64 x 1 pixel row spreads 8x further).  Pixels do not depend on the order; the outputs are put back below.
-    tile = int(getattr(config, 'render_ray_tile', 8))
-    perm = inv = None
-    if tile > 1 and height > 1 and width > 1 and flat['origins'].is_cuda:
-        perm, inv = _tile_order(height, width, tile, flat['origins'].device)
-        flat = {k: v.index_select(0, perm) for k, v in flat.items()}
-    world = getattr(accelerator, 'num_processes', 1)
-    rank = getattr(accelerator, 'process_index', 0)
-    lo, hi = udist.shard_bounds(num_rays, world, rank)
-    shard = {k: v[lo:hi] for k, v in flat.items()}
-    with torch.no_grad():
-        renderings, history = core._march(rand, shard, train_frac, True, eval_camidx, want_history=return_weights)
-    last = renderings[-1]
-    keys = [k for k in last if not k.startswith('ray_')]
-    # rendering['weights'] ([H, W, S] of the last level) is 27x the pixels' payload.  The reference gathers it with
-    # everything else (models.py:965-968) and so does this function by default -- the returned key set never depends
-    # on the world size.  None of the reference's callers reads it unless return_weights=True (where models.py:977
-    # overwrites it with the history's copy): `config.render_gather_weights = False` is the explicit opt-out that drops
-    # the key at EVERY world size (INTEGRATION.md B).
-    if not return_weights and not getattr(config, 'render_gather_weights', True):
-        keys = [k for k in keys if k != 'weights']
-    local = {k: last[k].reshape(hi - lo, -1) for k in keys}
-    if return_weights:
-        local['weights'] = history[-1]['weights'].reshape(hi - lo, -1)
-        local['coord'] = history[-1]['coord'].reshape(hi - lo, -1)
-    shapes = {k: tuple(last[k].shape[1:]) for k in keys}
-    if return_weights:
-        shapes['weights'] = tuple(history[-1]['weights'].shape[1:])
-        shapes['coord'] = tuple(history[-1]['coord'].shape[1:])
-    gathered = udist.all_gather_rows(local, num_rays, world, rank)
-    if inv is not None:
-        gathered = {k: v.index_select(0, inv) for k, v in gathered.items()}
-    rendering = {k: gathered[k].reshape((height, width) + shapes[k]) for k in gathered}
-    # 'ray_*' bundles: vis_num_rays rays per level, drawn like the reference's final randperm subset
-    bundle_keys = [k for k in last if k.startswith('ray_')]
-    if bundle_keys:
-        n_vis = getattr(config, 'vis_num_rays', 16)
-        per_level = [{k: r[k] for k in bundle_keys} for r in renderings]
-        per_level = udist.all_gather_bundles(per_level, world, rank)
-        n_have = per_level[0][bundle_keys[0]].shape[0]
-        pick = torch.randperm(n_have)[:n_vis].to(per_level[0][bundle_keys[0]].device)
-        for k in bundle_keys:
-            rendering[k] = [lvl[k][pick] for lvl in per_level]
-    model.train()                       # ref models.py:1006 (unconditional)
+    try:      # the mode is restored on EVERY exit: a failed render must not leave the next training step on the inference route
+        # the reference hands over the `accelerator.prepare`d model (train.py:95,330, render.py:119,146, eval.py:103,140):
+        # a DistributedDataParallel wrapper when num_processes > 1.  The march itself is a method of the bare Model.
+        core = unwrap_model(model)
+        height, width = batch['origins'].shape[:2]
+        num_rays = height * width
+        flat = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None and torch.is_tensor(v)}
+        # Rays are marched in TILE-major order (8 x 8 pixel blocks): a wave's 64 lanes are then the rays of one block, whose
+        # samples at one depth index sit within ~8 pixel footprints of each other in BOTH image directions -- on the hash
+        # grid's coarse and middle levels they share lattice cells, i.e. cache lines, and the gather's requests coalesce
+        # (a 64 x 1 pixel row spreads 8x further).  Pixels do not depend on the order; the outputs are put back below.
+        tile = int(getattr(config, 'render_ray_tile', 8))
+        perm = inv = None
+        if tile > 1 and height > 1 and width > 1 and flat['origins'].is_cuda:
+            perm, inv = _tile_order(height, width, tile, flat['origins'].device)
+            flat = {k: v.index_select(0, perm) for k, v in flat.items()}
+        world = getattr(accelerator, 'num_processes', 1)
+        rank = getattr(accelerator, 'process_index', 0)
+        lo, hi = udist.shard_bounds(num_rays, world, rank)
+        shard = {k: v[lo:hi] for k, v in flat.items()}
+        with torch.no_grad():
+            renderings, history = core._march(rand, shard, train_frac, True, eval_camidx, want_history=return_weights)
+        last = renderings[-1]
+        keys = [k for k in last if not k.startswith('ray_')]
+        # rendering['weights'] ([H, W, S] of the last level) is 27x the pixels' payload.  The reference gathers it with
+        # everything else (models.py:965-968) and so does this function by default -- the returned key set never depends
+        # on the world size.  None of the reference's callers reads it unless return_weights=True (where models.py:977
+        # overwrites it with the history's copy): `config.render_gather_weights = False` is the explicit opt-out that drops
+        # the key at EVERY world size (INTEGRATION.md B).
+        if not return_weights and not getattr(config, 'render_gather_weights', True):
+            keys = [k for k in keys if k != 'weights']
+        local = {k: last[k].reshape(hi - lo, -1) for k in keys}
+        if return_weights:
+            local['weights'] = history[-1]['weights'].reshape(hi - lo, -1)
+            local['coord'] = history[-1]['coord'].reshape(hi - lo, -1)
+        shapes = {k: tuple(last[k].shape[1:]) for k in keys}
+        if return_weights:
+            shapes['weights'] = tuple(history[-1]['weights'].shape[1:])
+            shapes['coord'] = tuple(history[-1]['coord'].shape[1:])
+        gathered = udist.all_gather_rows(local, num_rays, world, rank)
+        if inv is not None:
+            gathered = {k: v.index_select(0, inv) for k, v in gathered.items()}
+        rendering = {k: gathered[k].reshape((height, width) + shapes[k]) for k in gathered}
+        # 'ray_*' bundles: vis_num_rays rays per level, drawn like the reference's final randperm subset
+        bundle_keys = [k for k in last if k.startswith('ray_')]
+        if bundle_keys:
+            n_vis = getattr(config, 'vis_num_rays', 16)
+            per_level = [{k: r[k] for k in bundle_keys} for r in renderings]
+            per_level = udist.all_gather_bundles(per_level, world, rank)
+            n_have = per_level[0][bundle_keys[0]].shape[0]
+            pick = torch.randperm(n_have)[:n_vis].to(per_level[0][bundle_keys[0]].device)
+            for k in bundle_keys:
+                rendering[k] = [lvl[k][pick] for lvl in per_level]
+    finally:
+        model.train()                   # ref models.py:1006 (unconditional)
     return rendering

@@ -418,10 +418,16 @@ def wgrad(A, B1, B2=None):
     for t in (A, B1) + ((B2,) if B2 is not None else ()):
         assert t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.shape[0] == M and t.shape[1] % 32 == 0, (t.dtype, t.stride(), t.shape)
     n = lib.ucn_wgrad_ws_floats(KA, kb1 + kb2, M)
-    key = (str(A.device), torch.cuda.current_stream().cuda_stream)      # one split-K workspace per stream: the sky branch runs beside the field
-    ws = _WGRAD_WS.get(key)
-    if ws is None or ws.numel() < n:
-        ws = _WGRAD_WS[key] = torch.empty(max(n, 256 * 256 * 288), device=A.device)
+    # one split-K workspace per stream (the sky branch runs beside the field), keyed by the Stream OBJECT kept alive in the entry:
+    # a raw handle value can be recycled by a later stream and would alias a workspace still in flight
+    st = torch.cuda.current_stream()
+    key = (str(A.device), st.cuda_stream)
+    hit = _WGRAD_WS.get(key)
+    if hit is None or hit[0] != st or hit[1].numel() < n:
+        if len(_WGRAD_WS) > 8:
+            _WGRAD_WS.clear()
+        hit = _WGRAD_WS[key] = (st, torch.empty(n, device=A.device))
+    ws = hit[1]
     out = torch.empty(KA, kb1 + kb2, device=A.device)
     _lib.check(lib.ucn_wgrad_bf16(A.data_ptr(), A.stride(0), KA, B1.data_ptr(), B1.stride(0), kb1, _lib.ptr(B2),
                                   0 if B2 is None else B2.stride(0), kb2, M, ws.data_ptr(), out.data_ptr(), _lib.stream()))
@@ -866,8 +872,10 @@ def _ptr_array(tensors):
 
 
 def _tail_fusable(*tensors):
-    """the fused tail kernels (csrc/heads_train.hip) take contiguous float32 device tensors"""
-    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+    """the fused tail kernels (csrc/heads_train.hip) take contiguous float32 device tensors; bf16 affine maps (what the
+    colour-correction nn.Linear layers return under train.py:165's autocast) are upcast by the caller -- exact, and what the eager
+    form's bf16 * fp32 type promotion does"""
+    return all(t is None or (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.float16)) for t in tensors)
 
 
 class _AffineBlend(torch.autograd.Function):
@@ -1057,12 +1065,15 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         affine = lambda M, v: (M[:, :3, :3] * v.reshape(N, 1, 3)).sum(dim=-1, keepdim=True) + M[:, :3, 3:]
         fused_tail = model.fused_heads_tail and _tail_fusable(A, A_sky, renderings[-1]['rgb'])
         acc_last = renderings[-1]['acc'].reshape(N) if (fused_tail and with_sky) else None   # = sum of the last level's weights
+        if fused_tail:                       # explicit upcast (differentiable; a no-op for fp32): the kernel reads float32
+            A32 = A.float().reshape(N, 12)
+            A_sky32 = A_sky.float().reshape(N, 12) if with_sky else None
         for r in renderings:
             if fused_tail:
                 # one launch forward + one backward per level (csrc/heads_train.hip); acc of the last level stands for the
                 # sum of its weights (render.py:199: the same sum, in the compositing kernel's order)
-                rgb = _AffineBlend.apply(r['rgb'].reshape(N, 3), A.reshape(N, 12), acc_last,
-                                         r['sky_rgbs'].reshape(N, 3) if with_sky else None, A_sky.reshape(N, 12) if with_sky else None)
+                rgb = _AffineBlend.apply(r['rgb'].reshape(N, 3).float(), A32, acc_last,
+                                         r['sky_rgbs'].reshape(N, 3).float() if with_sky else None, A_sky32)
                 r['rgb'] = rgb.reshape(N, 1, 1, 3) if eval_camidx is None else rgb.reshape(N, 3)
                 r['affine_trans'] = A
                 if with_sky:

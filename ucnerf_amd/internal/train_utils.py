@@ -240,8 +240,9 @@ class _IdentityLoss(torch.autograd.Function):
         return gA, gB
 
 
-def _f32_cuda(*tensors):
-    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+def _f32_cuda(*tensors, half_ok=False):
+    ok = (torch.float32, torch.bfloat16, torch.float16) if half_ok else (torch.float32,)
+    return all(t.is_cuda and t.dtype in ok for t in tensors)
 
 
 def compute_data_loss(batch, renderings, config):
@@ -331,8 +332,10 @@ def transformIdentityLoss(renderings):
     """ref train_utils.py:159-169."""
     A = renderings[0]['affine_trans']
     A_sky = renderings[0].get('affine_trans_sky')
-    if _f32_cuda(A, *([A_sky] if A_sky is not None else [])) and A.shape[-2:] == (3, 4):
-        return _IdentityLoss.apply(A, A_sky)                          # one HIP node (csrc/heads_train.hip)
+    maps = [A] + ([A_sky] if A_sky is not None else [])
+    if _f32_cuda(*maps, half_ok=True) and A.shape[-2:] == (3, 4):
+        # bf16 maps (the heads ran under train.py:165's autocast) are upcast first: exact, and what `eye (float64) - A` promotes through
+        return _IdentityLoss.apply(A.float(), A_sky.float() if A_sky is not None else None)     # one HIP node (csrc/heads_train.hip)
     eye = torch.eye(4, dtype=torch.float64, device=A.device)[:3].unsqueeze(0).expand(A.shape[0], 3, 4)
     loss = torch.abs(eye - A)
     if 'affine_trans_sky' in renderings[0]:
