@@ -339,8 +339,9 @@ def live_traffic(autocast):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"]
                     half = "DF16_" in name or "_Float16" in name
+                    nerf_level = "Lb0E" in name or ", false>" in name     # the FEW_LEVELS name tag (mangled / demangled): false = NeRF field
                     if (r["Counter_Name"] == ctr and "k_march_features" in name and "bwd" not in name and half == bool(autocast)
-                            and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 500000):     # NeRF-level launches (prop: 0.1 ms)
+                            and nerf_level):
                         tot += float(r["Counter_Value"]) * 1024.0
                         n += 1
             if n == 0:
@@ -609,7 +610,7 @@ def main():
         lo, hi = udist.shard_bounds(n_rays, world, rank)
         rays_rank = (hi - lo) * args.steps
         assert rays_seen[1] == rays_rank
-        gather = dict(bound="hbm", kernel="k_march_features<2> (NeRF level)" + (", half tables" if args.autocast else ""),
+        gather = dict(bound="hbm", kernel="k_march_features<2, 256, float, false> (FEW_LEVELS = false: the NeRF-level launches)" + (", half tables" if args.autocast else ""),
                       achieved=rays_seen[1] * (GATHER_BYTES_NERF // 2 if args.autocast else GATHER_BYTES_NERF) / (feat_ms[1] * 1e-3) / 1e9,
                       peak=PEAK_HBM_GBS, unit="GB/s",
                       avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)

@@ -139,6 +139,12 @@ int ucn_tsdf_integrate(const float *voxel_world, uint32_t N, const float *w2c /*
  * (4 bytes per level and sample, round to nearest even) instead of float pairs: the operand format of the bf16 inference
  * MLP (ucn_train_fwd with feat_level_dim = 2 | UCN_FEAT_BF16), which would round the floats the same way. */
 #define UCN_FEATURES_BF16 0x400
+/* OR-ed into ucn_march_features_backward's layout: accumulate the row blocks in int32 FIXED POINT (one fire-and-forget 64-bit LDS add
+ * per channel pair instead of a compare-and-swap round trip; scale = a power of two from a guaranteed per-task bound on every row sum,
+ * so it cannot overflow).  Order-independent, hence bit-reproducible per task; resolution ~2^-30 of the task's summed |gradient| --
+ * the autocast training step's mode (the reference accumulates that step's table gradient in fp16, gridencoder.cu:319-334); the fp32
+ * step and every parity test of it keep exact fp32 adds.  Ignored for level_dim 1 and for calls of more than 2^22 samples. */
+#define UCN_BWD_FIXED_POINT 0x800
 /* OR-ed into ucn_train_fwd's feat_level_dim: `feat` holds the bf16 pairs UCN_FEATURES_BF16 produced. */
 #define UCN_FEAT_BF16 0x100
 

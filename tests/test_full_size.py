@@ -141,6 +141,77 @@ def test_featurisation_is_linear_with_closed_form_on_ones_and_exact_adjoint(scen
         assert abs(a - b) <= 1e-5 * s, (l, a, b, s)
 
 
+def test_fixed_point_row_blocks_against_the_float_row_blocks(scene):
+    """UCN_BWD_FIXED_POINT (the autocast training step's table gradient; r04): int32 fixed-point row blocks, one 64-bit LDS add
+    per channel pair.  On the training batch of config B (8192 rays x 128 samples, all 16 levels) against the exact-fp32-add
+    route: (i) no row differs by more than the rounding model allows -- a task's resolution is q <= 2^-29 of ITS summed
+    max_c |g| (power-of-two scale from a guaranteed bound), every addend is rounded to nearest (+- q / 2, unbiased), a row
+    collects a few hundred of them; (ii) the adjoint identity holds to 1e-4 of the absolute sum (the float route: 1e-5);
+    (iii) the error is unbiased: its mean over the touched rows is << its rms; (iv) non-finite gradients poison, not vanish."""
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    model, flat, n_total = scene
+    n = 8192
+    batch = _pick(flat, n_total, n, seed=9)
+    with torch.no_grad():
+        _, hist = model(False, batch, 1.0, True)
+    mlp = model.nerf_mlp
+    enc = mlp.encoder
+    L, C = enc.num_levels, enc.level_dim
+    sdist = hist[-1]["sdist"].reshape(n, -1).contiguous()
+    S = sdist.shape[1] - 1
+    basis = torch.empty(n, 6, device="cuda")
+    rvec = batch["rand_vec"][:, 3:6].contiguous()
+    _lib.check(lib.ucn_cone_basis(batch["cam_dirs"].data_ptr(), rvec.data_ptr(), n, basis.data_ptr(), _lib.stream()))
+    near, far, rad = (batch[k].reshape(-1).contiguous() for k in ("near", "far", "radii"))
+    geom = (sdist, near, far, batch["origins"], batch["directions"], basis, rad, None, None)
+    std_scale = float(model.std_scale)
+    g = torch.Generator(device="cuda").manual_seed(10)
+    grad = torch.randn(n * S, L * C, device="cuda", generator=g) * 1e-3          # autograd's layout; a realistic magnitude
+    grad[::5] = 0
+    ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.field()), n, S), device="cuda")
+
+    def run(flag, gr=grad):
+        out = torch.zeros_like(enc.embeddings)
+        _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.field()), *[_lib.ptr(t) for t in geom], std_scale, n, S,
+                                                   0, 1 | flag, gr.data_ptr(), out.data_ptr(), ws.data_ptr(), _lib.stream()))
+        return out
+    want = run(0)
+    got = run(_lib.BWD_FIXED_POINT)
+    err = (got - want).double()
+    # a task (row block x sample part) sees at most B / split samples; bound its resolution by the WHOLE call's sum (looser)
+    l1 = float(grad.reshape(n * S, L, C).abs().amax(-1).double().sum(0).max())
+    q = l1 * 2.0 ** -29
+    touched = want != 0
+    n_touched = int(touched.sum())
+    assert n_touched > 1e6
+    rms = float(err[touched].pow(2).mean().sqrt())
+    print(f"fixed point: resolution bound {q:.3e}, max |err| {float(err.abs().max()):.3e}, rms {rms:.3e}, mean {float(err[touched].mean()):.3e}, "
+          f"max |grad row| {float(want.abs().max()):.3e}")
+    assert float(err.abs().max()) <= 40 * q                    # a few hundred addends x q / 2, random signs (level 0: more addends, run-merged)
+    assert abs(float(err[touched].mean())) <= 0.05 * rms + 1e-12     # round to nearest: no drift
+    assert rms <= 2e-3 * float(want[touched].double().pow(2).mean().sqrt())
+    # adjoint identity through the fixed-point route
+    T2 = torch.rand(enc.embeddings.shape, device="cuda", generator=g) * 2 - 1
+    d2 = _lib.UcnField.from_buffer_copy(mlp.field())
+    d2.embeddings = T2.data_ptr()
+    f2 = _features(lib, _lib, d2, geom, n, S, std_scale, L, C)                  # [L][B][C]
+    gl = grad.reshape(n * S, L, C).permute(1, 0, 2)
+    lhs = float((gl.double() * f2.double()).sum())
+    rhs = float((got.double() * T2.double()).sum())
+    scale = float((gl.double() * f2.double()).abs().sum())
+    assert abs(lhs - rhs) <= 1e-4 * scale, (lhs, rhs, scale)
+    # the same call twice: the row blocks are order-independent; what remains is the float flush of `split` parts per block
+    again = run(_lib.BWD_FIXED_POINT)
+    assert float((again - got).abs().max()) <= 1e-6 * float(want.abs().max())
+    # a NaN / inf in the feature gradient must not vanish in the integer conversion
+    bad = grad.clone()
+    bad[12345, 3] = float("nan")
+    bad[54321, 20] = float("inf")
+    out = run(_lib.BWD_FIXED_POINT, bad)
+    assert not bool(torch.isfinite(out).all())
+
+
 @pytest.mark.gpu
 def test_coresident_launch_shapes_give_identical_pixels():
     """Model.overlap_streams: featurisation of pass i + 1 on a second HIP stream beside the MLP of pass i, both in their
@@ -278,3 +349,72 @@ def test_table_gradient_over_random_grid_shapes():
     p = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_backward_grids.py"), "32"], capture_output=True, text=True,
                        timeout=900, cwd=repo)
     assert p.returncode == 0 and "mismatches: 0" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def _oracle_vs_gpu_on_the_frame(heads, autocast, mlp_mode=None, n=2048, grid="B"):
+    """`n` strided rays of bench.py's frame (the headline workload's own rays, weights and cone-basis draws) through the product
+    path and through the CPU oracle at FULL table size (T = 2^19, 16 levels, 64 + 128 samples, 256-wide colour MLP): the
+    headline parity as a test, not only as a number bench.py prints.  ~2 s of oracle time at ~2 k rays/s."""
+    from ucnerf_amd.internal import models
+    dev = torch.device("cuda", 0)
+    model, cfg, sd = bench.build_model(dev, heads=heads, grid=grid)
+    saved = models.MLP.mlp_mode
+    try:
+        if mlp_mode is not None:
+            for m in (model.nerf_mlp, model.prop_mlp_0):
+                m.mlp_mode = mlp_mode
+        rays = bench.frame_rays(dev, virtual=heads)
+        n_total = bench.H_IMG * bench.W_IMG
+        idx = torch.linspace(0, n_total - 1, n).long()
+        flat = {k: v.reshape(n_total, -1)[idx.to(dev)].contiguous() for k, v in rays.items()}
+        rand_vec = torch.randn(n, 6, generator=torch.Generator().manual_seed(1))
+        batch = dict(flat, rand_vec=rand_vec.to(dev))
+        eval_camidx = torch.tensor([7]) if heads else None
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            rend, _ = model(False, batch, 1.0, True, eval_camidx=eval_camidx)
+        got = rend[-1]["rgb"].reshape(n, 3).float().cpu()
+        spec = rm.make_spec(grid, model_sky=True, brightness_correction=True, training_views=210) if heads else rm.make_spec(grid)
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        noise = [rm.LevelNoise(rand_vec=rand_vec[:, 3 * l:3 * l + 3]) for l in range(2)]
+        with torch.no_grad():
+            want, _ = rm.model_forward(spec, sd, {k: v.cpu() for k, v in flat.items()}, noise, eval_camidx=eval_camidx)
+        want = want[-1]["rgb"].reshape(n, 3)
+    finally:
+        models.MLP.mlp_mode = saved
+    linf = float((got - want).abs().max())
+    psnr = float(-10 * np.log10(max(float(((got - want) ** 2).mean()), 1e-20)))
+    return linf, psnr
+
+
+@pytest.mark.parametrize("mlp_mode", [1, 0])
+def test_config_B_full_tables_vs_oracle(mlp_mode):
+    """BASELINE configs[1] (the headline): RGB L-inf <= 1e-4 against the oracle (north_star's fp32 bar), in the default split-f16
+    MFMA mode (fp32-class) and in the exact fp32-input MFMA mode."""
+    linf, psnr = _oracle_vs_gpu_on_the_frame(heads=False, autocast=False, mlp_mode=mlp_mode)
+    print(f"config B, mlp_mode {mlp_mode}: rgb L-inf {linf:.3e}, PSNR {psnr:.1f} dB")
+    assert linf <= 1e-4 and psnr >= 95.0, (linf, psnr)
+
+
+def test_config_B_with_heads_full_tables_vs_oracle():
+    """BASELINE configs[4]'s model (sky NeRF layer + colour-correction head, rays of perturbed poses, eval_camidx = 7) in fp32-class
+    arithmetic: the same 1e-4 bar."""
+    linf, psnr = _oracle_vs_gpu_on_the_frame(heads=True, autocast=False)
+    print(f"config B + heads: rgb L-inf {linf:.3e}, PSNR {psnr:.1f} dB")
+    assert linf <= 1e-4 and psnr >= 95.0, (linf, psnr)
+
+
+def test_config_B_mixed_precision_route_has_a_stated_bar():
+    """The 'mixed bf16/fp32' route of BASELINE configs[4] (render under a bf16 autocast: half tables, bf16 MFMA dense layers, fp32
+    resampling / compositing) is NOT the fp32 route and is not held to 1e-4.  Its bar: RGB L-inf <= 2e-3 (half a bf16 step of
+    a value in [0.5, 1): one rounding of the output's size) and PSNR >= 70 dB against the fp32 oracle -- an 8-bit image differs
+    from its source by 48 dB.  The measured figures are printed (driver's r03 line: L-inf 1.5e-4 on a 5-camera frame)."""
+    linf, psnr = _oracle_vs_gpu_on_the_frame(heads=True, autocast=True)
+    print(f"config B + heads, mixed: rgb L-inf {linf:.3e}, PSNR {psnr:.1f} dB")
+    assert linf <= 2e-3 and psnr >= 70.0, (linf, psnr)
+
+
+def test_waymo_gin_grid_full_tables_vs_oracle():
+    """The reference's own waymo.gin grid (L = 10, C = 4, T = 2^21, 128 + 32 samples) at full table size: the same 1e-4 bar."""
+    linf, psnr = _oracle_vs_gpu_on_the_frame(heads=False, autocast=False, n=1024, grid="R")
+    print(f"waymo.gin grid: rgb L-inf {linf:.3e}, PSNR {psnr:.1f} dB")
+    assert linf <= 1e-4 and psnr >= 95.0, (linf, psnr)

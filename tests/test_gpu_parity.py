@@ -670,6 +670,11 @@ def test_features_backward_algorithms_agree():
     assert H.maxdiff(run(4, 1, g1), want) <= tol
     twice = run(0, 0, g0, ws, run(0, 0, g0, ws))              # accumulates into grad_embeddings
     assert H.maxdiff(twice, 2 * want) <= 2 * tol
+    # fixed-point row blocks (UCN_BWD_FIXED_POINT): resolution 2^-29 of a task's summed |g|, in every gradient layout
+    tol_fx = 2e-4 * float(want.abs().max())
+    for lay, gg in ((0, g0), (1, g1), (3, g3)):
+        assert H.maxdiff(run(0, lay | _lib.BWD_FIXED_POINT, gg, ws), want) <= tol_fx, lay
+    assert H.maxdiff(run(0, 1 | _lib.BWD_FIXED_POINT, g1), want) <= tol   # no workspace: the flag is ignored (float rows)
 
 
 def test_render_image_vs_golden_and_invariants():

@@ -137,20 +137,37 @@ def main():
     with torch.no_grad():
         rend, hist = model._march(False, sub, 1.0, True, None, want_history=True)
     w = hist[-1]["weights"].reshape(idx.numel(), -1).double()
-    print("benchmark frame, 65536 strided rays: acc mean", float(w.sum(-1).mean()))
+    true_rgb, t_hit = scene_colour(sub["origins"], sub["directions"])
+    hit = t_hit < 1e8                                       # rays that meet the plane or a sphere (the rest see the far background)
+    acc = w.sum(-1)
+    mse = float(((rend[-1]["rgb"].reshape(-1, 3).double() - true_rgb.double()) ** 2).mean())
+    print(f"benchmark frame, 65536 strided rays: psnr vs the analytic scene {-10 * np.log10(max(mse, 1e-12)):.2f} dB; acc mean {float(acc.mean()):.4f}; "
+          f"on the {int(hit.sum())} surface-hit rays: acc mean {float(acc[hit].mean()):.4f}, 1 % quantile {float(torch.quantile(acc[hit], 0.01)):.4f}")
     for w_min in (1e-9, 4e-8, 1e-6, 1e-5, 1e-4):
         keep = w >= w_min
         print(f"  weight >= {w_min:g}: keep {float(keep.double().mean()):.4f} of the samples; worst lost weight per ray "
               f"{float((w * (~keep)).sum(-1).max()):.3e}")
     q = torch.tensor([0.01, 0.1, 0.5, 0.9, 0.99], device=dev, dtype=torch.double)
     print("  weight quantiles (1, 10, 50, 90, 99 %):", [f"{v:.3e}" for v in torch.quantile(w.flatten()[:4000000], q).tolist()])
+    # frame time against the alive fraction: thresholds from "everything alive" to "nothing alive" -> the fixed cost of the
+    # compacted route, its slope, and the alive fraction below which it beats the plain route
     model.compact_min_weight = 0.0
     ms0, rgb0 = frame_ms(model, flat)
-    model.compact_min_weight = 4e-8
-    model._alive_stats = None
-    ms1, rgb1 = frame_ms(model, flat)
-    print(f"full frame: {ms0:.1f} ms without compaction, {ms1:.1f} ms with compact_min_weight = 4e-8; "
-          f"rgb L-inf between the two {float((rgb0 - rgb1).abs().max()):.2e}")
+    pts = []
+    for thr in (1e-45, 4e-8, 1e-6, 1e-4, 1e-2, 2.0):
+        model.compact_min_weight = thr
+        model._alive_stats = []
+        frame_ms(model, flat, reps=1)                        # the statistics run (its host reads are not timed)
+        alive = sum(a for a, _ in model._alive_stats) / max(1, sum(b for _, b in model._alive_stats))
+        model._alive_stats = None
+        ms1, rgb1 = frame_ms(model, flat)
+        pts.append((alive, ms1))
+        print(f"  compact_min_weight {thr:g}: alive {alive:.4f}, frame {ms1:.1f} ms (plain route {ms0:.1f} ms), rgb L-inf vs plain {float((rgb0 - rgb1).abs().max()):.2e}")
+    a = np.array([p[0] for p in pts]); t = np.array([p[1] for p in pts])
+    slope, fixed = np.polyfit(a, t, 1)
+    print(f"compacted route: {fixed:.1f} ms at 0 % alive + {slope:.1f} ms x alive fraction; plain route {ms0:.1f} ms; "
+          f"break-even alive fraction {(ms0 - fixed) / slope:.3f}")
+    model.compact_min_weight = 0.0
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
 ABI_VERSION = 19
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
+BWD_FIXED_POINT = 0x800    # ucn_march_features_backward layout flag: int32 fixed-point row blocks (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
 FEAT_BF16 = 0x100          # ucn_train_fwd feat_level_dim flag: the features are those pairs          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
 

@@ -28,6 +28,7 @@
 //     for given positions -- stay bit-identical to the oracle.
 #include "ucn_common.h"
 #include "wave_dpp.h"
+#include <type_traits>
 
 namespace {
 
@@ -365,8 +366,37 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
 // changed in between has to retry, and on the coarser levels neighbouring lanes DO share rows.  So:
 //   CAS = false (coarse levels, run-merged updates): plain ds_add_f32, contention-proof;
 //   CAS = true  (fine levels): one compare-and-swap attempt, the lanes that lose fall back to ds_add_f32.
-template <uint32_t C, bool CAS>
-__device__ __forceinline__ void lds_row_add(float *acc, uint32_t r, const float (&v)[C]) {
+// FIXED-POINT accumulation (the autocast training step; r04).  The row block may hold, instead of C floats per row, C / 2
+// 64-bit words per row, each TWO int32 fixed-point channels: word = (b << 32) + sign_extend(a).  One fire-and-forget ds_add_u64
+// per channel pair replaces the read + compare-and-swap round trip (53 % of this kernel's instruction waits were LDS,
+// profiles/r03/pmc_table_train.txt): integer adds are associative, so the 64-bit total is exact mod 2^64 whatever the order, and
+// it splits back uniquely into (a, b) as long as each channel's FINAL sum fits int32.  That is guaranteed, not hoped for: the
+// addends of a sample are (w_k damp / 6) g_c with sum_k w_k = 1, damp <= 1, six points -- their absolute values sum to at most
+// |g_c|, so any row's |sum| <= L1 = sum over the task's samples of |g| (accumulated by the mask pass); the task scales its
+// gradients by the power of two that puts L1 at <= 2^30 (rounding adds <= 1/2 per addend, < 2^24 addends per task).  The
+// accumulator type selects the mode: `float` rows (exact fp32 adds, the fp32 route and every test of it) or `FxLane` rows.
+struct FxLane { float raw; };                                  // same size as float: row / channel pointer arithmetic is shared
+template <typename A> constexpr bool kFixed = false;
+template <> constexpr bool kFixed<FxLane> = true;
+__device__ __forceinline__ unsigned long long fixed_pack(float a, float b) {
+    const long long ia = (long long)__float2int_rn(a), ib = (long long)__float2int_rn(b);
+    return (unsigned long long)((ib << 32) + ia);
+}
+__device__ __forceinline__ void fixed_unpack(unsigned long long w, float inv, float &a, float &b) {
+    const int lo = (int)(uint32_t)w;
+    const long long hi = ((long long)w - (long long)lo) >> 32;
+    a = (float)lo * inv;
+    b = (float)(int)hi * inv;
+}
+template <uint32_t C, bool CAS, typename A>
+__device__ __forceinline__ void lds_row_add(A *acc_, uint32_t r, const float (&v)[C]) {
+    if constexpr (kFixed<A>) {
+        static_assert(C % 2u == 0u, "fixed-point rows pack channel pairs");
+#pragma unroll
+        for (uint32_t c = 0; c < C; c += 2) atomicAdd(reinterpret_cast<unsigned long long *>(acc_ + r * C + c), fixed_pack(v[c], v[c + 1]));
+        return;
+    }
+    float *acc = reinterpret_cast<float *>(acc_);
     if constexpr (CAS && (C % 2u == 0u)) {
 #pragma unroll
         for (uint32_t c = 0; c < C; c += 2) {
@@ -400,8 +430,8 @@ struct RowRun {
     bool have;
 };
 
-template <uint32_t C>
-__device__ __forceinline__ void run_flush(float *__restrict__ acc, uint32_t row_lo, uint32_t nrows, const RowRun<C> &run) {
+template <uint32_t C, typename A>
+__device__ __forceinline__ void run_flush(A *__restrict__ acc, uint32_t row_lo, uint32_t nrows, const RowRun<C> &run) {
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
         const uint32_t r = run.cur[k] - row_lo;
@@ -409,8 +439,8 @@ __device__ __forceinline__ void run_flush(float *__restrict__ acc, uint32_t row_
     }
 }
 
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void run_merge_sample(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void run_merge_sample(const UcnLevel &lv, A *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
                                                  const float (&u)[6][3], const float (&rs)[6], const float (&gout)[C],
                                                  RowRun<C> &run) {
 #pragma unroll
@@ -439,8 +469,8 @@ __device__ __forceinline__ void run_merge_sample(const UcnLevel &lv, float *__re
 
 // Row-block variant of level_scatter: only corners whose row lies in [row_lo, row_lo + nrows) count, and
 // they go to the workgroup's LDS copy of that row block (lds_row_add).
-template <uint32_t C, bool HASHED, bool POW2, bool MERGE>
-__device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo,
+template <uint32_t C, bool HASHED, bool POW2, bool MERGE, typename A>
+__device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, A *__restrict__ acc, uint32_t row_lo,
                                                     uint32_t nrows, const float (&u)[6][3], const float (&rs)[6],
                                                     const float (&gout)[C]) {
     if constexpr (MERGE) {
@@ -704,7 +734,10 @@ static LevelGroups make_groups(const UcnLevels &lv, uint32_t levels_per_block) {
 }
 
 // layout: 0 = [L][N*S][C] with b = ray*S+s; 1 = [N*S][L*C]; 2 = [L][S*N][C] with b = s*N+ray
-template <uint32_t C, uint32_t TPB, typename TT = float>
+// FEW_LEVELS is a NAME TAG only (same code): grids of <= 8 levels (the proposal fields: L = 6) and of more (the NeRF field:
+// L = 16 / 10) get distinct kernel names, so that a rocprofv3 --stats summary separates the proposal-level from the
+// NeRF-level launches without subtracting one from the other.
+template <uint32_t C, uint32_t TPB, typename TT = float, bool FEW_LEVELS = false>
 __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const TT *__restrict__ table, RayInputs in,
                                                         HexPattern hx, float std_scale, uint32_t N, uint32_t S,
                                                         LevelGroups grp, int layout, float *__restrict__ features,
@@ -909,10 +942,13 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
                                                           const float *__restrict__ grad_features, GradStrides gs, uint32_t C,
                                                           float *__restrict__ geom, uint32_t *__restrict__ masks,
                                                           float *__restrict__ grad_level_major /*[L][N*S][C], / 6*/,
-                                                          uint32_t *__restrict__ task_counter) {
+                                                          uint32_t *__restrict__ task_counter,
+                                                          float *__restrict__ l1_partial /*[L][gridDim.x] or null: sum over the block's samples of max_c |g|*/) {
     const size_t B = (size_t)N * S;
     const size_t b = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (b < 8) task_counter[b] = 0u;                      // the compacted kernel's persistent workgroups pull tasks from here
+    __shared__ float s_l1[UCN_MAX_LEVELS][4];             // per level: the four waves' sums of max_c |g| (fixed-point bound)
+    if ((threadIdx.x & 63u) < UCN_MAX_LEVELS) s_l1[threadIdx.x & 63u][threadIdx.x >> 6] = 0.0f;   // own column (a wave past the end leaves zeros)
     if ((b & ~(size_t)63) >= B) return;                   // whole waves only: the bit planes below are built by wave ballots
     const bool valid = b < B;
     const size_t bb = valid ? b : B - 1;                  // lanes past the end recompute the last sample and store nothing
@@ -930,13 +966,20 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         const UcnLevel lv = lvls.lv[lvl];
         const uint32_t nb_l = (lv.rows + (1u << plan.shift) - 1u) >> plan.shift;
         bool nz = false;
+        float gmax = 0.0f;
         for (uint32_t c = 0; c < C; c++) {
             const float g = grad_features[lvl * gs.level + bb * gs.sample + c * gs.chan];
             nz |= valid && g != 0.0f;
+            gmax = fmaxf(gmax, valid ? fabsf(g) : 0.0f);
+            if (valid && !(fabsf(g) <= 3.0e38f)) gmax = __builtin_inff();        // NaN / inf poisons the bound (fmaxf drops NaN)
             // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample,
             // already divided by the 6 multisamples of the mean (an IEEE division is ~13 VALU instructions per channel;
             // an item stage would repeat it ~27 times per sample and level)
             if (valid) grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
+        }
+        if (l1_partial) {                                   // (workgroup-uniform; every wave of the block gets here: no early `continue` above)
+            const float wsum = wave_sum_dpp<float>(gmax);
+            if ((threadIdx.x & 63u) == 0u) s_l1[lvl][threadIdx.x >> 6] = wsum;
         }
         if (nb_l > 32u) {
             // one bit per (sample, block) in nb / 32 words: set through the thread's own LDS column (dynamic word index)
@@ -1014,13 +1057,28 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             }
         }
     }
+    if (l1_partial) {
+        __syncthreads();
+        if (threadIdx.x < lvls.L)                           // fixed order: deterministic
+            l1_partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+                ((s_l1[threadIdx.x][0] + s_l1[threadIdx.x][1]) + s_l1[threadIdx.x][2]) + s_l1[threadIdx.x][3];
+    }
 }
 
 // Two rows of the block at once (the x0 / x0 + 1 corners of one (y, z) combination): both reads, then both compare-and-swaps
 // -- two LDS round trips where two lds_row_add calls make four.  A lane whose row is outside the block skips its half.
-template <uint32_t C>
-__device__ __forceinline__ void lds_row_add_pair(float *acc, uint32_t r0, bool in0, const float (&v0)[C], uint32_t r1, bool in1,
+template <uint32_t C, typename A>
+__device__ __forceinline__ void lds_row_add_pair(A *acc_, uint32_t r0, bool in0, const float (&v0)[C], uint32_t r1, bool in1,
                                                  const float (&v1)[C]) {
+    if constexpr (kFixed<A>) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c += 2) {
+            if (in0) atomicAdd(reinterpret_cast<unsigned long long *>(acc_ + r0 * C + c), fixed_pack(v0[c], v0[c + 1]));
+            if (in1) atomicAdd(reinterpret_cast<unsigned long long *>(acc_ + r1 * C + c), fixed_pack(v1[c], v1[c + 1]));
+        }
+        return;
+    }
+    float *acc = reinterpret_cast<float *>(acc_);
     if constexpr (C % 2u == 0u) {
 #pragma unroll
         for (uint32_t c = 0; c < C; c += 2) {
@@ -1050,8 +1108,8 @@ __device__ __forceinline__ void lds_row_add_pair(float *acc, uint32_t r0, bool i
 // two LDS round trips) per wave; here a lane lists its in-block combinations first (4 row pairs, no weights) and the wave loops
 // over "my next combination" -- as many rounds as the busiest lane has combinations (2-3), each with both corners' update in
 // flight together.  Same addends ((w_k damp) g_c, w_k = ((wx wy) wz)) as point_scatter_block.
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void point_scatter_combos(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void point_scatter_combos(const UcnLevel &lv, A *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
                                                      const float (&p)[3], float rsj, const float (&gout)[C]) {
     if (!in_unit_cube(p[0], p[1], p[2])) return;
     float fx = fmaf(p[0], lv.scale, 0.5f), fy = fmaf(p[1], lv.scale, 0.5f), fz = fmaf(p[2], lv.scale, 0.5f);
@@ -1104,8 +1162,8 @@ __device__ __forceinline__ void point_scatter_combos(const UcnLevel &lv, float *
 }
 
 // Direct (no run merging) scatter of ONE multisample point into the workgroup's row block.
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, float *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void point_scatter_block(const UcnLevel &lv, A *__restrict__ acc, uint32_t row_lo, uint32_t nrows,
                                                     const float (&p)[3], float rsj, const float (&gout)[C]) {
     if (!in_unit_cube(p[0], p[1], p[2])) return;
     float fx, fy, fz, w[8];
@@ -1212,10 +1270,10 @@ constexpr uint32_t kScan = UCN_KSCAN;                          // samples per th
 
 template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
 __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, const float *__restrict__ gl,
-                                          const float *__restrict__ geom, float (&u)[6][3], float (&rs)[6], float (&gout)[C]) {
+                                          const float *__restrict__ geom, float (&u)[6][3], float (&rs)[6], float (&gout)[C], float gscale) {
     const uint32_t b = valid ? item & 0x1FFFFFFFu : 0u, j = valid ? item >> 29 : 0u;
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++) gout[c] = gl[(size_t)b * C + c];                      // d(mean over the 6 multisamples): / 6 done by k_cast_cache_masks
+    for (uint32_t c = 0; c < C; c++) gout[c] = gl[(size_t)b * C + c] * gscale;             // d(mean over the 6 multisamples): / 6 done by k_cast_cache_masks; x the task's power-of-two fixed-point scale (1 for float rows)
     if constexpr (COARSE) {
 #pragma unroll
         for (uint32_t jj = 0; jj < 6; jj++) {
@@ -1228,11 +1286,11 @@ __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, c
     }
 }
 
-template <uint32_t C, bool HASHED, bool POW2, bool COARSE, bool RUNS, int FINE = 0>
-__device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
+template <uint32_t C, bool HASHED, bool POW2, bool COARSE, bool RUNS, int FINE = 0, typename A = float>
+__device__ __forceinline__ void cmp_block(const UcnLevel &lv, A *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
                                           uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                           const uint32_t *__restrict__ mp, const float *__restrict__ gl,
-                                          const float *__restrict__ geom) {
+                                          const float *__restrict__ geom, float gscale = 1.0f) {
     // one mask word per sample: coarse levels bit `blk`; fine levels the word of this block's group of four,
     // bit 4 * j + (blk & 3) for multisample j (k_cast_cache_masks)
     constexpr uint32_t P = COARSE ? 1u : 6u;                                  // items a sample can contribute
@@ -1312,7 +1370,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 RowRun<C> run;
                 run.have = false;
                 float un[6][3], rsn[6], gn[C];
-                cmp_fetch<C, HASHED, POW2, true>(q[(head + kPer * lane) & (kQueue - 1u)], kPer * lane < avail, B, gl, geom, un, rsn, gn);
+                cmp_fetch<C, HASHED, POW2, true>(q[(head + kPer * lane) & (kQueue - 1u)], kPer * lane < avail, B, gl, geom, un, rsn, gn, gscale);
 #pragma unroll 1
                 for (uint32_t k = 0; k < kPer; k++) {
                     float uc[6][3], rsc[6], gc[C];
@@ -1326,7 +1384,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                     for (uint32_t c = 0; c < C; c++) gc[c] = gn[c];
                     const uint32_t idx = kPer * lane + k;
                     if (k + 1 < kPer)
-                        cmp_fetch<C, HASHED, POW2, true>(q[(head + idx + 1u) & (kQueue - 1u)], idx + 1u < avail, B, gl, geom, un, rsn, gn);
+                        cmp_fetch<C, HASHED, POW2, true>(q[(head + idx + 1u) & (kQueue - 1u)], idx + 1u < avail, B, gl, geom, un, rsn, gn, gscale);
                     if (idx < avail) run_merge_sample<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, uc, rsc, gc, run);
                 }
                 if (run.have) run_flush<C>(s_acc, row_lo, nrows, run);
@@ -1338,8 +1396,8 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, float *__restrict_
                 const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
                 const bool v0 = lane < avail, v1 = lane + 64u < avail;
                 float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
-                cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0);
-                cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1);
+                cmp_fetch<C, HASHED, POW2, COARSE>(i0, v0, B, gl, geom, u0, rs0, g0, gscale);
+                cmp_fetch<C, HASHED, POW2, COARSE>(i1, v1, B, gl, geom, u1, rs1, g1, gscale);
                 if (v0) {
                     if constexpr (COARSE) level_scatter_block<C, HASHED, POW2, FINE == 0>(lv, s_acc, row_lo, nrows, u0, rs0, g0);
                     else if constexpr (FINE == 2) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
@@ -1399,10 +1457,10 @@ __device__ __forceinline__ uint32_t wide_row(const UcnLevel &lv, uint32_t xv, ui
 // (on the coarser levels all six points of a sample share the cell: six times fewer LDS updates, and none of the same-row
 // collisions that consecutive points of a sample would cause).  (A function, force-inlined at its two call sites: a lambda
 // called from several sites gets outlined by hipcc -- see cmp_block.)
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void wide_drain(const UcnLevel &lv, float *__restrict__ s_acc, const uint32_t *__restrict__ q2, uint32_t &head2,
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void wide_drain(const UcnLevel &lv, A *__restrict__ s_acc, const uint32_t *__restrict__ q2, uint32_t &head2,
                                            uint32_t tail2, uint32_t thr, uint32_t lane, uint32_t row_lo, uint32_t nrows,
-                                           const float *__restrict__ gl, const float *__restrict__ geom) {
+                                           const float *__restrict__ gl, const float *__restrict__ geom, float gscale) {
     while (tail2 - head2 >= thr && tail2 != head2) {
         const uint32_t avail = tail2 - head2 < 64u ? tail2 - head2 : 64u;
         const bool v = lane < avail;
@@ -1411,7 +1469,7 @@ __device__ __forceinline__ void wide_drain(const UcnLevel &lv, float *__restrict
         uint32_t pts = it >> 26;
         float gout[C], v0[C], v1[C];
 #pragma unroll
-        for (uint32_t cc = 0; cc < C; cc++) { gout[cc] = gl[(size_t)b * C + cc]; v0[cc] = 0.0f; v1[cc] = 0.0f; }
+        for (uint32_t cc = 0; cc < C; cc++) { gout[cc] = gl[(size_t)b * C + cc] * gscale; v0[cc] = 0.0f; v1[cc] = 0.0f; }
         uint32_t r0 = 0u, r1 = 0u;
         while (pts) {
             const uint32_t j = (uint32_t)__builtin_ctz(pts);
@@ -1444,11 +1502,11 @@ __device__ __forceinline__ void wide_load_group(const uint32_t *__restrict__ T, 
     }
 }
 
-template <uint32_t C, bool HASHED, bool POW2>
-__device__ __forceinline__ void wide_block(const UcnLevel &lv, float *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void wide_block(const UcnLevel &lv, A *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t blk,
                                            uint32_t row_lo, uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                            const uint32_t *__restrict__ mp, const float *__restrict__ gl,
-                                           const float *__restrict__ geom) {
+                                           const float *__restrict__ geom, float gscale) {
     uint32_t *q1 = q, *q2 = q + kRing1;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t head1 = 0, tail1 = 0, head2 = 0, tail2 = 0;                      // wave-uniform ring positions
@@ -1556,13 +1614,13 @@ __device__ __forceinline__ void wide_block(const UcnLevel &lv, float *__restrict
                 head2 = tail2;
 #endif
                 // ring 2: <= 63 left over + <= 256 appended per round <= kRing2
-                wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 64u, lane, row_lo, nrows, gl, geom);
+                wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 64u, lane, row_lo, nrows, gl, geom, gscale);
             }
             head1 += avail;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 1u, lane, row_lo, nrows, gl, geom);
+    wide_drain<C, HASHED, POW2>(lv, s_acc, q2, head2, tail2, 1u, lane, row_lo, nrows, gl, geom, gscale);
 }
 
 #ifdef UCN_WG_CLOCK                                    // tools/bwd_balance.py: start / end time of every workgroup (experiment builds only)
@@ -1573,14 +1631,17 @@ __device__ uint64_t g_wg_clock[8192][3];
 // task times differ (45 ... 1010 us inside the uneven levels) a full XCD blocks the dispatch for all eight -- the workgroup
 // clocks of the benchmark grid showed 164-208 of 256 CUs busy behind the uneven levels and a 1.3 ms drain at the end
 // (tools/bwd_balance.py: 4.26 ms where the workgroup times sum to 3.70 ms per CU).
-template <uint32_t C>
+template <uint32_t C, bool FX = false>
 __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls, float *__restrict__ grad_table, uint32_t N,
                                                                  uint32_t S, uint32_t rpb, MaskPlan plan,
                                                                  const float *__restrict__ grad_features /*[L][N*S][C]*/,
                                                                  const float *__restrict__ geom,
                                                                  const uint32_t *__restrict__ masks,
-                                                                 uint32_t *__restrict__ counter, uint32_t total) {
+                                                                 uint32_t *__restrict__ counter, uint32_t total,
+                                                                 const float *__restrict__ l1_partial /*FX: [L][ceil(B / 256)]*/) {
     extern __shared__ float s_acc[];                      // 128 KiB row block + 16 rings of 2 KiB: all of the CU's 160 KiB
+    using Acc = typename std::conditional<FX, FxLane, float>::type;
+    Acc *acc_rows = reinterpret_cast<Acc *>(s_acc);       // FX: the same bytes as int32 fixed-point channel pairs (0.0f == 0)
     for (uint32_t i = threadIdx.x; i < rpb * C; i += 1024u) s_acc[i] = 0.0f;          // a flush leaves zeros behind
     uint32_t *q = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C) + (threadIdx.x >> 6) * kQueue;
     volatile uint32_t *s_task = reinterpret_cast<uint32_t *>(s_acc + (size_t)rpb * C);   // = wave 0's ring, idle between tasks
@@ -1622,18 +1683,49 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
         const uint32_t nrows = lv.rows - row_lo < rpb ? lv.rows - row_lo : rpb;
         const uint32_t *mp = masks + (size_t)(plan.plane[lvl] + (plan.coarse[lvl] ? blk >> 5 : blk >> 2)) * B;
         const float *gl = grad_features + (size_t)lvl * B * C;
-#define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom)
+        float gscale = 1.0f, ginv = 1.0f;
+        if constexpr (FX) {
+            // the task's bound: L1 = sum over ITS samples of max_c |g| (256-sample partials of the mask pass; the sample-item
+            // and point-item shapes take the units of kScan x 1024 samples with unit % split == part, the wide shape interleaves
+            // 64-sample words and is given the whole level's sum), then the power of two that puts L1 at <= 2^30
+            const uint32_t nblk = (uint32_t)((B + 255u) / 256u);
+            const float *lp = l1_partial + (size_t)lvl * nblk;
+            const bool every = plan.coarse[lvl] == 3 || split == 1u;
+            float mine = 0.0f;
+            for (uint32_t i = threadIdx.x; i < nblk; i += 1024u)
+                if (every || (i / (kScan * 4u)) % split == part) mine += lp[i];
+            mine = wave_sum_dpp<float>(mine);
+            volatile float *s_red = reinterpret_cast<volatile float *>(s_acc + (size_t)rpb * C) + 16;      // wave 0's ring, idle here
+            if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = mine;
+            __syncthreads();
+            float l1 = 0.0f;
+#pragma unroll
+            for (uint32_t w = 0; w < 16u; w++) l1 += s_red[w];                     // fixed order, every thread the same value
+            __syncthreads();                                                       // before the rings are used again
+            l1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l1)));
+            if (l1 > 0.0f && l1 <= 3.0e38f) {
+                int x;
+                (void)frexpf(l1, &x);                                              // l1 = m 2^x, m in [0.5, 1): l1 <= 2^x
+                int e = 30 - x;
+                e = e > 120 ? 120 : (e < -96 ? -96 : e);
+                gscale = ldexpf(1.0f, e);
+                ginv = ldexpf(1.0f, -e);
+            } else if (!(l1 <= 3.0e38f)) {
+                ginv = __builtin_nanf("");                                         // a non-finite gradient on this level: every row the task touches becomes NaN
+            }
+        }
+#define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale)
 #define UCN_CMPF(H, P2)                                                                                                      \
     do {                                                                                                                     \
-        if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom);      \
-        else if (plan.fine_kind[lvl] == 1) cmp_block<C, H, P2, false, false, 1>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom); \
-        else cmp_block<C, H, P2, false, false, 0>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, mp, gl, geom);           \
+        if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);      \
+        else if (plan.fine_kind[lvl] == 1) cmp_block<C, H, P2, false, false, 1>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale); \
+        else cmp_block<C, H, P2, false, false, 0>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);           \
     } while (0)
         if (plan.coarse[lvl] == 2) {                                          // all workgroup-uniform; the coarsest
             if (lv.mask) UCN_CMP(false, true, true, true);                    // levels are never hashed
             else UCN_CMP(false, false, true, true);
         } else if (plan.coarse[lvl] == 3) {                                   // > 32 row blocks: sample items, unmerged scatter
-#define UCN_CMPW(H, P2) wide_block<C, H, P2>(lv, s_acc, q, blk, row_lo, nrows, part, split, B, masks + (size_t)plan.plane[lvl] * B, gl, geom)
+#define UCN_CMPW(H, P2) wide_block<C, H, P2>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, masks + (size_t)plan.plane[lvl] * B, gl, geom, gscale)
             if (lv.hashed) { if (lv.mask) UCN_CMPW(true, true); else UCN_CMPW(true, false); }
             else { if (lv.mask) UCN_CMPW(false, true); else UCN_CMPW(false, false); }
 #undef UCN_CMPW
@@ -1648,6 +1740,19 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
 #undef UCN_CMPF
         __syncthreads();
         float *gtab = grad_table + ((size_t)lv.first_row + row_lo) * C;
+        if constexpr (FX) {
+            unsigned long long *words = reinterpret_cast<unsigned long long *>(s_acc);
+            for (uint32_t i = threadIdx.x; i < nrows * C / 2u; i += 1024u) {
+                const unsigned long long w = words[i];
+                if (w != 0ull) {
+                    words[i] = 0ull;
+                    float a, b;
+                    fixed_unpack(w, ginv, a, b);
+                    if (split == 1) { gtab[2u * i] += a; gtab[2u * i + 1u] += b; }
+                    else { atomicAdd(gtab + 2u * i, a); atomicAdd(gtab + 2u * i + 1u, b); }
+                }
+            }
+        } else {
         for (uint32_t i = threadIdx.x; i < nrows * C; i += 1024u) {
             const float v = s_acc[i];
             if (v != 0.0f) {
@@ -1655,6 +1760,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
                 if (split == 1) gtab[i] += v;
                 else atomicAdd(gtab + i, v);
             }
+        }
         }
 #ifdef UCN_WG_CLOCK
         __syncthreads();
@@ -2007,18 +2113,23 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     const uint32_t tpb = coresident ? 512u : 256u;
     const size_t lds = coresident ? 88u * 1024u : dummy_lds;
     const dim3 grid(ucn_div_up(B, tpb), grp.n);
-#define UCN_MF(CC)                                                                                                        \
+#define UCN_MF2(CC, FEW)                                                                                                  \
     do {                                                                                                                  \
         if (half_table)                                                                                                   \
-            hipLaunchKernelGGL((k_march_features<CC, 256, _Float16>), grid, dim3(256), lds, st, lv,                       \
+            hipLaunchKernelGGL((k_march_features<CC, 256, _Float16, FEW>), grid, dim3(256), lds, st, lv,                  \
                                reinterpret_cast<const _Float16 *>(f->embeddings), in, hx, std_scale, N, S, grp, layout,   \
                                features_out, coord_out, tmean_out);                                                       \
         else if (coresident)                                                                                              \
-            hipLaunchKernelGGL((k_march_features<CC, 512>), grid, dim3(512), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
+            hipLaunchKernelGGL((k_march_features<CC, 512, float, FEW>), grid, dim3(512), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
                                grp, layout, features_out, coord_out, tmean_out);                                          \
         else                                                                                                              \
-            hipLaunchKernelGGL((k_march_features<CC, 256>), grid, dim3(256), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
+            hipLaunchKernelGGL((k_march_features<CC, 256, float, FEW>), grid, dim3(256), lds, st, lv, f->embeddings, in, hx, std_scale, N, S, \
                                grp, layout, features_out, coord_out, tmean_out);                                          \
+    } while (0)
+#define UCN_MF(CC)                                                                                                        \
+    do {                                                                                                                  \
+        if (lv.L <= 8) UCN_MF2(CC, true);                                                                                 \
+        else UCN_MF2(CC, false);                                                                                          \
     } while (0)
     switch (lv.C) {
         case 1: UCN_MF(1); break;
@@ -2026,6 +2137,7 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
         case 4: UCN_MF(4); break;
         case 8: UCN_MF(8); break;
     }
+#undef UCN_MF2
 #undef UCN_MF
     UCN_LAUNCH_CHECK("march_features");
     return 0;
@@ -2107,6 +2219,7 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     const bool masks = make_mask_plan(lv, rpb, B, &plan);
     // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
     uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B + 64u;             // + the task counter
+    n += (((uint64_t)lv.L * ucn_div_up(B, 256) + 63u) & ~63ull);                                 // + the 256-sample L1 partials of the fixed-point mode
     ListPlan lp;
     if (masks && make_list_plan(lv, plan, rpb, B, &lp))      // + the item lists of the fine levels and their control block
         n += (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
@@ -2122,12 +2235,16 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     UCN_REQUIRE(sdist && near_ && far_ && origins && directions && basis && radii && grad_features && grad_embeddings,
                 "march_features_backward: null pointer argument");
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
+    const bool want_fixed = (layout & UCN_BWD_FIXED_POINT) != 0;
+    layout &= ~UCN_BWD_FIXED_POINT;
     UCN_REQUIRE(layout == 0 || layout == 1 || layout == 3, "march_features_backward: layout must be 0, 1 or 3");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
     const size_t B = (size_t)N * S;
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
+    // fixed-point row blocks pack channel PAIRS and bound a task by < 2^24 addends: C = 1 and huge calls keep float rows
+    const bool fixed = want_fixed && lv.C % 2u == 0u && B <= (1ull << 22);
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     const GradStrides gs = grad_strides(layout, B, lv.L, lv.C);
@@ -2154,8 +2271,9 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             uint32_t *masks = reinterpret_cast<uint32_t *>(workspace + 24ull * B);
             float *glm = workspace + (24ull + plan.n_planes) * B;                               // level-major copy, / 6
             uint32_t *task_counter = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
+            float *l1_partial = reinterpret_cast<float *>(task_counter + 64);                   // [L][ceil(B / 256)] (fixed-point mode)
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
-                               grad_features, gs, lv.C, workspace, masks, glm, task_counter);
+                               grad_features, gs, lv.C, workspace, masks, glm, task_counter, fixed ? l1_partial : nullptr);
             const float *glv = glm;                                                             // [L][B][C]
             const uint32_t cus = device_cu_count();
             ListPlan lp;
@@ -2163,7 +2281,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             uint32_t *ctl = nullptr, *items = nullptr;
             if (lists) {
                 // fine levels: counting sort of (point, (y, z) combination) items into per-block lists, then k_bwd_list
-                ctl = task_counter + 64;
+                ctl = task_counter + 64 + (((size_t)lv.L * ucn_div_up(B, 256) + 63u) & ~(size_t)63u);
                 items = ctl + (((size_t)lp.n_fine * kCtlPerLevel + 63u) & ~(size_t)63u);
                 if (hipMemsetAsync(ctl, 0, (size_t)lp.n_fine * kCtlPerLevel * sizeof(uint32_t), st) != hipSuccess)
                     return ucn_fail("march_features_backward: hipMemsetAsync failed");
@@ -2182,10 +2300,14 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             hipLaunchKernelGGL(k_bwd_bin_scan, dim3(lp.n_fine), dim3(64), 0, st, lp, ctl);                       \
             hipLaunchKernelGGL((k_bwd_bin<CC, true>), bg, dim3(256), 0, st, lv, lp, plan.shift, B, workspace, glv, ctl, items); \
         }                                                                                                        \
-        if (tasks)                                                                                               \
-            hipLaunchKernelGGL(k_march_features_bwd_cmp<CC>, dim3(tasks < cus ? tasks : cus), dim3(1024),        \
+        if (tasks && fixed && CC % 2 == 0)                                                                       \
+            hipLaunchKernelGGL((k_march_features_bwd_cmp<(CC % 2 == 0 ? CC : 2), true>), dim3(tasks < cus ? tasks : cus), dim3(1024), \
                                (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, lv, grad_embeddings, N, S, rpb, plan, glv, \
-                               workspace, masks, task_counter, tasks);                                           \
+                               workspace, masks, task_counter, tasks, l1_partial);                               \
+        else if (tasks)                                                                                          \
+            hipLaunchKernelGGL((k_march_features_bwd_cmp<CC, false>), dim3(tasks < cus ? tasks : cus), dim3(1024), \
+                               (size_t)rpb * CC * 4 + 16 * kQueue * 4, st, lv, grad_embeddings, N, S, rpb, plan, glv, \
+                               workspace, masks, task_counter, tasks, nullptr);                                  \
         if (lists)                                                                                               \
             hipLaunchKernelGGL(k_bwd_list<CC>, dim3(kListTasks, lp.n_fine), dim3(1024), (size_t)rpb * CC * 4, st, lv, lp, \
                                grad_embeddings, rpb, B, glv, workspace, ctl, items);                              \

@@ -120,6 +120,7 @@ class MLP(nn.Module):
     #   0 = fp32-input MFMA (exact fp32 products; 157 TF ceiling)
     #   1 = split-f16 MFMA, fp32 accumulate (hi/lo f16 operands, ~3e-7 relative per product; 5.3x rate)
     mlp_mode: int = 1
+    bwd_fixed_point: bool = True      # autocast training step: table-gradient row blocks in guaranteed-range fixed point (UCN_BWD_FIXED_POINT)
 
     def __init__(self, **kwargs):
         super().__init__()

@@ -52,6 +52,9 @@ class _FieldFeatures(torch.autograd.Function):
         _lib.check(lib.ucn_march_features(ctypes.byref(desc), *[_lib.ptr(t) for t in geom], float(std_scale), N, S,
                                           int(lpb), layout, feat.data_ptr(), coord.data_ptr(), tmean.data_ptr(), _lib.stream()))
         ctx.mlp, ctx.geom, ctx.dims = mlp, geom, (N, S, float(std_scale), int(lpb))
+        # the autocast step (half tables): the table gradient's row blocks accumulate in guaranteed-range fixed point (order-
+        # independent, one LDS add per channel pair); the fp32 step keeps exact fp32 adds (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
+        ctx.fixed = bool(half_table) and bool(getattr(mlp, 'bwd_fixed_point', True))
         ctx.mark_non_differentiable(coord, tmean)
         return feat, coord, tmean
 
@@ -74,7 +77,8 @@ class _FieldFeatures(torch.autograd.Function):
             g, layout = g.contiguous(), 1
         ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.grid_field()), N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.grid_field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
-                                                   N, S, 0, layout, g.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream()))
+                                                   N, S, 0, layout | (_lib.BWD_FIXED_POINT if ctx.fixed else 0), g.data_ptr(), grad.data_ptr(),
+                                                   ws.data_ptr(), _lib.stream()))
         return grad, None, None, None, None, None, None, None
 
 
