@@ -393,7 +393,7 @@ def sky_layer_ms(batch_flat, device, n_rays=65536, steps=3):
                            kernel="k_sky_mlp_bf (bf16 MFMA, two workgroups per CU; under autocast) + k_sky_composite"))
 
 
-def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False):
+def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False, autocast=True):
     """BASELINE configs[2]: one training step on an 8192-ray batch -- Model.forward(rand=True) under bf16
     autocast, the losses of train.py:173-216 with waymo defaults, backward, nan_to_num on grads
     (train_utils.py:335-344), Adam(lr 0.01, betas (0.9, 0.99), eps 1e-8; waymo.gin:6).  Median of `steps`.
@@ -420,7 +420,7 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False)
             batch['sky_segs'] = (torch.rand(n_rays, 1, 1, device=device, generator=g) > 0.7).float()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.autocast('cuda', dtype=torch.bfloat16):           # train.py:165-171: only the model call is autocast
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):     # train.py:165-171: only the model call is autocast
             rend, hist = model(True, batch, 0.5, False, zero_glo=False)
         loss = (tu.compute_data_loss(batch, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg)
                 + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg))
@@ -434,6 +434,13 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False)
         if it >= 2:
             times.append((time.perf_counter() - t0) * 1e3)
     model.eval()
+    if not autocast:
+        return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
+                    precision="fp32 throughout (the reference's shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision): fp32 tables, "
+                              "exact-fp32-add table gradients, every dense layer forward / dgrad / wgrad on csrc/gemm_f32.hip "
+                              "(v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)" +
+                              ("; UCN_F32_LIBRARY=1: the same graph on torch's library GEMMs (A/B)" if os.environ.get("UCN_F32_LIBRARY") == "1" else ""),
+                    heads=bool(heads))
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
                 heads=("sky NeRF (120 samples x 8 x 256 MLP) + per-ray colour-correction affines + sky-segment and identity "
                        "losses (scripts/train_waymo.sh:11-12)" if heads else "none (BASELINE configs[2])"),
@@ -738,6 +745,14 @@ def main():
         if world == 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
+            # the reference's shipped precision: fp32 (no autocast), hand-written fp32 MFMA dense layers; and the same graph on the
+            # library GEMMs for comparison
+            res["train_step_fp32"] = train_step_ms(model, flat, device, steps=6, autocast=False)
+            os.environ["UCN_F32_LIBRARY"] = "1"
+            try:
+                res["train_step_fp32"]["library_gemm_ms"] = train_step_ms(model, flat, device, steps=6, autocast=False)["ms"]
+            finally:
+                os.environ.pop("UCN_F32_LIBRARY", None)
             res["sky_layer"] = sky_layer_ms(flat, device)
             res["ray_generation"] = ray_generation_ms(device)
             res["virtual_warp"] = virtual_warp_ms(device)
@@ -750,6 +765,7 @@ def main():
                 # what the reference's shipped launch trains: sky NeRF + colour-correction head on (train_waymo.sh:11-12)
                 hmodel, _, _ = build_model(device, heads=True)
                 res["train_step_sky"] = train_step_ms(hmodel, flat, device, heads=True)
+                res["train_step_sky_fp32"] = train_step_ms(hmodel, flat, device, steps=4, heads=True, autocast=False)
                 del hmodel
                 torch.cuda.empty_cache()
                 # the same step on the reference's OWN grid (waymo.gin / class defaults: L = 10, C = 4, T = 2^21 -- 256 row blocks

@@ -448,6 +448,25 @@ uint64_t ucn_wgrad_ws_floats(uint32_t KA, uint32_t KB, uint64_t M);
 int ucn_wgrad_bf16(const void *A, uint32_t lda, uint32_t KA, const void *B1, uint32_t ldb1, uint32_t kb1, const void *B2,
                    uint32_t ldb2, uint32_t kb2, uint64_t M, float *workspace, float *out, ucn_stream_t stream);
 
+/* ---- fp32 dense layers of the NON-autocast training step (r04; csrc/gemm_f32.hip): exact fp32 products on v_mfma_f32_32x32x2_f32.
+ * The reference's shipped launch trains in fp32 (scripts/train_waymo.sh:3, train.py:165): every nn.Linear of the NeRF field
+ * (internal/models.py:438-483, 581-674), the sky NeRF (models.py:743-820) and the colour-correction head
+ * (internal/extrinsic_optimizer.py:4-48) is `F.linear` forward and two GEMMs backward.  These replace the library GEMMs of that route.
+ * Row-major fp32 operands with leading dimensions (column slices of wider buffers are passed as views).
+ * ucn_gemm_f32:  Y[M, N] = (Y if UCN_GEMM_ACCUMULATE) + X[M, K] W[N, K]^T + bias[N] (may be NULL), then ReLU if UCN_GEMM_RELU.
+ *   = torch.nn.functional.linear(X, W, bias); the input gradient d X = d Y W is the same call on the transposed weight.
+ *   K, ldx, ldw multiples of 4, X and W 16-byte aligned (16-byte operand loads); any M, N. */
+#define UCN_GEMM_ACCUMULATE 1
+#define UCN_GEMM_RELU 2
+int ucn_gemm_f32(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N, uint32_t K,
+                 int flags, float *Y, uint32_t ldy, ucn_stream_t stream);
+/* ucn_wgrad_f32: GW[N, K] = GY[M, N]^T X[M, K] (the weight gradient of the layer above) and, if gb != NULL, gb[N] = column sums of GY
+ *   (its bias gradient), reduction over the M samples in fixed-order partial sums (deterministic).  `ws`: ucn_wgrad_f32_ws_floats floats.
+ *   N, K, ldg, ldx multiples of 4, GY and X 16-byte aligned. */
+uint64_t ucn_wgrad_f32_ws_floats(uint32_t N, uint32_t K, uint64_t M);
+int ucn_wgrad_f32(const float *GY, uint32_t ldg, const float *X, uint32_t ldx, uint32_t M, uint32_t N, uint32_t K, float *ws, float *GW,
+                  float *gb, ucn_stream_t stream);
+
 /* Iso-surface extraction from a dense lattice of values on the device (ref: skimage.measure.marching_cubes as called by
  * extract.py:379-383, :420-460 and tsdf.py:98-102): volume [X][Y][Z] float32 (z fastest), inside = value < level.
  * Two calls around one host read of the two counts (the outputs have to be allocated):

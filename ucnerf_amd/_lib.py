@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 BWD_FIXED_POINT = 0x800    # ucn_march_features_backward layout flag: int32 fixed-point row blocks (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
@@ -118,6 +118,9 @@ SIGNATURES = {
     "ucn_sky_train_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "ucn_wgrad_ws_floats": [c_u32, c_u32, c_u64],
     "ucn_wgrad_bf16": [c_vp, c_u32, c_u32, c_vp, c_u32, c_u32, c_vp, c_u32, c_u32, c_u64, c_vp, c_vp, c_vp],
+    "ucn_gemm_f32": [c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp],
+    "ucn_wgrad_f32_ws_floats": [c_u32, c_u32, c_u64],
+    "ucn_wgrad_f32": [c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_marching_cubes_ws_bytes": [c_u32, c_u32, c_u32],
     "ucn_marching_cubes_count": [c_vp, c_u32, c_u32, c_u32, c_f32, c_vp, c_vp, c_vp],
     "ucn_marching_cubes_emit": [c_vp, c_u32, c_u32, c_u32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -133,7 +136,7 @@ SIGNATURES = {
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64,
-             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_image_metrics_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
+             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_wgrad_f32_ws_floats": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_image_metrics_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
              "ucn_sky_train_grad_ld": c_u32}
 
 _lib = None

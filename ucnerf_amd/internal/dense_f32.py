@@ -1,0 +1,128 @@
+"""fp32 dense layers of the NON-autocast training step on hand-written kernels (csrc/gemm_f32.hip; r04).
+
+The reference's shipped launch trains in fp32 (scripts/train_waymo.sh:3 has no --mixed_precision, train.py:165's autocast is then
+a no-op): every nn.Linear of the NeRF / proposal fields (internal/models.py:438-483, 507-674), of the sky NeRF (models.py:743-820) and
+of the colour-correction head (internal/extrinsic_optimizer.py:4-48) is an fp32 `F.linear` forward and two fp32 GEMMs backward.
+`hip_linear(x, W, b)` is that triple on `ucn_gemm_f32` / `ucn_wgrad_f32` (exact fp32 products on v_mfma_f32_32x32x2_f32, fp32
+accumulation): forward Y = X W^T + b (ReLU fused on request), d X = d Y W (the same kernel on the transposed weight), d W = d Y^T X and
+d b = column sums of d Y in one pass (fixed-order partial sums: deterministic).
+
+The kernels take 16-byte operand loads: reduction lengths and leading dimensions are multiples of 4 floats.  The few operands of this
+model that are not (3 / 27 / 283-wide inputs, 1 / 3-wide outputs) are zero-padded copies made here -- they are per-ray or weight-sized,
+never an activation-sized concatenation.
+
+UCN_F32_LIBRARY=1 (experiment switch, read per call) routes the same functions through torch's library GEMMs: the A/B measurement of
+bench.py `train_step_fp32`, not a fallback -- on a host tensor these functions raise like every other entry point.
+"""
+import os
+
+import torch
+
+from .. import _lib
+
+ACCUMULATE, RELU = 1, 2
+
+
+def library_route():
+    return os.environ.get("UCN_F32_LIBRARY", "0") == "1"
+
+
+def _rows(t):
+    """[M, K] float32 device view with unit column stride, a row stride that is a multiple of 4 and a 16-byte aligned base; K padded
+    to a multiple of 4 with zero columns if it is not (copy).  Views that already conform (column slices at multiples of 4 of a wider
+    buffer) are passed as they are."""
+    _lib.require_device(t, "dense_f32 operand")
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.reshape(-1, t.shape[-1])
+    k = t.shape[1]
+    ok = (t.stride(1) == 1 or k == 1) and t.stride(0) % 4 == 0 and t.stride(0) >= k and t.data_ptr() % 16 == 0 and k % 4 == 0
+    if ok:
+        return t
+    kp = (k + 3) // 4 * 4
+    if kp == k:
+        return t.contiguous()
+    out = t.new_zeros(t.shape[0], kp)
+    out[:, :k] = t
+    return out
+
+
+def gemm(x, w, bias=None, flags=0, out=None, n_out=None):
+    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (ReLU); x / w as returned by _rows (equal padded K).  `out` may be a column view."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = w.shape[0] if n_out is None else n_out
+    assert w.shape[1] == K, (x.shape, w.shape)
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    assert out.stride(1) == 1 or N == 1
+    _lib.check(lib.ucn_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
+                                out.data_ptr(), out.stride(0), _lib.stream()))
+    return out
+
+
+_WS = {}
+
+
+def wgrad(gy, x, want_bias=False):
+    """(gy^T x as [N, K] float32, column sums of gy [N] or None); gy [M, N], x [M, K] as returned by _rows."""
+    lib = _lib.load()
+    M, N = gy.shape
+    K = x.shape[1]
+    n = lib.ucn_wgrad_f32_ws_floats(N, K, M)
+    st = torch.cuda.current_stream()
+    key = (str(gy.device), st.cuda_stream)
+    hit = _WS.get(key)
+    if hit is None or hit[0] != st or hit[1].numel() < n:
+        if len(_WS) > 8:
+            _WS.clear()
+        hit = _WS[key] = (st, torch.empty(max(n, 1), device=gy.device))
+    gw = torch.empty(N, K, device=gy.device)
+    gb = torch.empty(N, device=gy.device) if want_bias else None
+    _lib.check(lib.ucn_wgrad_f32(gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), M, N, K, hit[1].data_ptr(), gw.data_ptr(),
+                                 _lib.ptr(gb), _lib.stream()))
+    return gw, gb
+
+
+class _HipLinear(torch.autograd.Function):
+    """torch.nn.functional.linear(x, weight, bias) (+ ReLU) in fp32 on the hand-written kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        lead, K, N = x.shape[:-1], x.shape[-1], weight.shape[0]
+        x2, w2 = _rows(x), _rows(weight)
+        y = gemm(x2, w2, None if bias is None else bias.float().contiguous(), RELU if relu else 0)
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.meta = (lead, K, N, bias is not None, relu, x.dtype, weight.dtype)
+        return y.reshape(lead + (N,))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, y = ctx.saved_tensors
+        lead, K, N, has_bias, relu, x_dt, w_dt = ctx.meta
+        gy2 = gy.reshape(-1, N)
+        if relu:
+            gy2 = gy2 * (y > 0)
+        g4 = _rows(gy2)                                                  # [M, N padded to 4]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = _rows(weight.detach().t())                              # [K, N padded]: d X = d Y W as the forward kernel on W^T
+            gx = gemm(g4, wt)[:, :K].reshape(lead + (K,)).to(x_dt)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw_p, gb_p = wgrad(g4, x2, has_bias)
+            gw = gw_p[:N, :K].to(w_dt)
+            gb = None if gb_p is None else gb_p[:N]
+        return gx, gw, gb, None
+
+
+def hip_linear(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) [+ ReLU] for float32 device tensors: csrc/gemm_f32.hip forward and backward."""
+    if library_route():
+        y = torch.nn.functional.linear(x, weight, bias)
+        return torch.relu(y) if relu else y
+    return _HipLinear.apply(x, weight, bias, relu)
+
+
+def usable(*tensors):
+    """the fp32 route's kernels take float32 device tensors outside autocast"""
+    return (not torch.is_autocast_enabled()) and all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from . import dense_f32
 
 EPS = float(torch.finfo(torch.float32).eps)
 
@@ -164,6 +165,8 @@ def tall_linear(lin, x, grad_t=False):
     grad_t: the input gradient comes back as the transpose of a contiguous [K, M] matrix (for _FieldFeatures)."""
     if torch.is_autocast_enabled():
         return _TallLinear.apply(x, lin.weight, lin.bias, grad_t)
+    if dense_f32.usable(x, lin.weight):            # the fp32 step (train_waymo.sh:3): hand-written fp32 MFMA GEMMs (csrc/gemm_f32.hip)
+        return dense_f32.hip_linear(x, lin.weight, lin.bias)
     return F.linear(x, lin.weight, lin.bias)
 
 
@@ -171,7 +174,7 @@ def tall_matmul(x, weight, acc=None):
     """x @ weight.T (+ acc [M, N]) through _TallLinear under autocast."""
     if torch.is_autocast_enabled():
         return _TallLinear.apply(x, weight, acc)
-    y = x @ weight.t()
+    y = dense_f32.hip_linear(x, weight) if dense_f32.usable(x, weight) else x @ weight.t()
     return y if acc is None else y + acc
 
 
@@ -221,25 +224,38 @@ class _ColourMLP(torch.autograd.Function):
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
         code = {torch.float32: 0, torch.bfloat16: 2}[dt]
         NB, NW = x.shape[1], W0.shape[0]
+        hip = code == 0 and x.is_cuda and not dense_f32.library_route()      # fp32: csrc/gemm_f32.hip instead of the library GEMMs
         with torch.autocast("cuda", enabled=False):
             xb, eb = x.to(dt).contiguous(), enc.to(dt)
             W0x, W0e = W0[:, :NB].to(dt), W0[:, NB:].to(dt)
             W1h, W1x, W1e = W1[:, :NW].to(dt), W1[:, NW:NW + NB].to(dt), W1[:, NW + NB:].to(dt)
-            pr0 = torch.addmm(b0.to(dt), eb, W0e.t()).contiguous()                       # [N, NW] per ray
-            h1 = xb @ W0x.t()
-            _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
-            pr1 = torch.addmm(b1.to(dt), eb, W1e.t()).contiguous()
-            h2 = (h1 @ W1h.t()).addmm_(xb, W1x.t())                                      # accumulate in place: no copy
-            _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
+            if hip:
+                R, G = dense_f32._rows, dense_f32.gemm
+                xb, eb = R(xb), R(eb)
+                W0x, W1h, W1x = R(W0x), R(W1h), R(W1x)
+                pr0 = G(eb, R(W0e), b0.contiguous())                                     # [N, NW] per ray
+                h1 = G(xb, W0x)
+                _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
+                pr1 = G(eb, R(W1e), b1.contiguous())
+                h2 = G(h1, W1h)
+                G(xb, W1x, flags=dense_f32.ACCUMULATE, out=h2)                           # accumulate in place: no copy
+                _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
+            else:
+                pr0 = torch.addmm(b0.to(dt), eb, W0e.t()).contiguous()                   # [N, NW] per ray
+                h1 = xb @ W0x.t()
+                _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
+                pr1 = torch.addmm(b1.to(dt), eb, W1e.t()).contiguous()
+                h2 = (h1 @ W1h.t()).addmm_(xb, W1x.t())                                  # accumulate in place: no copy
+                _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
         ctx.save_for_backward(xb, eb, h1, h2, W0x, W1h, W1x)
-        ctx.meta = (N, S, NB, NW, code, x.dtype, W0.dtype, b0.dtype)
+        ctx.meta = (N, S, NB, NW, code, x.dtype, W0.dtype, b0.dtype, hip, enc.shape[1])
         return h2, xb[:, 0].clone()                       # raw density = column 0 of the bottleneck (models.py:508)
 
     @staticmethod
     def backward(ctx, g_h2, g_raw):
         lib = _lib.load()
         xb, eb, h1, h2, W0x, W1h, W1x = ctx.saved_tensors
-        N, S, NB, NW, code, x_dt, w_dt, b_dt = ctx.meta
+        N, S, NB, NW, code, x_dt, w_dt, b_dt, hip, E = ctx.meta
         dt = xb.dtype
         with torch.autocast("cuda", enabled=False):
             g = g_h2.to(dt).contiguous()
@@ -247,6 +263,22 @@ class _ColourMLP(torch.autograd.Function):
             r1 = torch.empty(N, NW, device=g.device, dtype=dt)
             _lib.check(lib.ucn_relu_backward_reduce(g.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, code,
                                                     _lib.stream()))
+            if hip:
+                # the same node on the hand-written fp32 kernels: dgrad = the forward kernel on the transposed weight; every
+                # weight gradient one pass of ucn_wgrad_f32 (fixed-order partial sums); both paths into x accumulate in one output
+                R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
+                d0 = G(d1, R(W1h.t()))                                                    # d h1, masked in place below
+                r0 = torch.empty(N, NW, device=g.device, dtype=dt)
+                _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, code,
+                                                        _lib.stream()))
+                gW0 = torch.cat([WG(d0, xb)[0][:, :NB], WG(r0, eb)[0][:, :E]], dim=1)
+                gW1 = torch.cat([WG(d1, h1)[0], WG(d1, xb)[0][:, :NB], WG(r1, eb)[0][:, :E]], dim=1)
+                gb0, gb1 = r0.sum(0), r1.sum(0)
+                gx = G(d1, R(W1x[:, :NB].t()))
+                G(d0, R(W0x[:, :NB].t()), flags=dense_f32.ACCUMULATE, out=gx)
+                if g_raw is not None:
+                    gx[:, 0] += g_raw.reshape(-1)
+                return gx[:, :NB].to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
             d_h1 = d1 @ W1h
             d0 = d_h1                                                                     # masked in place
             r0 = torch.empty(N, NW, device=g.device, dtype=dt)
@@ -750,14 +782,33 @@ def sky_forward(net, origins, directions, cam_dirs, far):
     views = cam_dirs[:, None, :].expand(-1, 120, -1)
     freqs = 2. ** torch.linspace(0., 3., 4, device=origins.device)
     venc = torch.cat([views] + [fn(views * f) for f in freqs for fn in (torch.sin, torch.cos)], dim=-1)
-    h = pts
-    for i in range(8):
-        h = F.relu(net.pts_linears[i](h))
-        if i == 4:
-            h = torch.cat([pts, h], dim=-1)
-    sigma = net.alpha_linear(h)
-    h = F.relu(net.views_linears[0](torch.cat([net.feature_linear(h), venc], dim=-1)))
-    rgb = torch.sigmoid(net.rgb_linear(h))
+    if dense_f32.usable(pts, net.pts_linears[0].weight) and not dense_f32.library_route():
+        # the fp32 step: every layer on csrc/gemm_f32.hip.  The reference's two concatenations (models.py:790-795: [pts | h] into
+        # layer 5, [feature | view encoding] into the views layer) are products by column blocks of the weight instead -- the
+        # direction block is per RAY ([n, 27] against [n * 120, 283] rows)
+        lin = dense_f32.hip_linear
+        h = pts
+        for i in range(8):
+            L = net.pts_linears[i]
+            if i == 5:
+                h = torch.relu(lin(h, L.weight[:, 3:], L.bias) + lin(pts, L.weight[:, :3]))
+            else:
+                h = lin(h, L.weight, L.bias, relu=True)
+        sigma = lin(h, net.alpha_linear.weight, net.alpha_linear.bias)
+        Lv = net.views_linears[0]
+        feat = lin(h, net.feature_linear.weight, net.feature_linear.bias)
+        per_ray = lin(venc[:, 0, :], Lv.weight[:, feat.shape[-1]:])                       # the same encoding for a ray's 120 samples
+        h = torch.relu(lin(feat, Lv.weight[:, :feat.shape[-1]], Lv.bias) + per_ray[:, None, :])
+        rgb = torch.sigmoid(lin(h, net.rgb_linear.weight, net.rgb_linear.bias))
+    else:
+        h = pts
+        for i in range(8):
+            h = F.relu(net.pts_linears[i](h))
+            if i == 4:
+                h = torch.cat([pts, h], dim=-1)
+        sigma = net.alpha_linear(h)
+        h = F.relu(net.views_linears[0](torch.cat([net.feature_linear(h), venc], dim=-1)))
+        rgb = torch.sigmoid(net.rgb_linear(h))
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], dim=-1)
     dists = dists * torch.norm(directions[:, None, :], dim=-1)
     alpha = 1. - torch.exp(-F.relu(sigma[..., 0]) * dists)
@@ -931,15 +982,20 @@ def brightness_forward(bc, idx, which="latent_code"):
     gradients (autograd's gather backward sums a code's rays), 40x fewer rows through six GEMMs forward + backward."""
     codes = getattr(bc, which)
     idx = idx.reshape(-1).long()
+    mlp = bc.brightness_MLP
+    if dense_f32.usable(codes, mlp.output_linear.weight) and not dense_f32.library_route():      # the fp32 step: csrc/gemm_f32.hip
+        def run(x):
+            for lin in mlp.pts_linears:
+                x = dense_f32.hip_linear(x, lin.weight, lin.bias, relu=True)
+            return dense_f32.hip_linear(x, mlp.output_linear.weight, mlp.output_linear.bias).view(-1, 3, 4)
+    else:
+        def run(x):
+            for lin in mlp.pts_linears:
+                x = F.relu(lin(x))
+            return mlp.output_linear(x).view(-1, 3, 4)
     if codes.shape[0] > 2 * idx.shape[0]:                           # more codes than rays: the per-ray form is the smaller one
-        x = codes[idx]
-        for lin in bc.brightness_MLP.pts_linears:
-            x = F.relu(lin(x))
-        return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)
-    x = codes
-    for lin in bc.brightness_MLP.pts_linears:
-        x = F.relu(lin(x))
-    return bc.brightness_MLP.output_linear(x).view(-1, 3, 4)[idx]
+        return run(codes[idx])
+    return run(codes)[idx]
 
 
 def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
