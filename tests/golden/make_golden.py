@@ -82,6 +82,8 @@ def gen_stepfun(ref):
                              torch.full_like(sd_[..., :-1], -torch.inf))
         out[f'logits_{frac}'] = logits
         out[f'sample_eval_{frac}'] = ref.stepfun.sample_intervals(False, sd_, logits, 128, single_jitter=True, domain=(0., 1.))
+    torch.manual_seed(12)      # the reference draws its training jitter from torch's GLOBAL generator (stepfun.py:216): seeded, so that
+    #                            this fixture re-generates bit for bit (r03's stored an unseeded draw)
     with ref_import.capture_rng() as cap:
         out['sample_train'] = ref.stepfun.sample_intervals(True, sd_, out['logits_0.25'], 32, single_jitter=True, domain=(0., 1.))
     out['sample_train_jitter'] = cap.draws[0][1]
@@ -336,6 +338,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'train':
         gen_train_step(ref, 'train_step.npz', rm.make_spec('tiny'), 71)
         gen_train_step(ref, 'train_step_sky.npz', rm.make_spec('tiny', model_sky=True, brightness_correction=True), 81, sky_alpha_bias=0.5)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'stepfun':
+        gen_stepfun(ref)
         sys.exit(0)
     gen_stepfun(ref)
     gen_cast(ref)

@@ -1,4 +1,4 @@
-"""Training soak: 400 optimiser steps of bench.py's step on (heads, config-B grid), (heads, waymo.gin grid), (no heads, waymo.gin grid) against a fixed random target image; the loss must fall and every parameter stay finite.  GPU box:  python tools/train_soak.py"""
+"""Training soak (the long form of tests/test_soak.py; its log: profiles/r04/train_soak.txt): 400 optimiser steps of bench.py's step on (heads, config-B grid), (heads, waymo.gin grid), (no heads, waymo.gin grid) against a fixed random target image; the loss must fall and every parameter stay finite.  GPU box:  python tools/train_soak.py"""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
