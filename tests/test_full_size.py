@@ -141,6 +141,44 @@ def test_featurisation_is_linear_with_closed_form_on_ones_and_exact_adjoint(scen
         assert abs(a - b) <= 1e-5 * s, (l, a, b, s)
 
 
+def test_lane_paired_fetch_is_bit_identical_to_the_per_lane_fetch(scene):
+    """k_march_features fetches the x0 / x0 + 1 corners of the levels finer than 2048 through lane PAIRS (level_accumulate_lanepairs:
+    lane i and lane i + 32 of one load instruction serve one point, v_permlane32_swap sorts rows and values) -- only in waves whose 64
+    lanes are all active; the one partial wave of a launch keeps the per-lane fetch.  Same values, same fmaf order: a sample must get
+    bit-identical features on either route.  129 rays x 65 samples = 131 x 64 + 1: the LAST sample of the launch is alone in its wave
+    (per-lane route); with the rays in reverse order the same sample is lane 0 of a full wave (lane-paired route).  fp32 and half tables."""
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    model, flat, n_total = scene
+    n, S = 129, 65
+    batch = _pick(flat, n_total, n, seed=21)
+    mlp = model.nerf_mlp
+    enc = mlp.encoder
+    L, C = enc.num_levels, enc.level_dim
+    g = torch.Generator(device="cuda").manual_seed(22)
+    sdist = torch.sort(torch.rand(n, S + 1, device="cuda", generator=g), dim=-1).values.contiguous()
+    basis = torch.empty(n, 6, device="cuda")
+    _lib.check(lib.ucn_cone_basis(batch["cam_dirs"].data_ptr(), batch["rand_vec"][:, 3:6].contiguous().data_ptr(), n, basis.data_ptr(), _lib.stream()))
+    near, far, rad = (batch[k].reshape(-1).contiguous() for k in ("near", "far", "radii"))
+    emb16 = enc.embeddings.detach().to(torch.half)
+
+    def run(order, half):
+        geom = [t[order].contiguous() for t in (sdist, near, far, batch["origins"], batch["directions"], basis, rad)]
+        d = _lib.UcnField.from_buffer_copy(mlp.field())
+        if half:
+            d.embeddings = emb16.data_ptr()
+        out = torch.empty(L, S * n, C, device="cuda")                          # layout 2: b = s * n + ray
+        _lib.check(lib.ucn_march_features(ctypes.byref(d), *[t.data_ptr() for t in geom], None, None, float(model.std_scale), n, S, 0,
+                                          2 | (_lib.TABLE_F16 if half else 0), out.data_ptr(), None, None, _lib.stream()))
+        return out.reshape(L, S, n, C)
+    fwd = torch.arange(n, device="cuda")
+    rev = torch.flip(fwd, dims=[0])
+    for half in (False, True):
+        a, b = run(fwd, half), run(rev, half)
+        assert torch.equal(a, torch.flip(b, dims=[2])), half                  # every sample, whichever wave and lane it landed in
+        assert float(a[:, S - 1, n - 1].abs().max()) > 0                     # (the lone sample of the partial wave is a live one)
+
+
 def test_fixed_point_row_blocks_against_the_float_row_blocks(scene):
     """UCN_BWD_FIXED_POINT (the autocast training step's table gradient; r04): int32 fixed-point row blocks, one 64-bit LDS add
     per channel pair.  On the training batch of config B (8192 rays x 128 samples, all 16 levels) against the exact-fp32-add

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libucnerf_march.so")
+# UCN_LIB_PATH: an experiment build of the same ABI (tools/build_variant.sh) for A/B measurements; default = the in-tree product
+LIB_PATH = os.environ.get("UCN_LIB_PATH") or os.path.join(_HERE, "csrc", "libucnerf_march.so")
 ABI_VERSION = 20
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200

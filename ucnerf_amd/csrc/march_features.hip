@@ -289,6 +289,64 @@ __device__ __forceinline__ void level_accumulate_pairs(const UcnLevel &lv, const
     }
 }
 
+// LANE-PAIRED fetch (r04), C = 2, power-of-two tables.  The corners (x0, y, z) and (x0 + 1, y, z) of a point hash to rows r and
+// r ^ d (hashed levels; r, r + 1 on the strided ones): in 7 cases of 8 (x0 & 7 != 7) the same aligned group of eight 8-byte rows,
+// i.e. the SAME 64-byte line -- but up to 56 bytes apart, so no single load of one lane covers both, and as two load
+// instructions they are two line requests (the bound of the fine levels: L1 lines per clock).  The texture-address path DOES
+// merge lanes of ONE instruction that hit the same line, wherever they sit in the wave (tools/ta_merge_bench.hip: two 8-byte
+// loads per point 349 G rows/s; the same rows as ONE instruction over lane pairs 532 G rows/s -- the rate of an aligned 16-byte
+// load).  So a wave fetches a (y, z) combination in two instructions that each serve 32 POINTS: lane i < 32 asks for the x0 row of
+// point i while lane i + 32 asks for the x0 + 1 row of the same point (second instruction: the points of lanes 32 ... 63).  One
+// v_permlane32_swap of (row_x0, row_x1) forms both address registers, one per channel sorts the values back:
+//   swap(a, b) -> {a.lo, b.lo}, {a.hi, b.hi}.  4.5 line requests per point instead of 6 (pair fetch) or 8, no divergent branch.
+// Points outside the unit cube fetch (masked, hence valid) dummy rows and are skipped at the accumulation: same values, same
+// fmaf order as level_accumulate.  Needs every lane of the wave active (the caller checks).
+template <bool HASHED, typename TT>
+__device__ __forceinline__ void level_accumulate_lanepairs(const UcnLevel &lv, const TT *__restrict__ tab,
+                                                           const float (&u)[6][3], const float (&rs)[6], float (&acc)[2]) {
+    acc[0] = acc[1] = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        const bool valid = in_unit_cube(u[j][0], u[j][1], u[j][2]);
+        float fx, fy, fz, w[8];
+        uint32_t rows[8];
+        corner_rows<HASHED, true>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
+        float v[8][2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {                              // (y, z) choice; corners 2q (x0) and 2q + 1 (x0 + 1)
+            const auto ad = __builtin_amdgcn_permlane32_swap(rows[2 * q], rows[2 * q + 1], false, false);
+            if constexpr (sizeof(TT) == 4) {
+                const float2 ta = *reinterpret_cast<const float2 *>(tab + (size_t)ad[0] * 2);
+                const float2 tb = *reinterpret_cast<const float2 *>(tab + (size_t)ad[1] * 2);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ta.x), __builtin_bit_cast(uint32_t, tb.x), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ta.y), __builtin_bit_cast(uint32_t, tb.y), false, false);
+                v[2 * q][0] = __builtin_bit_cast(float, (uint32_t)s0[0]); v[2 * q + 1][0] = __builtin_bit_cast(float, (uint32_t)s0[1]);
+                v[2 * q][1] = __builtin_bit_cast(float, (uint32_t)s1[0]); v[2 * q + 1][1] = __builtin_bit_cast(float, (uint32_t)s1[1]);
+            } else {
+                typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+                const uint32_t ta = *reinterpret_cast<const uint32_t *>(tab + (size_t)ad[0] * 2);     // a row = two halves = one word
+                const uint32_t tb = *reinterpret_cast<const uint32_t *>(tab + (size_t)ad[1] * 2);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(ta, tb, false, false);
+                const hx2 h0 = __builtin_bit_cast(hx2, (uint32_t)s0[0]), h1 = __builtin_bit_cast(hx2, (uint32_t)s0[1]);
+                v[2 * q][0] = (float)h0[0]; v[2 * q][1] = (float)h0[1];
+                v[2 * q + 1][0] = (float)h1[0]; v[2 * q + 1][1] = (float)h1[1];
+            }
+        }
+        corner_weights(fx, fy, fz, w);
+        float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            f0 = fmaf(w[k], v[k][0], f0);
+            f1 = fmaf(w[k], v[k][1], f1);
+        }
+        const float damp = erf_pos(rs[j] * lv.inv_gs);
+        if (valid) {
+            acc[0] += f0 * damp;
+            acc[1] += f1 * damp;
+        }
+    }
+}
+
 // Backward of level_accumulate w.r.t. the table: grad_table[row_k] += w_k * damp_j * g
 // (gridencoder.cu:304-339 composed with models.py:495-496).  When all multisamples of the sample share
 // one lattice cell (coarse levels) their corner weights are summed first: 8*C atomics instead of 48*C
@@ -512,13 +570,17 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, A *__res
 #ifndef UCN_SHARED_CELL_MAX_RES
 #define UCN_SHARED_CELL_MAX_RES 64
 #endif
+#ifndef UCN_LANEPAIR_MIN_RES
+#define UCN_LANEPAIR_MIN_RES 2048u                                  // levels finer than this take the lane-paired fetch (experiment knob)
+#endif
 constexpr uint32_t kSharedCellMaxRes = UCN_SHARED_CELL_MAX_RES;     // dense levels up to this resolution use level_accumulate_shared
 
 // layout: 0 = [L][B][C] (b as given), 1 = [B][L*C]
 template <uint32_t C, typename TT>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__restrict__ table, uint32_t lvl0,
                                           uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
-                                          size_t B, size_t b, float *__restrict__ out, bool sample_major, bool out_bf16 = false) {
+                                          size_t B, size_t b, float *__restrict__ out, bool sample_major, bool out_bf16 = false,
+                                          bool full_wave = false) {
     const uint32_t F_out = lvls.L * C;
     for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
@@ -530,6 +592,10 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__res
             else level_accumulate_shared<C, true, false>(lv, tab, u, rs, acc);
         } else if (lv.hashed) {
             if constexpr (C == 2) {
+#ifndef UCN_NO_LANEPAIRS
+                if (lv.mask && G == 6 && full_wave && lv.resolution > UCN_LANEPAIR_MIN_RES) level_accumulate_lanepairs<true, TT>(lv, tab, u, rs, acc);
+                else
+#endif
                 if (lv.mask && lv.resolution > 2048u && G == 6) level_accumulate_pairs(lv, tab, u, rs, acc);
                 else if (lv.mask) level_accumulate<C, true, true>(lv, tab, u, rs, G, acc);
                 else level_accumulate<C, true, false>(lv, tab, u, rs, G, acc);
@@ -541,8 +607,20 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__res
             if (lv.mask) level_accumulate_shared<C, false, true>(lv, tab, u, rs, acc);
             else level_accumulate_shared<C, false, false>(lv, tab, u, rs, acc);
         } else {
-            if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
-            else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);
+#ifndef UCN_NO_LANEPAIRS
+            if constexpr (C == 2) {
+                if (lv.mask && G == 6 && full_wave && lv.stride[0] == 1u && lv.resolution > UCN_LANEPAIR_MIN_RES) {
+                    level_accumulate_lanepairs<false, TT>(lv, tab, u, rs, acc);
+                } else {
+                    if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
+                    else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);
+                }
+            } else
+#endif
+            {
+                if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
+                else level_accumulate<C, false, false>(lv, tab, u, rs, G, acc);
+            }
         }
         float *o = sample_major ? out + b * F_out + (size_t)lvl * C : out + ((size_t)lvl * B + b) * C;
         const float inv = (float)G;
@@ -759,8 +837,9 @@ __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const TT
     float u[6][3], rs[6], csum[3], tsum;
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = grp.lo[blockIdx.y], lvl1 = grp.lo[blockIdx.y + 1];
-    if constexpr (sizeof(TT) == 2) featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, (layout & 0x10) != 0);
-    else featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1);
+    const bool full_wave = __ballot(true) == ~0ull;                  // the lane-paired fetch trades rows between lanes i and i + 32
+    if constexpr (sizeof(TT) == 2) featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, (layout & 0x10) != 0, full_wave);
+    else featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1, false, full_wave);
     if (blockIdx.y == 0) {
         const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
         if (coord_out) {

@@ -596,23 +596,55 @@ extern "C" int ucn_composite(const float *density, const float *rgbs, const floa
 }
 
 namespace {
-// alive list of a pass: thread = feature index b; lanes of a wave are neighbouring rays at one sample (rays_fastest)
-// or consecutive samples of a ray.  Ballot + popcount give the rank inside the wave, one atomic per wave the base.
+// alive list of a pass.  The features of a pass are indexed b = s * N + ray (rays_fastest: the lanes of an MLP wave are neighbouring
+// rays at one sample) or b = ray * S + s; the compositing weights lie [N][S].  A workgroup takes a TILE of 64 rays x 64 samples:
+// the weights are read in memory order (a wave = one ray's 64 samples: coalesced) and balloted into one 64-bit mask per ray in
+// LDS; the list is then written in b order inside the tile (a wave = 64 rays at one sample: ballot + popcount give the rank) so that
+// consecutive list items are consecutive feature rows for the colour kernel's gathers; ONE atomic per tile reserves its span
+// (r03: one returning atomic per WAVE on a single counter -- 20 480 same-address atomics per pass, 236 us; r04: 320, ~10 us).
+// The order of the tiles in the list is unspecified.
 __global__ __launch_bounds__(256) void k_compact_alive(const float *__restrict__ weights, uint32_t N, uint32_t S, int rays_fastest,
                                                        float min_weight, uint32_t *__restrict__ idx, uint32_t *__restrict__ count) {
-    const uint32_t B = N * S;
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    bool alive = false;
-    if (b < B) {
-        const uint32_t ray = rays_fastest ? b % N : b / S, s = rays_fastest ? b / N : b % S;
-        alive = weights[(size_t)ray * S + s] >= min_weight;          // NaN weights are not alive
+    __shared__ unsigned long long s_mask[64];
+    __shared__ uint32_t s_cnt[4], s_base;
+    const uint32_t s_tiles = (S + 63u) / 64u;
+    const uint32_t ray0 = (blockIdx.x / s_tiles) * 64u, s0 = (blockIdx.x % s_tiles) * 64u;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t r = wave; r < 64u; r += 4u) {                        // wave-uniform r: this wave's rays of the tile
+        const uint32_t ray = ray0 + r, sm = s0 + lane;
+        bool alive = false;
+        if (ray < N && sm < S) alive = weights[(size_t)ray * S + sm] >= min_weight;       // NaN weights are not alive
+        const unsigned long long m = __ballot(alive);
+        if (lane == 0) s_mask[r] = m;
     }
-    const unsigned long long m = __ballot(alive);
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (alive) idx[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+    __syncthreads();
+    // b order inside the tile: rays_fastest -> sample-major (a wave step = the 64 rays at one sample, i.e. bit `s` of the 64 ray masks);
+    // ray-major -> the masks as they are (a wave step = one ray).  16 steps per wave; pass 1 counts, pass 2 writes.
+    const unsigned long long mine = s_mask[lane];                        // rays_fastest: lane = ray; else only used via s_mask[step]
+    uint32_t total = 0;
+    for (uint32_t step = wave; step < 64u; step += 4u) {
+        const unsigned long long m = rays_fastest ? __ballot((mine >> step) & 1ull) : s_mask[step];
+        total += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) s_cnt[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = t ? atomicAdd(count, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = s_base;
+    for (uint32_t w = 0; w < wave; w++) pos += s_cnt[w];
+    for (uint32_t step = wave; step < 64u; step += 4u) {
+        const unsigned long long m = rays_fastest ? __ballot((mine >> step) & 1ull) : s_mask[step];
+        if ((m >> lane) & 1ull) {
+            // rays_fastest: lane = ray, step = sample;  ray-major: step = ray, lane = sample
+            const uint32_t ray = ray0 + (rays_fastest ? lane : step), sm = s0 + (rays_fastest ? step : lane);
+            const uint32_t b = rays_fastest ? sm * N + ray : ray * S + sm;
+            idx[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+        }
+        pos += (uint32_t)__popcll(m);
+    }
 }
 __global__ void k_zero_u32(uint32_t *p) { *p = 0u; }
 }  // namespace
@@ -624,7 +656,7 @@ extern "C" int ucn_compact_alive(const float *weights, uint32_t N, uint32_t S, i
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(1), 0, st, count);
     if (N)
-        hipLaunchKernelGGL(k_compact_alive, dim3(ucn_div_up((uint64_t)N * S, 256)), dim3(256), 0, st, weights, N, S, rays_fastest,
+        hipLaunchKernelGGL(k_compact_alive, dim3(ucn_div_up(N, 64) * ucn_div_up(S, 64)), dim3(256), 0, st, weights, N, S, rays_fastest,
                            min_weight, idx_out, count);
     UCN_LAUNCH_CHECK("compact_alive");
     return 0;
