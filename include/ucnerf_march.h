@@ -145,6 +145,10 @@ int ucn_tsdf_integrate(const float *voxel_world, uint32_t N, const float *w2c /*
  * the autocast training step's mode (the reference accumulates that step's table gradient in fp16, gridencoder.cu:319-334); the fp32
  * step and every parity test of it keep exact fp32 adds.  Ignored for level_dim 1 and for calls of more than 2^22 samples. */
 #define UCN_BWD_FIXED_POINT 0x800
+/* OR-ed into ucn_march_features' layout: the rays of the call are NOT neighbouring pixels (a training batch of random rays) -- the lanes of
+ * a wave share no cache lines on any hashed level, so every hashed level takes the lane-paired corner fetch (rendering: only the levels
+ * finer than 2048, where neighbouring pixels stop sharing lines).  A scheduling hint: the features are bit-identical either way. */
+#define UCN_RAYS_INCOHERENT 0x1000
 /* OR-ed into ucn_train_fwd's feat_level_dim: `feat` holds the bf16 pairs UCN_FEATURES_BF16 produced. */
 #define UCN_FEAT_BF16 0x100
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("UCN_LIB_PATH") or os.path.join(_HERE, "csrc", "libucn
 ABI_VERSION = 20
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
+RAYS_INCOHERENT = 0x1000   # ucn_march_features layout flag: random (training) rays -> lane-paired fetch on every hashed level
 BWD_FIXED_POINT = 0x800    # ucn_march_features_backward layout flag: int32 fixed-point row blocks (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
 FEAT_BF16 = 0x100          # ucn_train_fwd feat_level_dim flag: the features are those pairs          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT

@@ -571,7 +571,11 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, A *__res
 #define UCN_SHARED_CELL_MAX_RES 64
 #endif
 #ifndef UCN_LANEPAIR_MIN_RES
-#define UCN_LANEPAIR_MIN_RES 2048u                                  // levels finer than this take the lane-paired fetch (experiment knob)
+#define UCN_LANEPAIR_MIN_RES 2048u                                  // levels finer than this take the lane-paired fetch when a wave's rays are
+//                                                                     neighbouring pixels (rendering: on the middle levels the lanes share lines anyway
+//                                                                     and the three swaps per corner pair cost more than they save -- per-level times in
+//                                                                     profiles/r04/level_times_*.txt); UCN_RAYS_INCOHERENT (random training rays, no
+//                                                                     sharing on any hashed level) lowers it to kSharedCellMaxRes
 #endif
 constexpr uint32_t kSharedCellMaxRes = UCN_SHARED_CELL_MAX_RES;     // dense levels up to this resolution use level_accumulate_shared
 
@@ -580,7 +584,7 @@ template <uint32_t C, typename TT>
 __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__restrict__ table, uint32_t lvl0,
                                           uint32_t lvl1, const float (&u)[6][3], const float (&rs)[6], uint32_t G,
                                           size_t B, size_t b, float *__restrict__ out, bool sample_major, bool out_bf16 = false,
-                                          bool full_wave = false) {
+                                          bool full_wave = false, uint32_t lp_min_res = UCN_LANEPAIR_MIN_RES) {
     const uint32_t F_out = lvls.L * C;
     for (uint32_t lvl = lvl0; lvl < lvl1; lvl++) {
         const UcnLevel lv = lvls.lv[lvl];
@@ -593,7 +597,7 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__res
         } else if (lv.hashed) {
             if constexpr (C == 2) {
 #ifndef UCN_NO_LANEPAIRS
-                if (lv.mask && G == 6 && full_wave && lv.resolution > UCN_LANEPAIR_MIN_RES) level_accumulate_lanepairs<true, TT>(lv, tab, u, rs, acc);
+                if (lv.mask && G == 6 && full_wave && lv.resolution > lp_min_res) level_accumulate_lanepairs<true, TT>(lv, tab, u, rs, acc);
                 else
 #endif
                 if (lv.mask && lv.resolution > 2048u && G == 6) level_accumulate_pairs(lv, tab, u, rs, acc);
@@ -609,7 +613,7 @@ __device__ __forceinline__ void featurise(const UcnLevels &lvls, const TT *__res
         } else {
 #ifndef UCN_NO_LANEPAIRS
             if constexpr (C == 2) {
-                if (lv.mask && G == 6 && full_wave && lv.stride[0] == 1u && lv.resolution > UCN_LANEPAIR_MIN_RES) {
+                if (lv.mask && G == 6 && full_wave && lv.stride[0] == 1u && lv.resolution > lp_min_res) {
                     level_accumulate_lanepairs<false, TT>(lv, tab, u, rs, acc);
                 } else {
                     if (lv.mask) level_accumulate<C, false, true>(lv, tab, u, rs, G, acc);
@@ -838,8 +842,9 @@ __global__ __launch_bounds__(TPB) void k_march_features(UcnLevels lvls, const TT
     cast_sample(in, hx, std_scale, ray, s, S, u, rs, csum, tsum);
     const uint32_t lvl0 = grp.lo[blockIdx.y], lvl1 = grp.lo[blockIdx.y + 1];
     const bool full_wave = __ballot(true) == ~0ull;                  // the lane-paired fetch trades rows between lanes i and i + 32
-    if constexpr (sizeof(TT) == 2) featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, (layout & 0x10) != 0, full_wave);
-    else featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, layout == 1, false, full_wave);
+    const uint32_t lp_min = (layout & 0x20) ? kSharedCellMaxRes : UCN_LANEPAIR_MIN_RES;     // 0x20: UCN_RAYS_INCOHERENT (private bit)
+    if constexpr (sizeof(TT) == 2) featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, (layout & 0x10) != 0, full_wave, lp_min);
+    else featurise<C, TT>(lvls, table, lvl0, lvl1, u, rs, 6, B, b, features, (layout & 3) == 1, false, full_wave, lp_min);
     if (blockIdx.y == 0) {
         const size_t o = (size_t)ray * S + s;                     // per-sample side outputs stay [N,S]
         if (coord_out) {
@@ -2169,12 +2174,14 @@ extern "C" int ucn_march_features(const ucn_field_t *f, const float *sdist, cons
     const bool coresident = (layout & UCN_LAUNCH_CORESIDENT) != 0;
     const bool half_table = (layout & UCN_TABLE_F16) != 0;
     const bool out_bf16 = (layout & UCN_FEATURES_BF16) != 0;
-    layout &= ~(UCN_LAUNCH_CORESIDENT | UCN_TABLE_F16 | UCN_FEATURES_BF16);
+    const bool incoherent = (layout & UCN_RAYS_INCOHERENT) != 0;
+    layout &= ~(UCN_LAUNCH_CORESIDENT | UCN_TABLE_F16 | UCN_FEATURES_BF16 | UCN_RAYS_INCOHERENT);
     UCN_REQUIRE(!(half_table && coresident), "march_features: the co-resident launch shape reads fp32 tables");
     UCN_REQUIRE(layout >= 0 && layout <= 2, "march_features: layout must be 0, 1 or 2");
     UCN_REQUIRE(!out_bf16 || (half_table && f->level_dim == 2 && layout != 1),
                 "march_features: bf16 features come with half tables, level_dim 2 and a level-major layout");
-    if (out_bf16) layout |= 0x10;                      // the kernel's private flag
+    if (out_bf16) layout |= 0x10;                      // the kernel's private flags
+    if (incoherent) layout |= 0x20;
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;

@@ -37,7 +37,7 @@ class _FieldFeatures(torch.autograd.Function):
         lib = _lib.load()
         desc = mlp.grid_field()
         L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
-        layout = 1
+        layout = 1 | _lib.RAYS_INCOHERENT               # a training batch is random rays (datasets.py:278): see include/ucnerf_march.h
         if half_table:
             # gridencoder/grid.py:41-44: under autocast (and C even) the reference gathers `embeddings.to(torch.half)`.
             # Same here -- half the bytes per corner, a 2 MiB level slice per XCD L2 -- with fp32 interpolation arithmetic
@@ -46,7 +46,7 @@ class _FieldFeatures(torch.autograd.Function):
             d16 = _lib.UcnField()
             ctypes.memmove(ctypes.byref(d16), ctypes.byref(desc), ctypes.sizeof(_lib.UcnField))
             d16.embeddings = emb16.data_ptr()
-            desc, layout = d16, 1 | _lib.TABLE_F16
+            desc, layout = d16, layout | _lib.TABLE_F16
         feat = torch.empty(N * S, L * C, device=embeddings.device)
         coord = torch.empty(N, S, 3, device=embeddings.device)
         tmean = torch.empty(N, S, device=embeddings.device)
