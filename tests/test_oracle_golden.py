@@ -173,3 +173,30 @@ def test_warp_oracle_vs_reference():
         ref, src = fx["ref_pose"] @ flip, fx[name + ".src_pose"] @ flip
         uv, mask = warp.img_warping(ref, src, fx["depth"], fx["intrinsic"])
         check_warp(fx, name, uv, mask, warp.img_warping_for_depth(ref, src, fx["depth"], fx["intrinsic"]))
+
+
+def test_live_sky_layer_overflows_by_the_references_own_formula():
+    """The NaN of profiles/r02c/bench_cfg5_fit.json explained on the CPU, with the oracle that reproduces the
+    reference's sky layer bit for bit (model_sky.npz): the sky samples run from z = batch.far DOWN to 1 / far (models.py:872, SURVEY.md
+    Appendix C.2), so every spacing but the last is NEGATIVE, alpha = 1 - exp(+relu(sigma) |dz|) <= 0 and the transmittance
+    prod(1 - alpha) GROWS like exp(sum sigma |dz|).  A sky density head that training has pushed to sigma ~ 12 over the ray
+    (|dz| 0.066 x 119 samples x 12 = 95 > log(float32 max) = 88.7) makes rgb_map inf / NaN -- what the reference reports itself as
+    `[Numerical Error] rgb_map contains nan or inf` (models.py:899-901).  Not an artefact of this implementation: a dead head
+    (sigma <= 0, the default initialisation on these rays) renders exactly 0, a mildly live one stays finite."""
+    spec = rm.make_spec("tiny", model_sky=True, brightness_correction=True)
+    sd = rm.init_state(spec, seed=3)
+    rays = rm.synthetic_rays(64, seed=4)
+    w, b = sd["skynerf.alpha_linear.weight"], sd["skynerf.alpha_linear.bias"]
+    out = {}
+    for name, bias in (("dead", -5.0), ("mild", 0.5), ("live", 2.0), ("pushed", 12.0)):
+        sd2 = dict(sd)
+        sd2["skynerf.alpha_linear.weight"] = torch.zeros_like(w)           # sigma = bias everywhere
+        sd2["skynerf.alpha_linear.bias"] = torch.full_like(b, bias)
+        with torch.no_grad():
+            out[name] = rm.sky_layer(sd2, rays["origins"], rays["directions"], rays["cam_dirs"], rays["far"])
+    assert float(out["dead"].abs().max()) == 0.0
+    assert bool(torch.isfinite(out["mild"]).all()) and float(out["mild"].abs().max()) > 0
+    assert not bool(torch.isfinite(out["pushed"]).all())
+    # well before the overflow the layer's "colour" has left [0, 1]: at sigma = 2 it is already in the thousands, of either sign
+    # (119 negative weights alpha_i T_i against the one positive weight of the last sample, whose spacing is +1e10)
+    assert bool(torch.isfinite(out["live"]).all()) and float(out["live"].abs().max()) > 100.0

@@ -7,6 +7,7 @@
 //   1: lane pair (2 i, 2 i + 1) = point i: ONE instruction fetches r (even lane) and r ^ d (odd lane); 2 instructions per 64 points
 //   2: like 1 but the partner lanes are 32 apart (lane i and lane i + 32)
 //   3: lane = point; one 16-byte load of the aligned pair (d = 1 only: the kernel's even-x0 case), for scale
+//   4-7: variant 1 with cache-policy bits on the load (nt / sc0 / sc1 / all three); 8: variant 1 through the same inline asm (waitcnt per load: the control)
 // hipcc --offload-arch=gfx950 -O3 tools/ta_merge_bench.hip -o tools/_exp/ta_merge_bench && tools/_exp/ta_merge_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -37,9 +38,24 @@ __global__ __launch_bounds__(256) void k(const float2 *__restrict__ tab, float *
                 const float2 p = tab[second ? rr ^ dd : rr];
                 a += p.x; b += p.y;
             }
-        } else {
+        } else if (V == 3) {
             const float4 p = reinterpret_cast<const float4 *>(tab)[r >> 1];
             a += p.x + p.z; b += p.y + p.w;
+        } else {
+            // variant 1's lane pairs with a cache-policy modifier on the load: 4 = nt, 5 = sc0, 6 = sc1, 7 = sc0 sc1 nt
+#pragma unroll
+            for (uint32_t round = 0; round < 2; round++) {
+                const uint32_t src = (lane >> 1) + 32u * round, second = lane & 1u;
+                const uint32_t rr = __shfl(r, src, 64), dd = __shfl(d, src, 64);
+                const float2 *ptr = tab + (second ? rr ^ dd : rr);
+                float2 p;
+                if (V == 4) asm volatile("global_load_dwordx2 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(ptr) : "memory");
+                if (V == 5) asm volatile("global_load_dwordx2 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(ptr) : "memory");
+                if (V == 6) asm volatile("global_load_dwordx2 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(ptr) : "memory");
+                if (V == 7) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(ptr) : "memory");
+                if (V == 8) asm volatile("global_load_dwordx2 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(ptr) : "memory");
+                a += p.x; b += p.y;
+            }
         }
     }
     out[gid] = a + b;
@@ -53,7 +69,7 @@ int main() {
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (uint32_t dmask = 1; dmask <= 7; dmask += 6) {
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < 9; v++) {
             float best = 1e9f;
             for (int rep = 0; rep < 4; rep++) {
                 hipEventRecord(e0);
@@ -61,6 +77,11 @@ int main() {
                 if (v == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
                 if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
                 if (v == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
+                if (v == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
+                if (v == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
+                if (v == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
+                if (v == 7) hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
+                if (v == 8) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, tab, out, iters, dmask);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep && ms < best) best = ms;

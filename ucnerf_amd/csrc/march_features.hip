@@ -223,7 +223,13 @@ __device__ __forceinline__ void level_accumulate_shared(const UcnLevel &lv, cons
         uint32_t row;
         if constexpr (POW2) row = idx & lv.mask;
         else row = idx < lv.rows ? idx : idx % lv.rows;
+#ifdef UCN_EXP_NO_COARSE_LOADS            // experiment build (r04): the coarse levels WITHOUT their table reads -- the ceiling of any LDS staging
+        (void)row;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) v[k][c] = __builtin_bit_cast(float, 0x3f000000u + k * 977u + c);
+#else
         load_row<C, TT>(tab, row, v[k]);
+#endif
     }
 #pragma unroll
     for (uint32_t j = 0; j < 6; j++) {
@@ -947,6 +953,9 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         // corners lie in ~4.5 of the 256 blocks: the `any corner in my block` test drops most points before weights and erf).
         // Before r03 these configurations fell back to the global-atomic kernel: 83.6 of the 88.5 ms of a waymo.gin training step.
         if (nb_l > 32u && mp->coarse[l] != 2) mp->coarse[l] = 3;         // (the run-merging dense levels keep their shape, with nb / 32 mask words)
+        // experiment knob (r04): the hashed sample-item levels (resolution 128 ... 512) through the pair-item shape as well
+        static const bool wide_mid = getenv("UCN_BWD_WIDE_MID") && atoi(getenv("UCN_BWD_WIDE_MID")) != 0;
+        if (wide_mid && mp->coarse[l] == 1 && lv.lv[l].hashed && nb_l == 32u) mp->coarse[l] = 3;
         // Point-item levels, three shapes (workgroup clocks per level, tools/bwd_balance.py, ms-CU per level of the benchmark grid):
         //   0: items appended point by point (six ballots per step), all 8 corners walked          res 1024: 75, 2048: 62, finer: 60-62, strided: 78
         //   1: items appended lane by lane (popcount + one DPP prefix sum per step: the scan was a third of a fine level)   1024: 120 (!), 2048: 78, finer: 51-55
@@ -1065,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             const float wsum = wave_sum_dpp<float>(gmax);
             if ((threadIdx.x & 63u) == 0u) s_l1[lvl][threadIdx.x >> 6] = wsum;
         }
-        if (nb_l > 32u) {
+        if (nb_l > 32u || plan.coarse[lvl] == 3) {
             // one bit per (sample, block) in nb / 32 words: set through the thread's own LDS column (dynamic word index)
             const uint32_t nw = (nb_l + 31u) / 32u;
             for (uint32_t k = 0; k < nw; k++) s_words[k * 256u + threadIdx.x] = 0u;
