@@ -9,7 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from ucnerf_amd import _lib
 lib = _lib.load()
-hog = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_exp", "libhog.so"))
+_hog = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_exp", "libhog.so")
+if not os.path.exists(_hog):                    # tools/_exp/ is not tracked: build the hog on first use
+    import subprocess
+    os.makedirs(os.path.dirname(_hog), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-w",
+                           os.path.join(os.path.dirname(os.path.abspath(__file__)), "hog.hip"), "-o", _hog])
+hog = ctypes.CDLL(_hog)
 hog.hog_launch.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda", 0)
 model, cfg, sd = bench.build_model(dev)
