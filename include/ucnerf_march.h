@@ -341,7 +341,9 @@ uint64_t ucn_train_fwd_fragments(void);
  * train_graph.py::_head_gather_index(dir_in_stream=True): bf16 copy of the features (operand of the first layer's weight gradient;
  * F % 8 == 0).  head: HOST float[4] {density_bias, rgb_premultiplier, rgb_bias, rgb_padding} | NULL.  With head the
  * output activations (models.py:515 softplus, :667-672 sigmoid + padding) are applied in fp32 before the store:
- * raw := density, y := rgb. */
+ * raw := density, y := rgb.  r04: x alone may be NULL in the training form -- the bottleneck is linear in h0 (models.py:508), so
+ * its weight-gradient operands can be formed from d^T h0 (train_graph.py::_FusedHeads) -- and ucn_train_bwd's gx likewise; dy's column 3
+ * then carries the density head's gradient at the bottleneck's feature 0. */
 int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float *bias_d0, const float *bias_d1,
                   const float *bias_rgb, const float *pr0, const float *pr1, uint32_t N, uint32_t S, void *h0, void *x,
                   void *h1, void *h2, uint32_t act_ld, const void *ray_cols, void *ray_dst, void *feat_bf16,

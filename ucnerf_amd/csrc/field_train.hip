@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
             xp[o][1] = to_b(acc[o], 1, false);
         }
         if constexpr (p == 0) x0[0] = xp[0][0];
-        if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);
+        if (a.store && a.x) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);     // (r04: x = NULL -- its weight gradients are formed from h0, see _FusedHeads)
     });
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
         const uint4 q = __builtin_bit_cast(uint4, x0[0]);
@@ -369,8 +369,13 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
             if (a.graw && h == 0) {
                 // head: d softplus(z) / dz = sigmoid(z) = -expm1(-softplus(z)) (no cancellation in empty space), from the saved density; rounded to bf16 like
                 // the gradient the per-layer path hands to the bottleneck's GEMM
-                if (a.head) acc[0][0] += (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (-expm1f(-a.density[sample])));
-                else acc[0][0] += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+                float gr;
+                if (a.head) gr = (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (-expm1f(-a.density[sample])));
+                else gr = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+                acc[0][0] += gr;
+                // (r04) the density head's gradient at the bottleneck's feature 0, kept as column 3 of dy: with gx not stored the
+                // host forms its share of d W_d1[0, :] and d b_d1[0] from dy[:, 3]^T h0 (wave half 0 holds feature 0 of its sample in register 0 of tile 0)
+                if (a.dy && live) a.dy[(size_t)sample * 4 + 3] = (uint16_t)(__float_as_uint((float)(__bf16)gr) >> 16);
             }
         }
         bf8 gp[2][2];
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
             gp[o][0] = to_b(acc[o], 0, false);
             gp[o][1] = to_b(acc[o], 1, false);
         }
-        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gx, 256, sample, 2 * p, h, gp[0], gp[1], live);
+        if (a.gx) store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gx, 256, sample, 2 * p, h, gp[0], gp[1], live);                  // (r04: gx = NULL -- the bottleneck's weight gradient is formed from d0^T h0, d1^T h0)
         tile_pair<2, 2, H2 + 72 * p + 64>(ring, a0, gp);
     });
     // ---- ReLU of h0
@@ -432,7 +437,8 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
     UCN_REQUIRE(aux || (pr0 && pr1), "train_fwd: pr0 and pr1 come together");
     UCN_REQUIRE(!aux || (ray_cols && !h0 && !x && !h1 && !h2), "train_fwd: the in-stream direction tile is an inference form: ray_cols, no stores");
     const bool store = h0 || x || h1 || h2 || m0 || m1 || m2;
-    UCN_REQUIRE(!store || (h0 && x && h1 && h2 && m0 && m1 && m2), "train_fwd: the activation / mask outputs come together (all, or none = inference)");
+    UCN_REQUIRE(!store || (h0 && h1 && h2 && m0 && m1 && m2),
+                "train_fwd: the activation / mask outputs come together (all, or none = inference; x alone may be NULL: it is linear in h0)");
     UCN_REQUIRE(feat_level_dim == 0 || (aux && !store && !feat_bf16 && F % feat_level_dim == 0),
                 "train_fwd: level-major rays-fastest features are the inference layout (in-stream direction tile, no stores), F a multiple of the level dim");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_fwd: 1..64 input features, got %u", F);
@@ -464,7 +470,7 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
                              void *d1, void *d0, void *gx, void *gh0, void *dy, float *gfeat, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
-    UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gx && gh0 && gfeat, "train_bwd: null pointer argument");
+    UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gh0 && gfeat, "train_bwd: null pointer argument");
     UCN_REQUIRE(F >= 1 && F <= 64, "train_bwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");
     UCN_REQUIRE(!head || (density && rgb), "train_bwd: head mode needs the forward's density and rgb");

@@ -540,39 +540,70 @@ class _FusedHeads(torch.autograd.Function):
             m1, m2 = (torch.empty(M, 2, 4, device=dev, dtype=torch.int32) for _ in range(2))
             hd = (ctypes.c_float * 4)(*[float(v) for v in head])
             base = act.data_ptr()
+            # r04: with the reference's widths the bottleneck x is neither stored nor read back -- it is linear in h0 (models.py:508 has
+            # no activation there), so every weight gradient that had x or d x as an operand is formed from the [256, 64] products
+            # d0^T h0, d1^T h0 instead (backward below): 0.5 GB less stored here, 0.5 GB less in the backward, 1.5 GB less read by wgrad
+            lean = NW == 256 and NB == 256 and F_in % 32 == 0
             _lib.check(lib.ucn_train_fwd(f.data_ptr(), F_in, packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
-                                         biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, base + 2 * _ACT_X,
+                                         biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, None if lean else base + 2 * _ACT_X,
                                          base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX,
                                          base + 2 * _ACT_FB if fb_in_act else None, hd, density.data_ptr(),
                                          rgb.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), 0, _lib.stream()))
             if not fb_in_act:
                 act[:, _ACT_FB:_ACT_FB + F_in] = f
-        ctx.save_for_backward(act, m0, m1, m2, packed_t, density, rgb)
+        ctx.save_for_backward(act, m0, m1, m2, packed_t, density, rgb, Wd1, bd1, W0, W1)
         ctx.meta = (N, S, NB, NW, E, F_in, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head))
         return density, rgb
 
     @staticmethod
     def backward(ctx, g_density, g_rgb):
         lib = _lib.load()
-        act, m0, m1, m2, packed_t, density, rgb = ctx.saved_tensors
+        act, m0, m1, m2, packed_t, density, rgb, Wd1, bd1, W0, W1 = ctx.saved_tensors
         N, S, NB, NW, E, F_in, f_dt, w_dt, b_dt, head = ctx.meta
         dt, dev, M = torch.bfloat16, act.device, act.shape[0]
         with torch.autocast("cuda", enabled=False):
             g_rgb = torch.zeros(M, 3, device=dev) if g_rgb is None else g_rgb.reshape(M, 3).float().contiguous()
             g_density = None if g_density is None else g_density.reshape(-1).float().contiguous()
-            d1, d0, gx = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(3))
+            lean = NW == 256 and NB == 256 and F_in % 32 == 0
+            d1, d0 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(2))
+            gx = None if lean else torch.empty(M, NW, device=dev, dtype=dt)
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
-            dy = torch.empty(M, 4, device=dev, dtype=dt)
+            dy = torch.zeros(M, 4, device=dev, dtype=dt)        # (column 3: the density head's gradient at the bottleneck, written where a sample has one)
             gfeat = torch.empty(M, F_in, device=dev)
             hd = (ctypes.c_float * 4)(*head)
             _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
                                          packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in,
-                                         d1.data_ptr(), d0.data_ptr(), gx.data_ptr(), gh0.data_ptr(), dy.data_ptr(), gfeat.data_ptr(),
+                                         d1.data_ptr(), d0.data_ptr(), _lib.ptr(gx), gh0.data_ptr(), dy.data_ptr(), gfeat.data_ptr(),
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
             # 302 + 119 us, tools/wgrad_bench.py); the 288-column GEMM of layer 0 is fine (255 us)
-            if NW == 256 and NB == 256:
-                # hand-written weight-gradient kernel (csrc/wgrad.hip), each pass reads its operands once:
+            if lean:
+                # hand-written weight-gradient kernel (csrc/wgrad.hip), each pass reads its operands once.  x = h0 Wd1^T + bd1 and
+                # d x = d0 W0x + d1 W1x (+ the density head's column) never touch memory: with P_i = d_i^T h0 [NW, 64] and
+                # s_i = d_i^T 1 [NW] (the constant-1 column of the aux tile),
+                #   d_i^T x = P_i Wd1^T + s_i bd1^T,     (d x)^T h0 = W0x^T P0 + W1x^T P1 (+ e0 g_raw^T h0),   (d x)^T 1 likewise
+                # -- four [256, 64] x [64, 256] products in fp32 on the weights as the kernels saw them (bf16-rounded) instead of
+                # 2.5 GB of activation traffic; exact where the stored route rounded x and d x to bf16
+                rb = lambda w: w.detach().to(dt).float()
+                Wd1b, bd1b, W0xb, W1xb = rb(Wd1), rb(bd1), rb(W0[:, :NB]), rb(W1[:, NW:NW + NB])
+                h0a = act[:, _ACT_AUX:_ACT_FB]                                  # [aux tile (32) | h0 (64)]
+                P1h = wgrad(d1, act[:, _ACT_H1:_ACT_H1 + NW])                  # [NW, NW]
+                Q1, Q0 = wgrad(d1, h0a), wgrad(d0, h0a)                       # [NW, 32 + 64] each
+                P1, P0, s1, s0 = Q1[:, 32:].contiguous(), Q0[:, 32:].contiguous(), Q1[:, E], Q0[:, E]
+                G = dense_f32.gemm
+                d1x = torch.addr(G(P1, Wd1b), s1, bd1b)                       # d1^T x   [NW, NB]
+                d0x = torch.addr(G(P0, Wd1b), s0, bd1b)                       # d0^T x
+                G1 = torch.cat([P1h, d1x, Q1[:, :32]], dim=1)                 # [NW, NW + NB + 32]
+                G0 = torch.cat([d0x, Q0[:, :32]], dim=1)                      # [NW, NB + 32]
+                gWd1_ = G(W0xb.t().contiguous(), P0.t().contiguous())         # W0x^T P0   [NB, 64]
+                G(W1xb.t().contiguous(), P1.t().contiguous(), flags=dense_f32.ACCUMULATE, out=gWd1_)
+                gbd1_ = (W0xb * s0[:, None]).sum(0) + (W1xb * s1[:, None]).sum(0)        # W0x^T s0 + W1x^T s1   [NB]
+                if g_density is not None:                                     # the density head: feature 0 of the bottleneck
+                    gr = _wgrad_cols(dy, act, _ACT_H0, _ACT_H0 + 64)[3]      # dy[:, 3]^T h0
+                    gWd1_[0] += gr
+                    gbd1_[0] += _colsum(dy)[3]
+                Gd1 = torch.cat([torch.zeros(NB, E, device=dev), gbd1_[:, None], torch.zeros(NB, 31 - E, device=dev), gWd1_], dim=1)   # the stored route's [NB, 32 + 64] layout
+            elif NW == 256 and NB == 256:
                 aux = act[:, _ACT_AUX:_ACT_AUX + 32]
                 G1 = torch.cat([wgrad(d1, act[:, _ACT_H1:_ACT_H1 + NW]), wgrad(d1, act[:, _ACT_X:_ACT_X + NB], aux)], dim=1)   # [NW, NW + NB + 32]
                 G0 = wgrad(d0, act[:, _ACT_X:_ACT_X + NB], aux)                # [NW, NB + 32]
