@@ -293,6 +293,54 @@ class _ColourMLP(torch.autograd.Function):
         return gx.to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
 
 
+class _ColourMLPComposed(torch.autograd.Function):
+    """fp32 route (r04): the colour MLP's two hidden layers with the activation-free bottleneck COMPOSED into them, on csrc/gemm_f32.hip.
+
+    The bottleneck x = h0 Wd1^T + bd1 (models.py:508) has no activation, so x W0x^T = h0 (W0x Wd1)^T + W0x bd1: with
+    A0 = W0x Wd1, A1 = W1x Wd1 ([256, 64], formed OUTSIDE this node with differentiable ops so that autograd carries
+    d A_i back to W_ix and Wd1) the 256-wide x is never materialised:
+
+        h1 = relu(h0 A0^T + pr0_ray),      h2 = relu(h1 W1h^T + h0 A1^T + pr1_ray)
+
+    pr_i [N, 256] = the per-ray terms (direction block, layer bias, W_ix bd1), also formed outside.  Against the uncomposed node:
+    two forward GEMMs of K = 256 become K = 64, the bottleneck GEMM disappears, the backward's two 256 x 256 dgrads into x and
+    the 256 -> 64 dgrad behind them become two 256 -> 64 dgrads, two 256 x 256 weight gradients become 256 x 64."""
+
+    @staticmethod
+    def forward(ctx, h0, A0, pr0, W1h, A1, pr1, N, S):
+        lib = _lib.load()
+        R, G = dense_f32._rows, dense_f32.gemm
+        NW = W1h.shape[0]
+        h0, A0, A1, W1h = R(h0), R(A0), R(A1), R(W1h)
+        pr0, pr1 = pr0.contiguous(), pr1.contiguous()
+        h1 = G(h0, A0)
+        _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, 0, _lib.stream()))
+        h2 = G(h1, W1h)
+        G(h0, A1, flags=dense_f32.ACCUMULATE, out=h2)
+        _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, 0, _lib.stream()))
+        ctx.save_for_backward(h0, h1, h2, A0, A1, W1h)
+        ctx.meta = (N, S, NW)
+        return h2
+
+    @staticmethod
+    def backward(ctx, g_h2):
+        lib = _lib.load()
+        h0, h1, h2, A0, A1, W1h = ctx.saved_tensors
+        N, S, NW = ctx.meta
+        R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
+        g = g_h2.float().contiguous()
+        d1 = torch.empty_like(g)
+        r1 = torch.empty(N, NW, device=g.device)
+        _lib.check(lib.ucn_relu_backward_reduce(g.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, 0, _lib.stream()))
+        d0 = G(d1, R(W1h.t()))
+        r0 = torch.empty(N, NW, device=g.device)
+        _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, 0, _lib.stream()))
+        gA0, gA1, gW1h = WG(d0, h0)[0], WG(d1, h0)[0], WG(d1, h1)[0]
+        gh0 = G(d0, R(A0.t()))
+        G(d1, R(A1.t()), flags=dense_f32.ACCUMULATE, out=gh0)
+        return gh0, gA0, r0, gW1h, gA1, r1, None, None
+
+
 # ------------------------------------------------------------------ fused bf16 forward of the NeRF field's dense layers
 _FRAG_CACHE = {}
 
@@ -689,6 +737,26 @@ def field_heads(mlp, feat, viewdirs, N, S):
         l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
         density = _PropHeads.apply(feat, l0.weight, l0.bias, l1.weight, l1.bias, mlp.density_bias, torch.is_autocast_enabled())
         return density.reshape(N, S), torch.zeros(N, S, 3, device=feat.device)
+    if (not mlp.disable_rgb and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and mlp.net_width_viewdirs % 8 == 0
+            and dense_f32.usable(feat, mlp.density_layer[0].weight) and not dense_f32.library_route()):
+        # the fp32 step on hand-written kernels, the bottleneck composed into the colour layers (_ColourMLPComposed)
+        lin = dense_f32.hip_linear
+        d0l, d1l, l0, l1 = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1
+        NB = d1l.out_features
+        NW = l0.out_features
+        enc = view_encoding(viewdirs, mlp.deg_view)                                              # [N, 27], per ray
+        h0 = lin(feat, d0l.weight, d0l.bias, relu=True)                                          # [N*S, 64]
+        Wd1t = d1l.weight.t()                                                                    # [64, NB] (view: autograd transposes back)
+        W0x, W0e = l0.weight[:, :NB], l0.weight[:, NB:]
+        W1h, W1x, W1e = l1.weight[:, :NW], l1.weight[:, NW:NW + NB], l1.weight[:, NW + NB:]
+        A0, A1 = lin(W0x, Wd1t), lin(W1x, Wd1t)                                                  # W_ix Wd1   [NW, 64]
+        pr0 = lin(enc, W0e, l0.bias) + lin(d1l.bias[None, :], W0x)                               # [N, NW] + [1, NW]
+        pr1 = lin(enc, W1e, l1.bias) + lin(d1l.bias[None, :], W1x)
+        h = _ColourMLPComposed.apply(h0, A0, pr0, W1h, A1, pr1, N, S)
+        raw = lin(h0, d1l.weight[:1], d1l.bias[:1])                                              # feature 0 of the bottleneck (models.py:508)
+        density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
+        rgb = torch.sigmoid(mlp.rgb_premultiplier * lin(h, mlp.rgb_layer.weight, mlp.rgb_layer.bias).reshape(N, S, -1) + mlp.rgb_bias)
+        return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
     if mlp.disable_rgb:
         return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)
