@@ -439,7 +439,8 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
                     precision="fp32 throughout (the reference's shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision): fp32 tables, "
                               "exact-fp32-add table gradients, every dense layer forward / dgrad / wgrad on csrc/gemm_f32.hip "
                               "(v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)" +
-                              ("; UCN_F32_LIBRARY=1: the same graph on torch's library GEMMs (A/B)" if os.environ.get("UCN_F32_LIBRARY") == "1" else ""),
+                              ("; UCN_F32_LIBRARY=1: the r03 graph (uncomposed colour MLP) on torch's library GEMMs (A/B)" if os.environ.get("UCN_F32_LIBRARY") == "1" else
+                               "; r04: the activation-free bottleneck is composed into the colour layers (K = 64 instead of 256 for two of the three 256-wide GEMMs)"),
                     heads=bool(heads))
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
                 heads=("sky NeRF (120 samples x 8 x 256 MLP) + per-ray colour-correction affines + sky-segment and identity "

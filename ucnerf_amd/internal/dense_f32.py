@@ -69,6 +69,10 @@ def wgrad(gy, x, want_bias=False):
     lib = _lib.load()
     M, N = gy.shape
     K = x.shape[1]
+    if not want_bias and K <= 64 < N:
+        # a wide gradient against a narrow input ([256, 64]: the composed colour layers): the kernel's blocks are 256 k columns wide,
+        # its narrow shapes are narrow in N -- form the transpose (x^T gy: a 64-row block, every k column used) and flip it back
+        return wgrad(x, gy, False)[0].t().contiguous(), None
     n = lib.ucn_wgrad_f32_ws_floats(N, K, M)
     st = torch.cuda.current_stream()
     key = (str(gy.device), st.cuda_stream)
@@ -102,7 +106,7 @@ class _HipLinear(torch.autograd.Function):
         lead, K, N, has_bias, relu, x_dt, w_dt = ctx.meta
         gy2 = gy.reshape(-1, N)
         if relu:
-            gy2 = gy2 * (y > 0)
+            gy2 = torch.ops.aten.threshold_backward(gy2.contiguous(), y, 0.0)      # gy where y > 0 else 0: one elementwise pass
         g4 = _rows(gy2)                                                  # [M, N padded to 4]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:

@@ -894,10 +894,14 @@ def sky_forward(net, origins, directions, cam_dirs, far):
             else:
                 h = lin(h, L.weight, L.bias, relu=True)
         sigma = lin(h, net.alpha_linear.weight, net.alpha_linear.bias)
-        Lv = net.views_linears[0]
-        feat = lin(h, net.feature_linear.weight, net.feature_linear.bias)
-        per_ray = lin(venc[:, 0, :], Lv.weight[:, feat.shape[-1]:])                       # the same encoding for a ray's 120 samples
-        h = torch.relu(lin(feat, Lv.weight[:, :feat.shape[-1]], Lv.bias) + per_ray[:, None, :])
+        Lv, Lf = net.views_linears[0], net.feature_linear
+        Wf_in = Lf.out_features
+        # feature_linear has no activation (models.py:806): composed into the views layer, Mv = Wv[:, :256] Wf -- formed with
+        # differentiable ops, autograd carries d Mv back to both weights -- one 256 x 256 layer less forward and backward
+        Mv = lin(Lv.weight[:, :Wf_in], Lf.weight.t())                                      # [128, 256]
+        cb = lin(Lf.bias[None, :], Lv.weight[:, :Wf_in])                                   # Wv[:, :256] b_f   [1, 128]
+        per_ray = lin(venc[:, 0, :], Lv.weight[:, Wf_in:]) + cb                            # the same encoding for a ray's 120 samples
+        h = torch.relu(lin(h, Mv, Lv.bias) + per_ray[:, None, :])
         rgb = torch.sigmoid(lin(h, net.rgb_linear.weight, net.rgb_linear.bias))
     else:
         h = pts
