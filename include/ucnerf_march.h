@@ -360,8 +360,10 @@ int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float
  * [M,256] and gh0 [M,64] as bf16, and the feature gradient gfeat [M,F] fp32. */
 int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
                   const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S,
-                  uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M,4] bf16 | NULL: the colour-logit
-                  gradient consumed, for the rgb layer's weight gradient*/, float *gfeat, ucn_stream_t stream);
+                  uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M, dy_ld] bf16 | NULL: the colour-logit
+                  gradient consumed (columns 0-2) and the density head's gradient at the bottleneck (column 3), for the rgb layer's and
+                  the bottleneck's weight gradients*/, uint32_t dy_ld /*0 = 4; 32: a zero-filled tile ucn_wgrad_bf16 takes as A*/,
+                  float *gfeat, ucn_stream_t stream);
 
 /* The PROPOSAL field's dense part in training (models.py:507-516 with disable_rgb: Linear(F,64) + ReLU, Linear(64,1),
  * softplus(raw + density_bias)), forward and backward, as VALU kernels (prop_train.hip) instead of ~45 library launches.

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UCN_LIB_PATH: an experiment build of the same ABI (tools/build_variant.sh) for A/B measurements; default = the in-tree product
 LIB_PATH = os.environ.get("UCN_LIB_PATH") or os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 RAYS_INCOHERENT = 0x1000   # ucn_march_features layout flag: random (training) rays -> lane-paired fetch on every hashed level
@@ -107,7 +107,7 @@ SIGNATURES = {
     "ucn_train_fwd": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp, c_vp, c_vp,
                       ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_vp],
     "ucn_train_bwd": [c_vp, c_vp, ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp,
-                      c_vp, c_vp, c_vp, c_vp],
+                      c_vp, c_vp, c_u32, c_vp, c_vp],
     "ucn_sky_packed_floats": [],
     "ucn_sky_pack": [ctypes.POINTER(UcnSky), c_vp],
     "ucn_sky_workspace_floats": [c_u32],

@@ -275,7 +275,8 @@ struct TrainBwdArgs {
     const uint32_t *m0;
     const uint4 *m1, *m2;
     uint16_t *d1, *d0, *gx, *gh0;     // bf16 [M,256] x3, [M,64]
-    uint16_t *dy;                     // bf16 [M,4] | NULL: the colour-logit gradient this kernel consumed (columns 0..2; 3 = 0)
+    uint16_t *dy;                     // bf16 [M, ld_dy] | NULL: the colour-logit gradient this kernel consumed (columns 0..2), column 3 = the density head's
+    uint32_t ld_dy;                   // row stride of dy in elements (4, or 32: a zero-padded tile that ucn_wgrad_bf16 takes as its A operand)
     float *gfeat;                     // [M, F]
     uint32_t M, F;
 };
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         gin[0][0] = pack8(v);
         if (a.dy && live && h == 0) {
             const uint4 q = __builtin_bit_cast(uint4, gin[0][0]);
-            *reinterpret_cast<uint2 *>(a.dy + (size_t)sample * 4) = make_uint2(q.x, q.y);
+            *reinterpret_cast<uint2 *>(a.dy + (size_t)sample * a.ld_dy) = make_uint2(q.x, q.y);
         }
         const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         gin[0][1] = pack8(z);
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
                 acc[0][0] += gr;
                 // (r04) the density head's gradient at the bottleneck's feature 0, kept as column 3 of dy: with gx not stored the
                 // host forms its share of d W_d1[0, :] and d b_d1[0] from dy[:, 3]^T h0 (wave half 0 holds feature 0 of its sample in register 0 of tile 0)
-                if (a.dy && live) a.dy[(size_t)sample * 4 + 3] = (uint16_t)(__float_as_uint((float)(__bf16)gr) >> 16);
+                if (a.dy && live) a.dy[(size_t)sample * a.ld_dy + 3] = (uint16_t)(__float_as_uint((float)(__bf16)gr) >> 16);
             }
         }
         bf8 gp[2][2];
@@ -467,7 +468,7 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
 
 extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
                              const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S, uint32_t F,
-                             void *d1, void *d0, void *gx, void *gh0, void *dy, float *gfeat, ucn_stream_t stream) {
+                             void *d1, void *d0, void *gx, void *gh0, void *dy, uint32_t dy_ld, float *gfeat, ucn_stream_t stream) {
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gh0 && gfeat, "train_bwd: null pointer argument");
@@ -476,7 +477,7 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     UCN_REQUIRE(!head || (density && rgb), "train_bwd: head mode needs the forward's density and rgb");
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
-                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, gfeat, (uint32_t)M, F};
+                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F};
     if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");

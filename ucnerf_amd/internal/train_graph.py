@@ -616,12 +616,14 @@ class _FusedHeads(torch.autograd.Function):
             d1, d0 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(2))
             gx = None if lean else torch.empty(M, NW, device=dev, dtype=dt)
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
-            dy = torch.zeros(M, 4, device=dev, dtype=dt)        # (column 3: the density head's gradient at the bottleneck, written where a sample has one)
+            # dy: colour-logit gradients (columns 0-2) + the density head's gradient at the bottleneck (column 3); lean: as a zero-filled
+            # 32-wide tile, the A operand of ucn_wgrad_bf16 (the rgb layer's and the bottleneck row's weight gradients without a library GEMM)
+            dy = torch.zeros(M, 32 if lean else 4, device=dev, dtype=dt)
             gfeat = torch.empty(M, F_in, device=dev)
             hd = (ctypes.c_float * 4)(*head)
             _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
                                          packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in,
-                                         d1.data_ptr(), d0.data_ptr(), _lib.ptr(gx), gh0.data_ptr(), dy.data_ptr(), gfeat.data_ptr(),
+                                         d1.data_ptr(), d0.data_ptr(), _lib.ptr(gx), gh0.data_ptr(), dy.data_ptr(), dy.shape[1], gfeat.data_ptr(),
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
             # 302 + 119 us, tools/wgrad_bench.py); the 288-column GEMM of layer 0 is fine (255 us)
@@ -646,10 +648,10 @@ class _FusedHeads(torch.autograd.Function):
                 gWd1_ = G(W0xb.t().contiguous(), P0.t().contiguous())         # W0x^T P0   [NB, 64]
                 G(W1xb.t().contiguous(), P1.t().contiguous(), flags=dense_f32.ACCUMULATE, out=gWd1_)
                 gbd1_ = (W0xb * s0[:, None]).sum(0) + (W1xb * s1[:, None]).sum(0)        # W0x^T s0 + W1x^T s1   [NB]
+                Gy = wgrad(dy, act[:, _ACT_H2:_ACT_H2 + NW], act[:, _ACT_AUX:_ACT_AUX + 32])     # dy^T [h2 | aux]   [32, NW + 32]
                 if g_density is not None:                                     # the density head: feature 0 of the bottleneck
-                    gr = _wgrad_cols(dy, act, _ACT_H0, _ACT_H0 + 64)[3]      # dy[:, 3]^T h0
-                    gWd1_[0] += gr
-                    gbd1_[0] += _colsum(dy)[3]
+                    gWd1_[0] += wgrad(dy, act[:, _ACT_H0:_ACT_H0 + 64])[3]    # dy[:, 3]^T h0
+                    gbd1_[0] += Gy[3, NW + E]                                 # dy[:, 3]^T 1
                 Gd1 = torch.cat([torch.zeros(NB, E, device=dev), gbd1_[:, None], torch.zeros(NB, 31 - E, device=dev), gWd1_], dim=1)   # the stored route's [NB, 32 + 64] layout
             elif NW == 256 and NB == 256:
                 aux = act[:, _ACT_AUX:_ACT_AUX + 32]
@@ -661,12 +663,17 @@ class _FusedHeads(torch.autograd.Function):
                 G1 = torch.cat([G1a, G1b], dim=1)
                 G0 = _wgrad_cols(d0, act, _ACT_X, _ACT_AUX + 32)                  # [NW, NB + 32]
                 Gd1 = _wgrad_cols(gx, act, _ACT_AUX, _ACT_FB)                     # [NB, 32 + 64]
-            Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)                  # [4, NW]
             gW1, gb1 = G1[:, :NW + NB + E], G1[:, NW + NB + E]
             gW0, gb0 = G0[:, :NB + E], G0[:, NB + E]
             gWd1, gbd1 = Gd1[:, 32:], Gd1[:, E]
-            gWr, gbr = Gr[:3], _colsum(dy)[:3]
-            gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
+            if lean:
+                gWr, gbr = Gy[:3, :NW], Gy[:3, NW + E]
+                G00 = wgrad(gh0, act[:, _ACT_FB:_ACT_FB + F_in], act[:, _ACT_AUX:_ACT_AUX + 32])      # gh0^T [features | aux]   [64, F + 32]
+                gWd0, gbd0 = G00[:, :F_in], G00[:, F_in + E]
+            else:
+                Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)              # [4, NW]
+                gWr, gbr = Gr[:3], _colsum(dy)[:3]
+                gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
         return (gfeat.to(f_dt), None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
                 gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None)
 
