@@ -1,0 +1,10 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import torch, bench
+dev = torch.device("cuda", 0)
+model, cfg, sd = bench.build_model(dev, heads=True)
+model.sky_side_stream = False
+batch = bench.frame_rays(dev)
+n = bench.H_IMG * bench.W_IMG
+flat = {k: v.reshape(n, -1) for k, v in batch.items()}
+print(bench.train_step_ms(model, flat, dev, steps=6, heads=True)["ms"])
