@@ -311,44 +311,72 @@ template <bool HASHED, typename TT>
 __device__ __forceinline__ void level_accumulate_lanepairs(const UcnLevel &lv, const TT *__restrict__ tab,
                                                            const float (&u)[6][3], const float (&rs)[6], float (&acc)[2]) {
     acc[0] = acc[1] = 0.0f;
+#ifndef UCN_LANEPAIR_DEPTH
+#define UCN_LANEPAIR_DEPTH 1
+#endif
+    constexpr uint32_t DEPTH = UCN_LANEPAIR_DEPTH;                  // points whose 8 loads are in flight together (experiment knob)
 #pragma unroll
-    for (uint32_t j = 0; j < 6; j++) {
-        const bool valid = in_unit_cube(u[j][0], u[j][1], u[j][2]);
-        float fx, fy, fz, w[8];
-        uint32_t rows[8];
-        corner_rows<HASHED, true>(lv, u[j][0], u[j][1], u[j][2], fx, fy, fz, rows);
-        float v[8][2];
+    for (uint32_t j0 = 0; j0 < 6; j0 += DEPTH) {
+        float fx[DEPTH], fy[DEPTH], fz[DEPTH];
+        uint32_t adr[DEPTH][4][2];
+        bool valid[DEPTH];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {                              // (y, z) choice; corners 2q (x0) and 2q + 1 (x0 + 1)
-            const auto ad = __builtin_amdgcn_permlane32_swap(rows[2 * q], rows[2 * q + 1], false, false);
-            if constexpr (sizeof(TT) == 4) {
-                const float2 ta = *reinterpret_cast<const float2 *>(tab + (size_t)ad[0] * 2);
-                const float2 tb = *reinterpret_cast<const float2 *>(tab + (size_t)ad[1] * 2);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ta.x), __builtin_bit_cast(uint32_t, tb.x), false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, ta.y), __builtin_bit_cast(uint32_t, tb.y), false, false);
-                v[2 * q][0] = __builtin_bit_cast(float, (uint32_t)s0[0]); v[2 * q + 1][0] = __builtin_bit_cast(float, (uint32_t)s0[1]);
-                v[2 * q][1] = __builtin_bit_cast(float, (uint32_t)s1[0]); v[2 * q + 1][1] = __builtin_bit_cast(float, (uint32_t)s1[1]);
-            } else {
-                typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
-                const uint32_t ta = *reinterpret_cast<const uint32_t *>(tab + (size_t)ad[0] * 2);     // a row = two halves = one word
-                const uint32_t tb = *reinterpret_cast<const uint32_t *>(tab + (size_t)ad[1] * 2);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(ta, tb, false, false);
-                const hx2 h0 = __builtin_bit_cast(hx2, (uint32_t)s0[0]), h1 = __builtin_bit_cast(hx2, (uint32_t)s0[1]);
-                v[2 * q][0] = (float)h0[0]; v[2 * q][1] = (float)h0[1];
-                v[2 * q + 1][0] = (float)h1[0]; v[2 * q + 1][1] = (float)h1[1];
+        for (uint32_t d = 0; d < DEPTH; d++) {
+            const uint32_t j = j0 + d;
+            valid[d] = in_unit_cube(u[j][0], u[j][1], u[j][2]);
+            uint32_t rows[8];
+            corner_rows<HASHED, true>(lv, u[j][0], u[j][1], u[j][2], fx[d], fy[d], fz[d], rows);
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {                          // (y, z) choice; corners 2q (x0) and 2q + 1 (x0 + 1)
+                const auto ad = __builtin_amdgcn_permlane32_swap(rows[2 * q], rows[2 * q + 1], false, false);
+                adr[d][q][0] = ad[0]; adr[d][q][1] = ad[1];
             }
         }
-        corner_weights(fx, fy, fz, w);
-        float f0 = 0.0f, f1 = 0.0f;
+        // every load of the group is issued before the first value is used
+        uint32_t raw[DEPTH][4][2][sizeof(TT) == 4 ? 2 : 1];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            f0 = fmaf(w[k], v[k][0], f0);
-            f1 = fmaf(w[k], v[k][1], f1);
-        }
-        const float damp = erf_pos(rs[j] * lv.inv_gs);
-        if (valid) {
-            acc[0] += f0 * damp;
-            acc[1] += f1 * damp;
+        for (uint32_t d = 0; d < DEPTH; d++)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+#pragma unroll
+                for (uint32_t e = 0; e < 2; e++) {
+                    if constexpr (sizeof(TT) == 4) {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(tab + (size_t)adr[d][q][e] * 2);
+                        raw[d][q][e][0] = t.x; raw[d][q][e][1] = t.y;
+                    } else {
+                        raw[d][q][e][0] = *reinterpret_cast<const uint32_t *>(tab + (size_t)adr[d][q][e] * 2);   // a row = two halves = one word
+                    }
+                }
+#pragma unroll
+        for (uint32_t d = 0; d < DEPTH; d++) {
+            float v[8][2], w[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                if constexpr (sizeof(TT) == 4) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(raw[d][q][0][0], raw[d][q][1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(raw[d][q][0][1], raw[d][q][1][1], false, false);
+                    v[2 * q][0] = __builtin_bit_cast(float, (uint32_t)s0[0]); v[2 * q + 1][0] = __builtin_bit_cast(float, (uint32_t)s0[1]);
+                    v[2 * q][1] = __builtin_bit_cast(float, (uint32_t)s1[0]); v[2 * q + 1][1] = __builtin_bit_cast(float, (uint32_t)s1[1]);
+                } else {
+                    typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(raw[d][q][0][0], raw[d][q][1][0], false, false);
+                    const hx2 h0 = __builtin_bit_cast(hx2, (uint32_t)s0[0]), h1 = __builtin_bit_cast(hx2, (uint32_t)s0[1]);
+                    v[2 * q][0] = (float)h0[0]; v[2 * q][1] = (float)h0[1];
+                    v[2 * q + 1][0] = (float)h1[0]; v[2 * q + 1][1] = (float)h1[1];
+                }
+            }
+            corner_weights(fx[d], fy[d], fz[d], w);
+            float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                f0 = fmaf(w[k], v[k][0], f0);
+                f1 = fmaf(w[k], v[k][1], f1);
+            }
+            const float damp = erf_pos(rs[j0 + d] * lv.inv_gs);
+            if (valid[d]) {
+                acc[0] += f0 * damp;
+                acc[1] += f1 * damp;
+            }
         }
     }
 }
