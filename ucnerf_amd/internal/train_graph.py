@@ -591,7 +591,7 @@ class _FusedHeads(torch.autograd.Function):
             # r04: with the reference's widths the bottleneck x is neither stored nor read back -- it is linear in h0 (models.py:508 has
             # no activation there), so every weight gradient that had x or d x as an operand is formed from the [256, 64] products
             # d0^T h0, d1^T h0 instead (backward below): 0.5 GB less stored here, 0.5 GB less in the backward, 1.5 GB less read by wgrad
-            lean = NW == 256 and NB == 256 and F_in % 32 == 0
+            lean = NW == 256 and NB == 256
             _lib.check(lib.ucn_train_fwd(f.data_ptr(), F_in, packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
                                          biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, None if lean else base + 2 * _ACT_X,
                                          base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX,
@@ -612,7 +612,7 @@ class _FusedHeads(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             g_rgb = torch.zeros(M, 3, device=dev) if g_rgb is None else g_rgb.reshape(M, 3).float().contiguous()
             g_density = None if g_density is None else g_density.reshape(-1).float().contiguous()
-            lean = NW == 256 and NB == 256 and F_in % 32 == 0
+            lean = NW == 256 and NB == 256
             d1, d0 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(2))
             gx = None if lean else torch.empty(M, NW, device=dev, dtype=dt)
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
@@ -668,8 +668,11 @@ class _FusedHeads(torch.autograd.Function):
             gWd1, gbd1 = Gd1[:, 32:], Gd1[:, E]
             if lean:
                 gWr, gbr = Gy[:3, :NW], Gy[:3, NW + E]
-                G00 = wgrad(gh0, act[:, _ACT_FB:_ACT_FB + F_in], act[:, _ACT_AUX:_ACT_AUX + 32])      # gh0^T [features | aux]   [64, F + 32]
-                gWd0, gbd0 = G00[:, :F_in], G00[:, F_in + E]
+                if F_in % 32 == 0:
+                    G00 = wgrad(gh0, act[:, _ACT_FB:_ACT_FB + F_in], act[:, _ACT_AUX:_ACT_AUX + 32])  # gh0^T [features | aux]   [64, F + 32]
+                    gWd0, gbd0 = G00[:, :F_in], G00[:, F_in + E]
+                else:                                   # (the waymo.gin grid: 10 levels x 4 = 40 features -- not a whole number of 32-column tiles)
+                    gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
             else:
                 Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)              # [4, NW]
                 gWr, gbr = Gr[:3], _colsum(dy)[:3]
