@@ -668,10 +668,13 @@ class _FusedHeads(torch.autograd.Function):
             gWd1, gbd1 = Gd1[:, 32:], Gd1[:, E]
             if lean:
                 gWr, gbr = Gy[:3, :NW], Gy[:3, NW + E]
-                if F_in % 32 == 0:
-                    G00 = wgrad(gh0, act[:, _ACT_FB:_ACT_FB + F_in], act[:, _ACT_AUX:_ACT_AUX + 32])  # gh0^T [features | aux]   [64, F + 32]
-                    gWd0, gbd0 = G00[:, :F_in], G00[:, F_in + E]
-                else:                                   # (the waymo.gin grid: 10 levels x 4 = 40 features -- not a whole number of 32-column tiles)
+                fb_cols = (F_in + 31) // 32 * 32 if F_in % 8 == 0 else 1 << 30          # (F_in % 8 != 0: the feature copy is not in the row)
+                if fb_cols <= 64:
+                    # gh0^T [features | aux]: the feature block rounded up to whole 32-column tiles (the waymo.gin grid has 10 levels x 4 = 40
+                    # features) -- the columns behind F_in are whatever the row holds; an output column depends on ITS operand column only
+                    G00 = wgrad(gh0, act[:, _ACT_FB:_ACT_FB + fb_cols], act[:, _ACT_AUX:_ACT_AUX + 32])          # [64, fb_cols + 32]
+                    gWd0, gbd0 = G00[:, :F_in], G00[:, fb_cols + E]
+                else:
                     gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
             else:
                 Gr = _wgrad_cols(dy, act, _ACT_H2, _ACT_H2 + NW)              # [4, NW]
