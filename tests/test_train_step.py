@@ -383,7 +383,9 @@ def test_config2_bf16_training_step_end_to_end():
     """BASELINE.json configs[2] as ONE integrated step at full size: config-B model (NeRF grid L16 / C2 / T = 2^19,
     proposal L6, 64 + 128 samples), 8192 rays, Model.forward(rand=True) under bf16 autocast -> the losses of
     train.py:173-216 with waymo defaults -> backward -> nan_to_num -> FusedAdam(lr 0.01, betas (0.9, 0.99), eps 1e-8).
-    The oracle cannot run at this size; the step is pinned by properties: (i) the bf16 loss is finite and equals the
+    The oracle's autograd pins this configuration on 1024 rays (tests/test_train_full_size.py: fp32 and bf16 routes against
+    oracle/raymarch.py + grid_oracle.c at the same full-size tables); at the full 8192-ray batch the step is additionally
+    held to properties: (i) the bf16 loss is finite and equals the
     loss of the fp32 graph on the same batch and random draws within bf16 rounding (the fp32 graph is the one pinned to
     the reference's own step by test_hip_train_graph_matches_reference_step), (ii) every parameter of both fields gets a
     finite, non-zero gradient, and the bf16 gradients point the way the fp32 ones do, (iii) three optimiser steps on the
