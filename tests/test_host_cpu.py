@@ -158,6 +158,100 @@ def test_all_gather_world_size_2_gloo(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+EXCHANGE_WORKER = r'''
+import copy, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ucnerf_amd.internal import dist as ud, train_utils as tu
+rank = int(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=2)
+
+
+class Field(torch.nn.Module):
+    """a table (gathered rows, like the grid) + a small dense layer: the two kinds of parameters of the path"""
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.table = torch.nn.Parameter(torch.rand(4096, 2, generator=g) * 2 - 1)
+        self.lin = torch.nn.Linear(2, 3)
+        with torch.no_grad():
+            self.lin.weight.copy_(torch.rand(3, 2, generator=g)); self.lin.bias.zero_()
+    def forward(self, idx):
+        return self.lin(self.table[idx]).square().mean() + 0.1 * self.table.square().mean()     # data term + a dense decay term
+
+
+def run(mode):
+    torch.manual_seed(0)
+    model = Field()
+    ddp = ud.wrap_ddp(model, grad_exchange=mode, shard_min_numel=1024)
+    assert ddp.grad_exchange == mode
+    params = list(model.parameters())
+    sharded = [p for p in params if getattr(p, "_ucn_sharded", False)]
+    assert len(sharded) == (1 if mode == "reduce_scatter" else 0)
+    cfg = type("C", (), dict(lr_init=0.01, lr_final=0.001, max_steps=10, lr_delay_steps=0, lr_delay_mult=1.0, adam_beta1=0.9,
+                             adam_beta2=0.99, adam_eps=1e-8))
+    opt, _ = tu.create_optimizer(cfg, model)
+    assert type(opt).__name__ == ("ShardedFusedAdam" if mode == "reduce_scatter" else "FusedAdam")
+    g = torch.Generator().manual_seed(100 + rank)                    # every rank its own rays
+    for it in range(3):
+        idx = torch.randint(0, 4096, (512,), generator=g)
+        opt.zero_grad(set_to_none=True)
+        loss = ddp(idx)
+        if it == 1 and rank == 1:                                    # a non-finite LOCAL gradient on one rank (tensor hooks run before
+            def poison(gr):                                          # DDP's reducer): the reference sanitises the REDUCED gradient
+                gr = gr.clone(); gr[7, 0] = float("nan"); return gr
+            h = model.table.register_hook(poison)
+        loss.backward()
+        if it == 1 and rank == 1:
+            h.remove()
+        tu.clip_gradients(model, None, type("C", (), dict(grad_max_norm=0.0, grad_max_val=0.0)))
+        opt.step()
+    return model, opt
+
+
+a_model, a_opt = run("all_reduce")
+b_model, b_opt = run("reduce_scatter")
+for (n, a), (_, b) in zip(a_model.named_parameters(), b_model.named_parameters()):
+    assert torch.equal(a, b), (n, float((a.detach() - b.detach()).abs().max()))         # two ranks: a + b == b + a, bit-identical
+# both ranks hold the same table (every row was stepped on exactly one of them)
+chk = torch.tensor([float(b_model.table.double().abs().sum())])
+both = [torch.zeros_like(chk) for _ in range(2)]
+dist.all_gather(both, chk)
+assert float(both[0]) == float(both[1])
+# moments: held for half the table only; the gathered state loads into the unsharded optimiser and equals it
+shard_state = [s for s in b_opt.state.values() if s["exp_avg"].numel() == 4096]
+assert len(shard_state) == 1
+full = b_opt.gathered_state_dict()
+ref = a_opt.state_dict()
+for i in ref["state"]:
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(full["state"][i][k].reshape(-1), ref["state"][i][k].reshape(-1)), (i, k)
+assert b_opt.exchange_bytes["reduce_scatter_in"] == 4096 * 2 * 4
+# gradient clipping needs the reduced gradient: refused with the tables sharded
+try:
+    tu.clip_gradients(b_model, type("A", (), dict(sync_gradients=True))(), type("C", (), dict(grad_max_norm=1.0, grad_max_val=0.0)))
+    raise SystemExit("clip_gradients accepted norm clipping on un-reduced table gradients")
+except NotImplementedError:
+    pass
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_reduce_scatter_gradient_exchange_equals_all_reduce_world_size_2_gloo(tmp_path):
+    """SURVEY.md section 5 / 8(e): reduce-scatter -> sharded Adam (each rank steps 1 / N of the table rows) -> all-gather of the
+    parameters, against DDP's all-reduce + the full Adam pass: identical parameters after 3 steps on 2 ranks (bit for bit),
+    a rank-local NaN gradient handled like the reference handles it (nan_to_num on the REDUCED gradient), optimiser state
+    interchangeable through gathered_state_dict()."""
+    script = tmp_path / "worker.py"
+    script.write_text(EXCHANGE_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("OK" in o for o in outs)
+
+
 def test_unwrap_model_sees_through_ddp_style_wrappers():
     """render_image is handed accelerate's prepared model (reference train.py:95,330): `.module` chains are unwrapped,
     anything else is rejected with a clear message."""

@@ -379,6 +379,41 @@ def test_fused_heads_forward_kernel_matches_the_per_layer_path(monkeypatch, fiel
 
 
 @pytest.mark.gpu
+def test_lean_bottleneck_route_against_the_stored_x_route(monkeypatch):
+    """_FusedHeads with the reference's widths forms every weight gradient that has the bottleneck x (or d x) as an operand
+    from d_i^T h0 products (the `lean` route, default); UCN_HEADS_STORED_X=1 selects the r03 route that stores x in the
+    forward, writes d x in the backward and runs three more ucn_wgrad_bf16 passes over them.  Same outputs bit for bit (the
+    forward kernel only skips a store); gradients equal up to the bf16 rounding of x and d x the stored route applies."""
+    import bench
+    from ucnerf_amd.internal import train_graph as tg
+    model, _, _ = bench.build_model(torch.device("cuda", 0))
+    mlp = model.nerf_mlp
+    N, S, F_in = 96, 128, 32
+    g = torch.Generator(device="cuda").manual_seed(18)
+    feat0 = torch.randn(N * S, F_in, device="cuda", generator=g) * 0.5
+    vd = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    cd, cr = torch.randn(N, S, device="cuda", generator=g), torch.randn(N, S, 3, device="cuda", generator=g)
+
+    def run(stored):
+        monkeypatch.setenv("UCN_HEADS_STORED_X", "1" if stored else "0")
+        mlp.zero_grad(set_to_none=True)
+        feat = feat0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            density, rgb = tg.field_heads(mlp, feat, vd, N, S)
+        ((density.float() * cd).sum() + (rgb.float() * cr).sum()).backward()
+        return density.detach(), rgb.detach(), feat.grad.clone(), {n: p.grad.float().clone() for n, p in mlp.named_parameters()
+                                                                    if "encoder" not in n and p.grad is not None}
+    l_d, l_rgb, l_gf, l_g = run(False)
+    s_d, s_rgb, s_gf, s_g = run(True)
+    assert torch.equal(l_d, s_d) and torch.equal(l_rgb, s_rgb) and torch.equal(l_gf, s_gf)
+    assert set(l_g) == set(s_g) and len(l_g) >= 10
+    for n in l_g:
+        a, b = l_g[n].double().reshape(-1), s_g[n].double().reshape(-1)
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel <= 1e-2, (n, rel)
+
+
+@pytest.mark.gpu
 def test_config2_bf16_training_step_end_to_end():
     """BASELINE.json configs[2] as ONE integrated step at full size: config-B model (NeRF grid L16 / C2 / T = 2^19,
     proposal L6, 64 + 128 samples), 8192 rays, Model.forward(rand=True) under bf16 autocast -> the losses of
@@ -580,6 +615,78 @@ def test_ddp_training_step_two_ranks(tmp_path):
     script = tmp_path / "ddp_train_worker.py"
     script.write_text(DDP_TRAIN_WORKER)
     port = str(33500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)
+
+
+SHARDED_WORKER = DDP_TRAIN_WORKER[:DDP_TRAIN_WORKER.index("# reference: the bare model on the whole batch")] + r'''
+from ucnerf_amd.internal import dist as ud
+lo, hi = rank * n // 2, (rank + 1) * n // 2
+half = {k: v[lo:hi] for k, v in full.items()}
+nz = [{k: v[lo:hi] for k, v in d.items()} for d in noise]
+ocfg = types.SimpleNamespace(lr_init=0.01, lr_final=0.001, max_steps=100, lr_delay_steps=0, lr_delay_mult=1.0, adam_beta1=0.9,
+                             adam_beta2=0.99, adam_eps=1e-8)
+
+def run(mode, bf16):
+    m, _ = H.hip_model(spec, sd)
+    m.train()
+    ddp = ud.wrap_ddp(m, device_ids=[0], grad_exchange=mode, shard_min_numel=1 << 14)
+    opt, _ = tu.create_optimizer(ocfg, m)
+    assert type(opt).__name__ == ("ShardedFusedAdam" if mode == "reduce_scatter" else "FusedAdam")
+    losses = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            loss = loss_of(ddp, half, nz)
+        loss.backward()
+        tu.clip_gradients(m, None, types.SimpleNamespace(grad_max_norm=0.0, grad_max_val=0.0))
+        opt.step()
+        losses.append(float(loss.detach()))
+    return m, opt, losses
+
+for bf16 in (False, True):
+    a, a_opt, la = run("all_reduce", bf16)
+    b, b_opt, lb = run("reduce_scatter", bf16)
+    tables = [k for k, p in b.named_parameters() if getattr(p, "_ucn_sharded", False)]
+    assert sorted(tables) == ["nerf_mlp.encoder.embeddings", "prop_mlp_0.encoder.embeddings"], tables
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        # the table gradient's `split` parts meet in the table through float atomics (DESIGN.md): a step is reproducible to fp32
+        # reassociation, not bit for bit; Adam's normalised update turns a 1e-7 gradient difference into <= lr * 1e-3 here
+        d = float((p.detach() - q.detach()).abs().max())
+        assert d <= (2e-5 if not bf16 else 2e-3), (bf16, k, d)
+    assert all(abs(x - y) <= (1e-5 if not bf16 else 2e-2) * abs(x) for x, y in zip(la, lb)), (la, lb)
+    # identical tables on both ranks: every element is stepped on exactly one rank and all-gathered
+    for k in tables:
+        t = dict(b.named_parameters())[k].detach()
+        chk = torch.tensor([float(t.double().sum()), float(t.double().abs().sum())])
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert torch.equal(both[0], both[1]), (k, both)
+    # moments for this rank's half only
+    numels = sorted(s["exp_avg"].numel() for s in b_opt.state.values())[-2:]
+    full_numels = sorted(dict(b.named_parameters())[k].numel() for k in tables)
+    assert numels == [x // 2 for x in full_numels], (numels, full_numels)
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.gpu
+def test_reduce_scatter_gradient_exchange_on_the_training_step_two_ranks(tmp_path):
+    """dist.wrap_ddp(grad_exchange="reduce_scatter") + train_utils.ShardedFusedAdam on the real model (SURVEY.md section 5 /
+    8(e); ref train.py:95,221): the tables leave DDP's reducer, each rank's `ucn_adam_step` covers its half of the rows
+    of the reduce-scattered gradient, the updated rows are all-gathered.  Three steps, fp32 and bf16 routes, against the
+    all-reduce route on the same batches: same parameters and losses (to the reproducibility of one backward), identical
+    tables on both ranks, moments held for half the rows."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER)
+    port = str(35500 + os.getpid() % 2000)
     procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]

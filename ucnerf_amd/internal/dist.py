@@ -53,16 +53,48 @@ def _exchange(out, mine, rank, rp):
     dist.all_gather_into_tensor(out, mine.clone())
 
 
-def wrap_ddp(model, device_ids=None, **kw):
+SHARD_MIN_NUMEL = 1 << 20        # parameters from this size on (the hash tables) take the reduce-scatter route
+
+
+def sharded_parameters(model, world, min_numel=None):
+    """(name, parameter) of every tensor the reduce-scatter exchange shards: the dense hash tables (7.1 M x 2 + 1.9 M x 2
+    floats at config B, 15.0 M x 4 + 6.6 M x 4 at waymo.gin) -- large, contiguous, and divisible by the world size (table
+    rows are padded to multiples of 8 per level, gridencoder/grid.py:122-147, so 1 / 2 / 4 / 8 ranks always divide)."""
+    min_numel = SHARD_MIN_NUMEL if min_numel is None else min_numel
+    return [(n, p) for n, p in model.named_parameters()
+            if p.requires_grad and p.numel() >= min_numel and p.numel() % world == 0 and p.is_contiguous()]
+
+
+def wrap_ddp(model, device_ids=None, grad_exchange="all_reduce", shard_min_numel=None, **kw):
     """DistributedDataParallel for the training step, sized for this model: the table gradients are two dense tensors of
     57 + 15 MB (config B), so ONE 128 MB bucket (default 25 MB would cut the NeRF table's all-reduce off from the rest and
     serialise three collectives) whose gradient views alias the bucket (gradient_as_bucket_view: no 76 MB copy per step).
     What `accelerator.prepare` builds with torch defaults works too (tests/test_train_step.py), just slower; pass
-    `accelerate.DistributedDataParallelKwargs(bucket_cap_mb=128, gradient_as_bucket_view=True)` to the Accelerator for the same."""
+    `accelerate.DistributedDataParallelKwargs(bucket_cap_mb=128, gradient_as_bucket_view=True)` to the Accelerator for the same.
+
+    grad_exchange="reduce_scatter" (ref train.py:95,221 leaves the exchange to DDP's ring
+    all-reduce): the hash tables are taken OUT of DDP's reducer.  Their gradients are produced by the last kernels of the
+    backward, so DDP cannot overlap their all-reduce with anything, and after it every rank runs the same Adam pass over
+    the whole table.  Instead train_utils.ShardedFusedAdam reduce-scatters each table's gradient (every rank receives the
+    mean of ITS 1 / N of the rows: half the bytes of an all-reduce on the wire before the optimiser can start), steps only
+    those rows (1 / N of the Adam traffic and of the moment memory), and all-gathers the updated rows.  The small dense
+    parameters (< 4 MB in all) stay in DDP's bucket.  The tables are marked (`_ucn_sharded`) so that
+    train_utils.sanitize_gradients leaves their still-local gradients alone: the reference's nan_to_num acts on the
+    REDUCED gradient (train_utils.py:342-344 runs after DDP's reduction), which the sharded step reproduces."""
     from torch.nn.parallel import DistributedDataParallel
+    if grad_exchange not in ("all_reduce", "reduce_scatter"):
+        raise ValueError(f"grad_exchange must be 'all_reduce' or 'reduce_scatter', got {grad_exchange!r}")
     opts = dict(bucket_cap_mb=128, gradient_as_bucket_view=True, broadcast_buffers=False)
     opts.update(kw)
-    return DistributedDataParallel(model, device_ids=device_ids, **opts)
+    if grad_exchange == "reduce_scatter":
+        world = dist.get_world_size(opts.get("process_group"))
+        sharded = sharded_parameters(model, world, shard_min_numel)
+        for _, p in sharded:
+            p._ucn_sharded = True
+        DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [n for n, _ in sharded])
+    ddp = DistributedDataParallel(model, device_ids=device_ids, **opts)
+    ddp.grad_exchange = grad_exchange
+    return ddp
 
 
 def all_gather_rows(local, num_rays, world, rank):

@@ -591,7 +591,9 @@ class _FusedHeads(torch.autograd.Function):
             # r04: with the reference's widths the bottleneck x is neither stored nor read back -- it is linear in h0 (models.py:508 has
             # no activation there), so every weight gradient that had x or d x as an operand is formed from the [256, 64] products
             # d0^T h0, d1^T h0 instead (backward below): 0.5 GB less stored here, 0.5 GB less in the backward, 1.5 GB less read by wgrad
-            lean = NW == 256 and NB == 256
+            # UCN_HEADS_STORED_X=1 keeps the r03 route (x stored, d x written by the backward, three more ucn_wgrad_bf16 passes)
+            # selectable: the A/B DESIGN cites and the cross-check of tests/test_train_step.py
+            lean = NW == 256 and NB == 256 and os.environ.get("UCN_HEADS_STORED_X", "0") != "1"
             _lib.check(lib.ucn_train_fwd(f.data_ptr(), F_in, packed.data_ptr(), bias0.data_ptr(), bias1.data_ptr(),
                                          biasr.data_ptr(), pr0.data_ptr(), pr1.data_ptr(), N, S, base + 2 * _ACT_H0, None if lean else base + 2 * _ACT_X,
                                          base + 2 * _ACT_H1, base + 2 * _ACT_H2, ACT_LD, aux.data_ptr(), base + 2 * _ACT_AUX,
@@ -600,19 +602,18 @@ class _FusedHeads(torch.autograd.Function):
             if not fb_in_act:
                 act[:, _ACT_FB:_ACT_FB + F_in] = f
         ctx.save_for_backward(act, m0, m1, m2, packed_t, density, rgb, Wd1, bd1, W0, W1)
-        ctx.meta = (N, S, NB, NW, E, F_in, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head))
+        ctx.meta = (N, S, NB, NW, E, F_in, feat.dtype, Wd0.dtype, bd0.dtype, tuple(float(v) for v in head), lean)
         return density, rgb
 
     @staticmethod
     def backward(ctx, g_density, g_rgb):
         lib = _lib.load()
         act, m0, m1, m2, packed_t, density, rgb, Wd1, bd1, W0, W1 = ctx.saved_tensors
-        N, S, NB, NW, E, F_in, f_dt, w_dt, b_dt, head = ctx.meta
+        N, S, NB, NW, E, F_in, f_dt, w_dt, b_dt, head, lean = ctx.meta
         dt, dev, M = torch.bfloat16, act.device, act.shape[0]
         with torch.autocast("cuda", enabled=False):
             g_rgb = torch.zeros(M, 3, device=dev) if g_rgb is None else g_rgb.reshape(M, 3).float().contiguous()
             g_density = None if g_density is None else g_density.reshape(-1).float().contiguous()
-            lean = NW == 256 and NB == 256
             d1, d0 = (torch.empty(M, NW, device=dev, dtype=dt) for _ in range(2))
             gx = None if lean else torch.empty(M, NW, device=dev, dtype=dt)
             gh0 = torch.empty(M, 64, device=dev, dtype=dt)
@@ -751,7 +752,8 @@ def field_heads(mlp, feat, viewdirs, N, S):
         density = _PropHeads.apply(feat, l0.weight, l0.bias, l1.weight, l1.bias, mlp.density_bias, torch.is_autocast_enabled())
         return density.reshape(N, S), torch.zeros(N, S, 3, device=feat.device)
     if (not mlp.disable_rgb and mlp.net_depth_viewdirs == 2 and mlp.skip_layer_dir == 0 and mlp.net_width_viewdirs % 8 == 0
-            and dense_f32.usable(feat, mlp.density_layer[0].weight) and not dense_f32.library_route()):
+            and dense_f32.usable(feat, mlp.density_layer[0].weight) and not dense_f32.library_route()
+            and os.environ.get("UCN_F32_COMPOSED", "1") == "1"):        # 0: the uncomposed _ColourMLP on the same kernels (A/B, cross-check)
         # the fp32 step on hand-written kernels, the bottleneck composed into the colour layers (_ColourMLPComposed)
         lin = dense_f32.hip_linear
         d0l, d1l, l0, l1 = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1

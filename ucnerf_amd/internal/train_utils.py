@@ -407,9 +407,101 @@ class FusedAdam(torch.optim.Adam):
         return loss
 
 
+class ShardedFusedAdam(FusedAdam):
+    """FusedAdam for `dist.wrap_ddp(model, grad_exchange="reduce_scatter")`: every parameter
+    marked `_ucn_sharded` (the hash tables) is represented in the optimiser by THIS rank's 1 / N of its elements -- a
+    Parameter that is a view of the table's own storage, so the update lands in place.  step():
+      1. per table one `reduce_scatter_tensor(AVG)` of the local full-size gradient -> the mean gradient of this rank's rows
+         (DDP's all-reduce = reduce-scatter + all-gather of GRADIENTS; the second half is not needed before the step);
+      2. nan_to_num on the reduced shard (what clip_gradients does to the reduced gradient in the reference,
+         train_utils.py:342-344) and the parent's step: `ucn_adam_step` over 1 / N of the rows, moments held for those only;
+      3. per table one `all_gather_into_tensor` of the updated rows into the table.
+    Every rank ends the step with identical tables (the same bits: each element is computed on exactly one rank).  With two
+    ranks the result is bit-identical to the all-reduce route (a + b is commutative); with more, equal up to the
+    summation order of the collective.  zero_grad() also clears the full-size table gradients, which are not in
+    param_groups.  `gathered_state_dict()` returns a torch.optim.Adam-compatible state (moments all-gathered) for
+    checkpoints that must load into the unsharded optimiser."""
+
+    def __init__(self, params, process_group=None, **kw):
+        import torch.distributed as dist
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise ValueError("ShardedFusedAdam takes a flat parameter list (create_optimizer's model.parameters())")
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("ShardedFusedAdam needs an initialised torch.distributed process group")
+        self._group = process_group
+        self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        self._tables = []                                      # (full parameter, shard parameter)
+        mine = []
+        for p in params:
+            if getattr(p, "_ucn_sharded", False):
+                n = p.numel() // self._world
+                assert p.numel() % self._world == 0 and p.is_contiguous()
+                shard = torch.nn.Parameter(p.data.view(-1)[self._rank * n:(self._rank + 1) * n], requires_grad=True)
+                self._tables.append((p, shard))
+                mine.append(shard)
+            else:
+                mine.append(p)
+        super().__init__(mine, **kw)
+        self.exchange_bytes = dict(mode="reduce_scatter", reduce_scatter_in=sum(p.numel() * 4 for p, _ in self._tables),
+                                   all_gather_out=sum(p.numel() * 4 for p, _ in self._tables), tables=len(self._tables))
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        for p, _ in self._tables:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import torch.distributed as dist
+        if closure is not None:
+            raise NotImplementedError("ShardedFusedAdam.step(closure): re-evaluating the model between the exchange steps is not supported")
+        live = []
+        for p, shard in self._tables:
+            if p.grad is None:
+                shard.grad = None
+                continue
+            g = p.grad.contiguous().view(-1)
+            out = torch.empty(shard.numel(), device=g.device, dtype=g.dtype)
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.AVG, group=self._group)
+            if not (out.is_cuda and out.numel() >= self.MIN_NUMEL):
+                out.nan_to_num_()                              # (the table kernel sanitises its gradient itself)
+            shard.grad = out
+            live.append((p, shard))
+        loss = super().step()
+        for p, shard in live:
+            # out-of-place send buffer: the shard is a slice of the receive buffer (see _exchange in dist.py for the in-place form)
+            dist.all_gather_into_tensor(p.data.view(-1), shard.data.clone(), group=self._group)
+            shard.grad = None
+        return loss
+
+    def gathered_state_dict(self):
+        """The optimiser state in torch.optim.Adam's layout over the FULL parameters (moments all-gathered): loads into
+        FusedAdam / torch.optim.Adam built on model.parameters().  Collective: every rank must call it."""
+        import torch.distributed as dist
+        sd = self.state_dict()
+        order = [p for g in self.param_groups for p in g['params']]
+        full_of = {id(shard): p for p, shard in self._tables}
+        for i, q in enumerate(order):
+            if id(q) in full_of and i in sd['state']:
+                p = full_of[id(q)]
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    full = torch.empty(p.numel(), device=p.device, dtype=p.dtype)
+                    dist.all_gather_into_tensor(full, sd['state'][i][k].contiguous().view(-1), group=self._group)
+                    sd['state'][i][k] = full.view_as(p)
+        return sd
+
+
 def clip_gradients(model, accelerator, config):
     """ref train_utils.py:335-344: norm / value clipping, then nan_to_num on every gradient.  (The tables stepped by
     FusedAdam are sanitised again inside its kernel -- idempotent.)"""
+    if (getattr(config, 'grad_max_norm', 0) > 0 or getattr(config, 'grad_max_val', 0) > 0) and \
+            any(getattr(p, "_ucn_sharded", False) for p in model.parameters()):
+        raise NotImplementedError("gradient clipping acts on the REDUCED gradient; the reduce-scatter exchange reduces the table "
+                                  "gradients inside the optimiser step -- use dist.wrap_ddp(grad_exchange='all_reduce') with clipping")
     if getattr(config, 'grad_max_norm', 0) > 0 and accelerator.sync_gradients:
         accelerator.clip_grad_norm_(model.parameters(), config.grad_max_norm)
     if getattr(config, 'grad_max_val', 0) > 0 and accelerator.sync_gradients:
@@ -425,7 +517,7 @@ def sanitize_gradients(params):
     small = []
     for p in params:
         g = p.grad
-        if g is None:
+        if g is None or getattr(p, "_ucn_sharded", False):        # sharded tables: sanitised AFTER their reduce-scatter (ShardedFusedAdam)
             continue
         if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse and g.numel() < (1 << 31):
             small.append(g)
@@ -455,8 +547,10 @@ def create_optimizer(config, model):
     lr_fn_main = lambda step: learning_rate_decay(step, lr_init=config.lr_init, lr_final=config.lr_final,
                                                   max_steps=config.max_steps, lr_delay_steps=config.lr_delay_steps,
                                                   lr_delay_mult=config.lr_delay_mult)
-    optimizer = FusedAdam(model.parameters(), lr=config.lr_init, betas=[config.adam_beta1, config.adam_beta2],
-                          eps=config.adam_eps)
+    params = list(model.parameters())
+    # tables taken out of DDP by dist.wrap_ddp(model, grad_exchange="reduce_scatter") need the optimiser that exchanges them
+    cls = ShardedFusedAdam if any(getattr(p, "_ucn_sharded", False) for p in params) else FusedAdam
+    optimizer = cls(params, lr=config.lr_init, betas=[config.adam_beta1, config.adam_beta2], eps=config.adam_eps)
     return optimizer, lr_fn_main
 
 
