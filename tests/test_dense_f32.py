@@ -18,7 +18,10 @@ def _ref(x, w, b=None, acc=None, relu=False):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 3, 256), (777, 256, 544), (4096, 64, 32), (130, 128, 28), (8192, 256, 256), (33, 12, 256),
-                                   (5, 1, 4), (65536, 256, 64)])
+                                   (5, 1, 4), (65536, 256, 64),
+                                   # r05: the weight-resident persistent kernel (N K small, >= 64 row tiles) incl. ragged last tiles,
+                                   # fewer tiles than waves, K not a multiple of the 32-wide chunk, N below the column tile
+                                   (100003, 64, 256), (70001, 4, 256), (3000, 128, 128), (2049, 256, 64), (40000, 60, 36), (8191, 20, 252)])
 def test_gemm_f32_against_float64(M, N, K):
     from ucnerf_amd.internal import dense_f32 as D
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -40,6 +43,26 @@ def test_gemm_f32_against_float64(M, N, K):
     D.gemm(wide_x[:, 4:4 + K], w, b, out=wide_y[:, 2:2 + N])
     assert float((wide_y[:, 2:2 + N].double() - _ref(wide_x[:, 4:4 + K], w, b)).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
     assert float(wide_y[:, :2].abs().max()) == 0 and float(wide_y[:, 2 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,ldm_extra", [(8192, 256, 256, 0), (100003, 64, 256, 8), (5000, 256, 64, 0), (333, 7, 256, 1), (70000, 128, 32, 4)])
+def test_gemm_f32_mask_epilogue(M, N, K, ldm_extra):
+    """UCN_GEMM_MASK: y = mask > 0 ? (x w^T + bias) : 0 -- the ReLU derivative of the layer below as the epilogue of its d X GEMM;
+    exactly the unmasked product where the mask is positive, exactly 0 elsewhere (also with ACCUMULATE: masked after the sum)."""
+    from ucnerf_amd.internal import dense_f32 as D
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    mwide = torch.relu(torch.randn(M, N + ldm_extra, device="cuda", generator=g))         # ~half zeros, like a ReLU output
+    mask = mwide[:, :N]
+    plain = D.gemm(x, w, b)
+    got = D.gemm(x, w, b, mask=mask)
+    assert torch.equal(got, torch.where(mask > 0, plain, torch.zeros_like(plain)))
+    base = torch.randn(M, N, device="cuda", generator=g)
+    acc_plain = base.clone(); D.gemm(x, w, b, D.ACCUMULATE, out=acc_plain)
+    acc_got = base.clone(); D.gemm(x, w, b, D.ACCUMULATE, out=acc_got, mask=mask)
+    assert torch.equal(acc_got, torch.where(mask > 0, acc_plain, torch.zeros_like(acc_plain)))
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 4, 256), (8191, 256, 544), (4096, 64, 32), (100000, 256, 256), (31, 12, 28), (262144, 128, 284)])

@@ -28,156 +28,321 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float f4e(const float4 &v, uint32_t s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
-constexpr uint32_t kGemmAccum = 1u, kGemmRelu = 2u, kGemmVec = 4u;
+constexpr uint32_t kGemmAccum = 1u, kGemmRelu = 2u, kGemmMask = 4u, kGemmVec = 16u;
+
+// ---- epilogue of both gemm kernels -------------------------------------------------------------------------------------------------
+// The product is formed TRANSPOSED, D[feature][sample] = W_tile X_tile^T (A operand = weight rows from LDS, B operand = this lane's
+// sample row): accumulator register r of lane (sample i, half kk) is feature 32 t + (r & 3) + 8 (r >> 2) + 4 kk -- four consecutive
+// output columns per register quad, i.e. ONE 16-byte piece per quad instead of four 4-byte pieces spread over four rows.
+struct GemmOut {
+    const float *bias, *mask;      // mask: y = mask[row][col] > 0 ? y : 0 (the ReLU derivative of the layer below, fused into its d X GEMM)
+    float *Y;
+    uint32_t ldy, ldm, M, N, flags;
+};
+
+__device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
+    if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (o.flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (o.flags & kGemmMask) {
+        const float4 m = *reinterpret_cast<const float4 *>(o.mask + (size_t)row * o.ldm + col);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    return v;
+}
+
+// Direct form: a lane stores the quads of its own row (any N, any alignment).
+template <uint32_t NT>
+__device__ __forceinline__ void gemm_store_direct(const f32x16 (&acc)[NT], const GemmOut &o, uint32_t orow, uint32_t n0, uint32_t kk) {
+    if (orow >= o.M) return;
+    const bool vec = (o.flags & kGemmVec) != 0;
+#pragma unroll
+    for (uint32_t t = 0; t < NT; t++) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint32_t col = n0 + 32u * t + 8u * g + 4u * kk;
+            if (col >= o.N) continue;
+            float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
+            float *yo = o.Y + (size_t)orow * o.ldy + col;
+            if (vec) { *reinterpret_cast<float4 *>(yo) = gemm_finish(v, o, orow, col); continue; }
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (col + c >= o.N) break;
+                float y = e[c] + (o.bias ? o.bias[col + c] : 0.f);
+                if (o.flags & kGemmRelu) y = fmaxf(y, 0.f);
+                if ((o.flags & kGemmMask) && !(o.mask[(size_t)orow * o.ldm + col + c] > 0.f)) y = 0.f;
+                yo[c] = y;
+            }
+        }
+    }
+}
+
+// Staged form (full tiles, 16-byte-aligned rows): a direct store instruction is 32 rows x two 16-byte pieces = 64 partial-line
+// requests; written to the wave's own LDS tile as [row][column] and read back row-contiguous, a store instruction covers whole
+// 128-byte lines (64 lanes x 16 B = 1 KiB of one or two rows) -- the K = 64 layer went from 1.4 to ~3 TB/s of stores.
+// SR rows per pass (the tile is SR x (NC + 4) floats), 32 / SR passes.
+template <uint32_t NT, uint32_t SR>
+__device__ __forceinline__ void gemm_store_staged(const f32x16 (&acc)[NT], const GemmOut &o, float *tile, uint32_t m0, uint32_t n0,
+                                                  uint32_t lane) {
+    constexpr uint32_t NC = NT * 32u, RS = NC + 4u;                // row stride in floats (+4: the rows of a write fall on 8 bank groups)
+    static_assert(SR * (NC / 4u) % 64u == 0u, "a pass is a whole number of wave-wide float4 reads");
+    const uint32_t i = lane & 31u, kk = lane >> 5;
+#pragma unroll
+    for (uint32_t pass = 0; pass < 32u / SR; pass++) {
+        if (i / SR == pass) {
+#pragma unroll
+            for (uint32_t t = 0; t < NT; t++)
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
+                    *reinterpret_cast<float4 *>(tile + (i % SR) * RS + 32u * t + 8u * g + 4u * kk) = v;
+                }
+        }
+        wave_lds_handoff();
+#pragma unroll
+        for (uint32_t u = 0; u < SR * (NC / 4u) / 64u; u++) {
+            const uint32_t f = lane + 64u * u, r = f / (NC / 4u), c4 = f % (NC / 4u);
+            const uint32_t ro = m0 + SR * pass + r, col = n0 + 4u * c4;
+            float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
+            if (ro < o.M) *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = gemm_finish(v, o, ro, col);
+        }
+        wave_lds_handoff();
+    }
+}
 
 template <uint32_t NT>
-__global__ __launch_bounds__(256) void k_gemm_f32(const float *__restrict__ X, uint32_t ldx, const float *__restrict__ W, uint32_t ldw,
-                                                  const float *__restrict__ bias, uint32_t M, uint32_t N, uint32_t K, uint32_t flags,
-                                                  float *__restrict__ Y, uint32_t ldy) {
-    constexpr uint32_t NC = NT * 32u, QS = NC + 1u;                // columns per pass; float4 stride between the k quads (+1: the
-    //                                                                staging writes of one row's 8 quads fall on 8 bank groups)
-    constexpr uint32_t WPT = NC * 8u / 256u;                       // float4 of a weight chunk per thread (= NT)
-    extern __shared__ float4 s_w[];                                // [2 buffers][8 quads][QS]
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, kk = lane >> 5;
-    const uint32_t m0 = blockIdx.x * 128u + wave * 32u, n0 = blockIdx.y * NC;
-    const uint32_t row = m0 + i < M ? m0 + i : M - 1u;             // rows past the end: clamped loads, no stores
-    const float *xrow = X + (size_t)row * ldx;
-    // The product is formed TRANSPOSED, D[feature][sample] = W_tile X_tile^T (A operand = weight rows from LDS, B operand = this lane's
-    // sample row): accumulator register r of lane (sample j, half kk) is then feature 32 t + (r & 3) + 8 (r >> 2) + 4 kk -- four
-    // consecutive output columns per register quad, i.e. ONE 16-byte store per quad instead of four 4-byte stores spread over four rows
-    // (a 1 M x 256 output is 4 M wave-level dword stores otherwise: the K = 64 layer ran at 1.4 TB/s of stores).
-    const bool vec = (flags & kGemmVec) != 0;                      // N, ldy multiples of 4 and Y 16-byte aligned (host-checked)
-    const uint32_t orow = m0 + i;                                  // this lane's output row
-    f32x16 acc[NT];
+__device__ __forceinline__ void gemm_init_acc(f32x16 (&acc)[NT], const GemmOut &o, uint32_t orow, uint32_t n0, uint32_t kk) {
+    const bool vec = (o.flags & kGemmVec) != 0;
 #pragma unroll
     for (uint32_t t = 0; t < NT; t++) {
 #pragma unroll
         for (uint32_t g = 0; g < 4; g++) {
             const uint32_t col = n0 + 32u * t + 8u * g + 4u * kk;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((flags & kGemmAccum) && orow < M) {
-                if (vec) { if (col < N) v = *reinterpret_cast<const float4 *>(Y + (size_t)orow * ldy + col); }
+            if ((o.flags & kGemmAccum) && orow < o.M) {
+                const float *yi = o.Y + (size_t)orow * o.ldy + col;
+                if (vec) { if (col < o.N) v = *reinterpret_cast<const float4 *>(yi); }
                 else {
-                    if (col < N) v.x = Y[(size_t)orow * ldy + col];
-                    if (col + 1u < N) v.y = Y[(size_t)orow * ldy + col + 1u];
-                    if (col + 2u < N) v.z = Y[(size_t)orow * ldy + col + 2u];
-                    if (col + 3u < N) v.w = Y[(size_t)orow * ldy + col + 3u];
+                    if (col < o.N) v.x = yi[0];
+                    if (col + 1u < o.N) v.y = yi[1];
+                    if (col + 2u < o.N) v.z = yi[2];
+                    if (col + 3u < o.N) v.w = yi[3];
                 }
             }
             acc[t][4u * g] = v.x; acc[t][4u * g + 1u] = v.y; acc[t][4u * g + 2u] = v.z; acc[t][4u * g + 3u] = v.w;
         }
     }
-    const uint32_t nchunks = (K + 31u) / 32u;
-    float4 wreg[WPT], a_cur[4], a_nxt[4];
-    auto load_w = [&](uint32_t c) {
+}
+
+// ---- k_gemm_f32: the weight streams through LDS in chunks of 4 CQ k (any N, K) ------------------------------------------------------
+// CQ = k quads per chunk (8: 32 k, 16: 64 k), OCC = workgroups per CU the register budget is cut for (2: <= 256 registers).
+template <uint32_t NT, uint32_t CQ, uint32_t OCC>
+__global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__ X, uint32_t ldx, const float *__restrict__ W, uint32_t ldw,
+                                                       uint32_t K, GemmOut o) {
+    constexpr uint32_t NC = NT * 32u, QS = NC + 1u;                // columns per pass; float4 stride between the k quads (+1: the
+    //                                                                staging writes of one row's quads fall on different bank groups)
+    constexpr uint32_t CK = 4u * CQ, NP = CQ / 2u;                 // k per chunk; quad PAIRS per chunk (one per lane half kk)
+    constexpr uint32_t WPT = NC * CQ / 256u;                       // float4 of a weight chunk per thread
+    constexpr uint32_t WPP = WPT >= 4u ? 4u : WPT, PARTS = WPT / WPP;    // staged through registers in pieces of <= 4 float4
+    static_assert(PARTS * 2u <= NP || PARTS == 1u, "a piece is requested before one quad pair and written behind the next");
+    extern __shared__ float4 s_w[];                                // [2 buffers][CQ quads][QS]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, kk = lane >> 5;
+    const uint32_t m0 = blockIdx.x * 128u + wave * 32u, n0 = blockIdx.y * NC;
+    const uint32_t row = m0 + i < o.M ? m0 + i : o.M - 1u;         // rows past the end: clamped loads, no stores
+    const float *xrow = X + (size_t)row * ldx;
+    f32x16 acc[NT];
+    gemm_init_acc<NT>(acc, o, m0 + i, n0, kk);
+    const uint32_t nchunks = (K + CK - 1u) / CK;
+    float4 wreg[WPP], a_cur[NP], a_nxt[NP];
+    // Every load of the loop is UNCONDITIONAL (clamped address, value zeroed by a select where it is consumed): a predicated load
+    // compiles to a branch around it, and behind a branch the compiler's wait-count pass no longer knows how many loads are in flight --
+    // it put `s_waitcnt vmcnt(0)` in front of the first MFMA of every chunk, i.e. the just-requested weights' full L2 latency.
+    auto load_w = [&](uint32_t c, uint32_t part) {
 #pragma unroll
-        for (uint32_t u = 0; u < WPT; u++) {
-            const uint32_t idx = threadIdx.x + u * 256u, n = idx >> 3, q = idx & 7u, k = c * 32u + 4u * q;
-            wreg[u] = (n0 + n < N && k < K) ? *reinterpret_cast<const float4 *>(W + (size_t)(n0 + n) * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t u = 0; u < WPP; u++) {
+            const uint32_t idx = threadIdx.x + (part * WPP + u) * 256u, n = idx / CQ, q = idx % CQ, k = c * CK + 4u * q;
+            const uint32_t nc = n0 + n < o.N ? n0 + n : o.N - 1u, kc = k < K ? k : 0u;
+            wreg[u] = *reinterpret_cast<const float4 *>(W + (size_t)nc * ldw + kc);
         }
     };
-    auto store_w = [&](uint32_t buf) {
+    auto store_w = [&](uint32_t c, uint32_t part) {
 #pragma unroll
-        for (uint32_t u = 0; u < WPT; u++) {
-            const uint32_t idx = threadIdx.x + u * 256u, n = idx >> 3, q = idx & 7u;
-            s_w[(buf * 8u + q) * QS + n] = wreg[u];
+        for (uint32_t u = 0; u < WPP; u++) {
+            const uint32_t idx = threadIdx.x + (part * WPP + u) * 256u, n = idx / CQ, q = idx % CQ, k = c * CK + 4u * q;
+            const bool live = n0 + n < o.N && k < K;
+            float4 v = wreg[u];
+            v.x = live ? v.x : 0.f; v.y = live ? v.y : 0.f; v.z = live ? v.z : 0.f; v.w = live ? v.w : 0.f;
+            s_w[((c & 1u) * CQ + q) * QS + n] = v;
         }
     };
-    auto load_a = [&](uint32_t c, float4 (&a)[4]) {
+    auto load_a = [&](uint32_t c, float4 (&a)[NP]) {
 #pragma unroll
-        for (uint32_t p = 0; p < 4; p++) {
-            const uint32_t k = c * 32u + 4u * (2u * p + kk);
-            a[p] = k < K ? *reinterpret_cast<const float4 *>(xrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t p = 0; p < NP; p++) {
+            const uint32_t k = c * CK + 4u * (2u * p + kk);
+            a[p] = *reinterpret_cast<const float4 *>(xrow + (k < K ? k : 0u));      // k >= K: the weight quad is zero, and so is this one below
         }
     };
-    load_w(0);
+    auto zero_tail = [&](uint32_t c, float4 (&a)[NP]) {                             // (0 x inf = NaN: both operands of a padding quad are zeroed)
+        if (c * CK + CK <= K) return;                                               // uniform: whole chunks skip the selects
+#pragma unroll
+        for (uint32_t p = 0; p < NP; p++) {
+            const bool live = c * CK + 4u * (2u * p + kk) < K;
+            a[p].x = live ? a[p].x : 0.f; a[p].y = live ? a[p].y : 0.f; a[p].z = live ? a[p].z : 0.f; a[p].w = live ? a[p].w : 0.f;
+        }
+    };
+#pragma unroll
+    for (uint32_t part = 0; part < PARTS; part++) { load_w(0, part); store_w(0, part); }
     load_a(0, a_cur);
-    store_w(0);
+    zero_tail(0, a_cur);
     __syncthreads();
+    // (UCN_EXP_GEMM_*: timing-only experiment builds, tools/build_variant.sh -- results are garbage by construction)
+#ifdef UCN_EXP_GEMM_NOLDS
+    float4 b_stale[NT];
+#pragma unroll
+    for (uint32_t t = 0; t < NT; t++) b_stale[t] = s_w[kk * QS + 32u * t + i];
+#endif
     for (uint32_t c = 0; c < nchunks; c++) {
-        const bool more = c + 1u < nchunks;
-        if (more) { load_w(c + 1u); load_a(c + 1u, a_nxt); }
-        const float4 *buf = s_w + (c & 1u) * 8u * QS;
+        // (the loads of the last chunk's iteration re-read chunk 0: harmless, unconditional -- see above)
+        const uint32_t cn = c + 1u < nchunks ? c + 1u : 0u;
+#ifndef UCN_EXP_GEMM_NOX
+        load_a(cn, a_nxt);
+#endif
+        const float4 *buf = s_w + (c & 1u) * CQ * QS;
+        float4 b[NT];
 #pragma unroll
-        for (uint32_t p = 0; p < 4; p++) {
-            float4 b[NT];
+        for (uint32_t p = 0; p < NP; p++) {
+            // the next chunk's weights: piece j requested before quad pair 2 j and written behind pair 2 j + 1 -- into the OTHER
+            // buffer, whose last readers passed the barrier of chunk c - 1
+#ifndef UCN_EXP_GEMM_NOW
+            if ((p & 1u) == 0u && p / 2u < PARTS) load_w(cn, p / 2u);
+#endif
+#ifdef UCN_EXP_GEMM_NOLDS
 #pragma unroll
-            for (uint32_t t = 0; t < NT; t++) b[t] = buf[(2u * p + kk) * QS + 32u * t + i];
+            for (uint32_t t = 0; t < NT; t++) { b[t] = b_stale[t]; asm volatile("" : "+v"(b[t].x)); }
+#else
+            if (p == 0u) {
+#pragma unroll
+                for (uint32_t t = 0; t < NT; t++) b[t] = buf[kk * QS + 32u * t + i];
+            }
+#endif
+            // the weight operands of the NEXT quad pair are requested tile by tile, each right behind the last MFMA that reads the
+            // register quad it lands in (s = 3): 7 MFMAs (~450 cycles) of cover per ds_read_b128 and no second set of registers
 #pragma unroll
             for (uint32_t s = 0; s < 4; s++)
 #pragma unroll
-                for (uint32_t t = 0; t < NT; t++) acc[t] = mfma32x2(f4e(b[t], s), f4e(a_cur[p], s), acc[t]);
+                for (uint32_t t = 0; t < NT; t++) {
+                    acc[t] = mfma32x2(f4e(b[t], s), f4e(a_cur[p], s), acc[t]);
+#ifndef UCN_EXP_GEMM_NOLDS
+                    if (s == 3u && p + 1u < NP) {
+                        b[t] = buf[(2u * (p + 1u) + kk) * QS + 32u * t + i];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                }
+#ifndef UCN_EXP_GEMM_NOW
+            if (((p & 1u) == 1u || NP == 1u) && p / 2u < PARTS && c + 1u < nchunks) store_w(c + 1u, p / 2u);
+#endif
         }
-        if (more) store_w((c + 1u) & 1u);               // the other buffer: its last readers passed the barrier of chunk c - 1
+#ifndef UCN_EXP_GEMM_NOBAR
         __syncthreads();
+#endif
+#ifndef UCN_EXP_GEMM_NOX
 #pragma unroll
-        for (uint32_t p = 0; p < 4; p++) a_cur[p] = a_nxt[p];
+        for (uint32_t p = 0; p < NP; p++) a_cur[p] = a_nxt[p];
+        zero_tail(c + 1u, a_cur);
+#endif
     }
-    // Epilogue.  Full tiles with 16-byte-aligned rows go through LDS (the weight buffers are free after the last barrier): a lane
-    // holds 4 consecutive columns of ITS row, so a direct store instruction is 32 rows x two 16-byte pieces = 64 partial-line
-    // requests; written to LDS as [row][column] and read back row-contiguous, a store instruction covers whole 128-byte lines
-    // (64 lanes x 16 B = 1 KiB of one or two rows) -- the K = 64 layer went from 1.4 to ~3 TB/s of stores.  Two passes of 16
-    // accumulator quads' worth per wave (16 rows x NC floats x 2 = the wave's quarter of the 64 KiB).
-    if constexpr (NT >= 4u) {
-        if (vec && n0 + NC <= N) {
-            constexpr uint32_t RS = NC + 4u;                           // row stride in floats (+4: the 32 rows of a write fall on 8 bank groups)
-            float *tile = reinterpret_cast<float *>(s_w) + wave * 16u * RS;       // this wave's 16 rows x NC columns (the launch reserves max(weight buffers, 4 such tiles))
-#pragma unroll
-            for (uint32_t half = 0; half < 2; half++) {
-                // rows 16 half ... 16 half + 15 of the wave's 32: the lanes whose row is in this half write their quads
-                if ((i >> 4) == half) {
-#pragma unroll
-                    for (uint32_t t = 0; t < NT; t++)
-#pragma unroll
-                        for (uint32_t g = 0; g < 4; g++) {
-                            float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
-                            *reinterpret_cast<float4 *>(tile + (i & 15u) * RS + 32u * t + 8u * g + 4u * kk) = v;
-                        }
-                }
-                wave_lds_handoff();
-                // read back: NC / 4 float4 per row; the wave's 64 lanes take consecutive float4 of consecutive rows
-#pragma unroll
-                for (uint32_t u = 0; u < 16u * (NC / 4u) / 64u; u++) {
-                    const uint32_t f = lane + 64u * u, r = f / (NC / 4u), c4 = f % (NC / 4u);
-                    const uint32_t ro = m0 + 16u * half + r, col = n0 + 4u * c4;
-                    float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
-                    if (bias) { const float4 bv = *reinterpret_cast<const float4 *>(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-                    if (flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (ro < M) *reinterpret_cast<float4 *>(Y + (size_t)ro * ldy + col) = v;
-                }
-                wave_lds_handoff();
-            }
+    // Full tiles with 16-byte-aligned rows go through LDS (the weight buffers are free after the last barrier), two passes of 16 rows
+    // per wave (16 rows x NC floats x 4 waves = the launch reserves max(weight buffers, 4 such tiles)).
+    if constexpr (NT >= 2u) {
+        if ((o.flags & kGemmVec) && n0 + NC <= o.N) {
+            gemm_store_staged<NT, 16u>(acc, o, reinterpret_cast<float *>(s_w) + wave * 16u * (NC + 4u), m0, n0, lane);
             return;
         }
     }
-    if (orow < M) {
+    gemm_store_direct<NT>(acc, o, m0 + i, n0, kk);
+}
+
+// ---- k_gemm_f32_res: the WHOLE weight resident in LDS, persistent waves (r05) -------------------------------------------------------
+// For the layers whose [N, K] weight fits beside the output staging (N K <= ~16 K floats: 256 x 64 -- the composed colour layers --,
+// 64 x 256 -- their input gradients --, the narrow heads): one workgroup of 8 waves per CU loads the weight ONCE (the chunked kernel
+// re-streams it per 128 rows: as many L2 -> LDS bytes as the activations themselves), then every wave walks its own 32-row tiles with no
+// barrier at all: X rows requested PD chunks ahead (across tile boundaries), products from the resident weight, output through the wave's
+// own 8-row staging tile.  The waves drift apart, so one wave's stores and first-touch reads sit behind the other wave's MFMAs on each SIMD.
+template <uint32_t NT, uint32_t PD>
+__global__ __launch_bounds__(512) void k_gemm_f32_res(const float *__restrict__ X, uint32_t ldx, const float *__restrict__ W, uint32_t ldw,
+                                                      uint32_t K, GemmOut o) {
+    constexpr uint32_t NC = NT * 32u, QS = NC + 1u, SR = 8u;
+    extern __shared__ float4 s_w[];                                // [KQ quads][QS], then 8 staging tiles of SR x (NC + 4) floats
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, kk = lane >> 5;
+    const uint32_t nchunks = (K + 31u) / 32u, KQ = nchunks * 8u;
+    for (uint32_t idx = threadIdx.x; idx < NC * KQ; idx += 512u) {
+        const uint32_t n = idx / KQ, q = idx - n * KQ;             // consecutive threads: consecutive 16-byte pieces of a weight row
+        s_w[q * QS + n] = (n < o.N && 4u * q < K) ? *reinterpret_cast<const float4 *>(W + (size_t)n * ldw + 4u * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float *tile = reinterpret_cast<float *>(s_w + KQ * QS) + wave * SR * (NC + 4u);
+    const uint32_t ntiles = (o.M + 31u) / 32u, gw = blockIdx.x * 8u + wave, GW = gridDim.x * 8u;
+    float4 a[PD + 1u][4];
+    uint32_t pt = gw, pc = 0;                                      // prefetch cursor: (tile, chunk)
+    // unconditional loads (clamped row / column; see k_gemm_f32): rows past the end re-read row M - 1 and are never stored, the k quads
+    // past K are zero in the resident weight and zeroed here before use (tail chunk only)
+    auto fetch = [&](float4 (&dst)[4]) {
+        const uint64_t r = (uint64_t)pt * 32u + i;
+        const uint32_t row = r < o.M ? (uint32_t)r : o.M - 1u;
+        const float *xr = X + (size_t)row * ldx;
 #pragma unroll
-        for (uint32_t t = 0; t < NT; t++) {
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                const uint32_t col = n0 + 32u * t + 8u * g + 4u * kk;
-                if (col >= N) continue;
-                float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
-                if (bias) {
-                    if (vec) { const float4 bv = *reinterpret_cast<const float4 *>(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-                    else {
-                        v.x += bias[col];
-                        if (col + 1u < N) v.y += bias[col + 1u];
-                        if (col + 2u < N) v.z += bias[col + 2u];
-                        if (col + 3u < N) v.w += bias[col + 3u];
-                    }
-                }
-                if (flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                float *yo = Y + (size_t)orow * ldy + col;
-                if (vec) *reinterpret_cast<float4 *>(yo) = v;
-                else {
-                    yo[0] = v.x;
-                    if (col + 1u < N) yo[1] = v.y;
-                    if (col + 2u < N) yo[2] = v.z;
-                    if (col + 3u < N) yo[3] = v.w;
-                }
-            }
+        for (uint32_t p = 0; p < 4; p++) {
+            const uint32_t k = pc * 32u + 4u * (2u * p + kk);
+            dst[p] = *reinterpret_cast<const float4 *>(xr + (k < K ? k : 0u));
         }
+        if (++pc == nchunks) { pc = 0; pt += GW; }
+    };
+    auto zero_tail = [&](uint32_t c, float4 (&v)[4]) {
+        if (c * 32u + 32u <= K) return;
+#pragma unroll
+        for (uint32_t p = 0; p < 4; p++) {
+            const bool live = c * 32u + 4u * (2u * p + kk) < K;
+            v[p].x = live ? v[p].x : 0.f; v[p].y = live ? v[p].y : 0.f; v[p].z = live ? v[p].z : 0.f; v[p].w = live ? v[p].w : 0.f;
+        }
+    };
+#pragma unroll
+    for (uint32_t d = 0; d < PD; d++) fetch(a[d]);
+    for (uint32_t t0 = gw; t0 < ntiles; t0 += GW) {
+        const uint32_t m0 = t0 * 32u;
+        f32x16 acc[NT];
+        gemm_init_acc<NT>(acc, o, m0 + i, 0u, kk);
+        for (uint32_t c = 0; c < nchunks; c++) {
+            fetch(a[PD]);
+            zero_tail(c, a[0]);
+            const float4 *buf = s_w + c * 8u * QS;
+            float4 b[NT];
+#pragma unroll
+            for (uint32_t p = 0; p < 4; p++) {
+                if (p == 0u) {
+#pragma unroll
+                    for (uint32_t t = 0; t < NT; t++) b[t] = buf[kk * QS + 32u * t + i];
+                }
+#pragma unroll
+                for (uint32_t s = 0; s < 4; s++)
+#pragma unroll
+                    for (uint32_t t = 0; t < NT; t++) {
+                        acc[t] = mfma32x2(f4e(b[t], s), f4e(a[0][p], s), acc[t]);
+                        if (s == 3u && p + 1u < 4u) {              // the next quad pair's operands, behind their registers' last reader
+                            b[t] = buf[(2u * (p + 1u) + kk) * QS + 32u * t + i];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+#pragma unroll
+            for (uint32_t d = 0; d < PD; d++)
+#pragma unroll
+                for (uint32_t p = 0; p < 4; p++) a[d][p] = a[d + 1u][p];
+        }
+        if constexpr (NT >= 2u) {
+            if ((o.flags & kGemmVec) && NC <= o.N) { gemm_store_staged<NT, SR>(acc, o, tile, m0, 0u, lane); continue; }
+        }
+        gemm_store_direct<NT>(acc, o, m0 + i, 0u, kk);
     }
 }
 
@@ -207,31 +372,36 @@ __global__ __launch_bounds__(512) void k_wgrad_f32(const float *__restrict__ GY,
     for (uint32_t a = 0; a < NA; a++) bsum[a] = 0.0f;
     // staging: 32 rows x 128 float4 (64 of GY, 64 of X) = 4096 float4, 8 per thread; a thread's float4 index keeps its column
     float4 reg[8];
+    // unconditional loads (clamped addresses, zeroed by selects at the LDS write): predicated loads become branches, and behind
+    // branches the wait-count pass gives up counting and drains every load in flight (see k_gemm_f32)
     auto load_slab = [&](uint32_t ms) {
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) {
-            const uint32_t idx = threadIdx.x + u * 512u, r = idx >> 7, c4 = idx & 127u, m = ms + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_hi) {
-                if (c4 < 64u) { const uint32_t n = n0 + 4u * c4; if (n < N && c4 < NB * 8u) v = *reinterpret_cast<const float4 *>(GY + (size_t)m * ldg + n); }
-                else { const uint32_t k = k0 + 4u * (c4 - 64u); if (k < K) v = *reinterpret_cast<const float4 *>(X + (size_t)m * ldx + k); }
-            }
-            reg[u] = v;
+            const uint32_t idx = threadIdx.x + u * 512u, r = idx >> 7, c4 = idx & 127u;
+            const uint32_t m = ms + r < m_hi ? ms + r : m_hi - 1u;
+            const bool gy = c4 < 64u;
+            const uint32_t n = n0 + 4u * c4, k = k0 + 4u * (c4 - 64u);
+            const uint32_t col = gy ? (n < N ? n : 0u) : (k < K ? k : 0u);
+            const float *src = gy ? GY + (size_t)m * ldg : X + (size_t)m * ldx;
+            reg[u] = *reinterpret_cast<const float4 *>(src + col);
         }
     };
-    auto store_slab = [&](uint32_t buf) {
+    auto store_slab = [&](uint32_t buf, uint32_t ms) {
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) {
-            const uint32_t idx = threadIdx.x + u * 512u;
-            reinterpret_cast<float4 *>(s_slab)[buf * (kWgSlab * kWgCols / 4u) + idx] = reg[u];
+            const uint32_t idx = threadIdx.x + u * 512u, r = idx >> 7, c4 = idx & 127u;
+            const bool live = ms + r < m_hi && (c4 < 64u ? (n0 + 4u * c4 < N && c4 < NB * 8u) : (k0 + 4u * (c4 - 64u) < K));
+            float4 v = reg[u];
+            v.x = live ? v.x : 0.f; v.y = live ? v.y : 0.f; v.z = live ? v.z : 0.f; v.w = live ? v.w : 0.f;
+            reinterpret_cast<float4 *>(s_slab)[buf * (kWgSlab * kWgCols / 4u) + idx] = v;
         }
     };
     const uint32_t nslabs = (m_hi - m_lo + kWgSlab - 1u) / kWgSlab;
-    if (nslabs) { load_slab(m_lo); store_slab(0); }
+    if (nslabs) { load_slab(m_lo); store_slab(0, m_lo); }
     __syncthreads();
     for (uint32_t sidx = 0; sidx < nslabs; sidx++) {
         const bool more = sidx + 1u < nslabs;
-        if (more) load_slab(m_lo + (sidx + 1u) * kWgSlab);
+        load_slab(more ? m_lo + (sidx + 1u) * kWgSlab : m_lo);        // (last slab: an unconditional re-read of the first, unused)
         const float *sl = s_slab + (sidx & 1u) * (kWgSlab * kWgCols);
 #pragma unroll 4
         for (uint32_t q = 0; q < 16; q++) {
@@ -248,7 +418,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f32(const float *__restrict__ GY,
 #pragma unroll
                 for (uint32_t a = 0; a < NA; a++) acc[a][t] = mfma32x2(av[a], b[t], acc[a][t]);
         }
-        if (more) store_slab((sidx + 1u) & 1u);
+        if (more) store_slab((sidx + 1u) & 1u, m_lo + (sidx + 1u) * kWgSlab);
         __syncthreads();
     }
     float *out = ws + (size_t)chunk * N * K;
@@ -296,35 +466,73 @@ uint32_t wgrad_chunk_rows(uint32_t M) {
 
 }  // namespace
 
-extern "C" int ucn_gemm_f32(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
-                            uint32_t K, int flags, float *Y, uint32_t ldy, ucn_stream_t stream) {
+static int gemm_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+extern "C" int ucn_gemm_f32_masked(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
+                                   uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, ucn_stream_t stream) {
     UCN_REQUIRE(X && W && Y, "gemm_f32: null pointer argument");
     UCN_REQUIRE(K % 4u == 0u && ldx % 4u == 0u && ldw % 4u == 0u && ldx >= K && ldw >= K && ldy >= N,
                 "gemm_f32: K, ldx, ldw must be multiples of 4 (16-byte operand loads) and cover the operands (K %u ldx %u ldw %u N %u ldy %u)",
                 K, ldx, ldw, N, ldy);
     UCN_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15u) == 0u, "gemm_f32: X and W must be 16-byte aligned");
-    UCN_REQUIRE((flags & ~3) == 0, "gemm_f32: flags = UCN_GEMM_ACCUMULATE | UCN_GEMM_RELU");
+    UCN_REQUIRE((flags & ~7) == 0, "gemm_f32: flags = UCN_GEMM_ACCUMULATE | UCN_GEMM_RELU | UCN_GEMM_MASK");
+    UCN_REQUIRE(!(flags & (int)kGemmMask) || (mask && ldm >= N), "gemm_f32: UCN_GEMM_MASK needs a mask [M, N] (ldm %u N %u)", ldm, N);
     if (M == 0 || N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nt = N <= 32u ? 1u : N <= 64u ? 2u : N <= 128u ? 4u : 8u;
-    const bool vec = N % 4u == 0u && ldy % 4u == 0u && ((uintptr_t)Y & 15u) == 0u && (!bias || ((uintptr_t)bias & 15u) == 0u);
-    const uint32_t kflags = (uint32_t)flags | (vec ? kGemmVec : 0u);
+    const bool vec = N % 4u == 0u && ldy % 4u == 0u && ((uintptr_t)Y & 15u) == 0u && (!bias || ((uintptr_t)bias & 15u) == 0u) &&
+                     (!(flags & (int)kGemmMask) || (ldm % 4u == 0u && ((uintptr_t)mask & 15u) == 0u));
+    GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, Y, ldy, ldm, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
+    // whole weight resident (persistent waves) when it fits beside the staging tiles and there are tiles for every wave
+    const uint32_t kq = ucn_div_up(K, 32) * 8u, nc = nt * 32u;
+    const size_t res_lds = (size_t)kq * (nc + 1u) * 16u + (nt >= 2u ? 8u * 8u * (nc + 4u) * 4u : 0u);
+    const uint32_t ntiles = ucn_div_up(M, 32);
+    static const bool no_res = getenv("UCN_GEMM_NO_RESIDENT") != nullptr;            // A/B switch (tools/gemm_f32_bench.py)
+    if (N <= nc && res_lds <= 150u * 1024u && ntiles >= 64u && !no_res) {
+        const uint32_t wgs = ucn_div_up(ntiles, 8) < (uint32_t)gemm_num_cus() ? ucn_div_up(ntiles, 8) : (uint32_t)gemm_num_cus();
+#define UCN_GR(NT) hipLaunchKernelGGL((k_gemm_f32_res<NT, 2u>), dim3(wgs), dim3(512), res_lds, st, X, ldx, W, ldw, K, o)
+        switch (nt) {
+            case 1: UCN_GR(1); break;
+            case 2: UCN_GR(2); break;
+            case 4: UCN_GR(4); break;
+            default: UCN_GR(8); break;
+        }
+#undef UCN_GR
+        UCN_LAUNCH_CHECK("gemm_f32 (resident)");
+        return 0;
+    }
     const dim3 grid(ucn_div_up(M, 128), ucn_div_up(N, nt * 32u));
-#define UCN_G(NT)                                                                                                         \
-    hipLaunchKernelGGL((k_gemm_f32<NT>), grid, dim3(256),                                                                 \
-                       (2u * 8u * (NT * 32u + 1u) * 16u > 4u * 16u * (NT * 32u + 4u) * 4u ? 2u * 8u * (NT * 32u + 1u) * 16u          \
-                                                                                       : 4u * 16u * (NT * 32u + 4u) * 4u),         \
-                       st, X, ldx, W, ldw,                                                                                \
-                       bias, M, N, K, kflags, Y, ldy)
+    static const int variant = getenv("UCN_GEMM_VARIANT") ? atoi(getenv("UCN_GEMM_VARIANT")) : 0;       // experiment switch
+#define UCN_LDS(NT, CQ) (2u * CQ * (NT * 32u + 1u) * 16u > 4u * 16u * (NT * 32u + 4u) * 4u ? 2u * CQ * (NT * 32u + 1u) * 16u : 4u * 16u * (NT * 32u + 4u) * 4u)
+#define UCN_G(NT, CQ, OCC) hipLaunchKernelGGL((k_gemm_f32<NT, CQ, OCC>), grid, dim3(256), UCN_LDS(NT, CQ), st, X, ldx, W, ldw, K, o)
     switch (nt) {
-        case 1: UCN_G(1); break;
-        case 2: UCN_G(2); break;
-        case 4: UCN_G(4); break;
-        default: UCN_G(8); break;
+        case 1: UCN_G(1, 8, 2); break;
+        case 2: UCN_G(2, 8, 2); break;
+        case 4: UCN_G(4, 8, 2); break;
+        default:
+            if (variant == 1) UCN_G(8, 16, 1);
+            else if (variant == 2) UCN_G(8, 8, 1);
+            else UCN_G(8, 8, 2);
+            break;
     }
 #undef UCN_G
+#undef UCN_LDS
     UCN_LAUNCH_CHECK("gemm_f32");
     return 0;
+}
+
+extern "C" int ucn_gemm_f32(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
+                            uint32_t K, int flags, float *Y, uint32_t ldy, ucn_stream_t stream) {
+    UCN_REQUIRE((flags & ~3) == 0, "gemm_f32: flags = UCN_GEMM_ACCUMULATE | UCN_GEMM_RELU");
+    return ucn_gemm_f32_masked(X, ldx, W, ldw, bias, M, N, K, flags, Y, ldy, nullptr, 0, stream);
 }
 
 extern "C" uint64_t ucn_wgrad_f32_ws_floats(uint32_t N, uint32_t K, uint64_t M) {

@@ -20,7 +20,7 @@ import torch
 
 from .. import _lib
 
-ACCUMULATE, RELU = 1, 2
+ACCUMULATE, RELU, MASK = 1, 2, 4
 
 
 def library_route():
@@ -47,8 +47,9 @@ def _rows(t):
     return out
 
 
-def gemm(x, w, bias=None, flags=0, out=None, n_out=None):
-    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (ReLU); x / w as returned by _rows (equal padded K).  `out` may be a column view."""
+def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None):
+    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (ReLU); x / w as returned by _rows (equal padded K).  `out` may be a column view.
+    mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below): out = mask > 0 ? out : 0 in the epilogue."""
     lib = _lib.load()
     M, K = x.shape
     N = w.shape[0] if n_out is None else n_out
@@ -56,8 +57,13 @@ def gemm(x, w, bias=None, flags=0, out=None, n_out=None):
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     assert out.stride(1) == 1 or N == 1
-    _lib.check(lib.ucn_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
-                                out.data_ptr(), out.stride(0), _lib.stream()))
+    if mask is None:
+        _lib.check(lib.ucn_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
+                                    out.data_ptr(), out.stride(0), _lib.stream()))
+    else:
+        assert mask.dtype == torch.float32 and mask.shape[0] == M and mask.shape[1] >= N and (mask.stride(1) == 1 or N == 1)
+        _lib.check(lib.ucn_gemm_f32_masked(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags) | MASK,
+                                           out.data_ptr(), out.stride(0), mask.data_ptr(), mask.stride(0), _lib.stream()))
     return out
 
 
