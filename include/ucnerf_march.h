@@ -469,11 +469,15 @@ int ucn_wgrad_bf16(const void *A, uint32_t lda, uint32_t KA, const void *B1, uin
 #define UCN_GEMM_MASK 4
 int ucn_gemm_f32(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N, uint32_t K,
                  int flags, float *Y, uint32_t ldy, ucn_stream_t stream);
-/* ucn_gemm_f32_masked (r05): the same product with UCN_GEMM_MASK allowed: Y = mask[M, N] > 0 ? Y : 0 as the last step of the epilogue --
- *   the ReLU derivative of the layer BELOW (mask = that layer's stored output) fused into the d X GEMM that produces its output gradient
- *   (autograd's threshold_backward pass over [M, N] disappears: 3 x M x N x 4 bytes per layer). */
-int ucn_gemm_f32_masked(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N, uint32_t K,
-                        int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, ucn_stream_t stream);
+/* ucn_gemm_f32_ex (r05): the same product with two more epilogue terms, so that a chain of Linear + ReLU layers needs no elementwise pass:
+ *   rowbias != NULL: + rowbias[row / rgroup][N] (ldr floats per row) before the ReLU -- a per-RAY term under a per-sample GEMM (the view
+ *     branch of the sky NeRF: the direction encoding is the same for a ray's 120 samples, models.py:796-806);
+ *   UCN_GEMM_MASK: Y = mask[M, N] > 0 ? Y : 0 as the last step -- the ReLU derivative of the layer BELOW (mask = that layer's stored
+ *     output) fused into the d X GEMM that produces its output gradient (autograd's threshold_backward pass over [M, N] disappears:
+ *     3 x M x N x 4 bytes per layer). */
+int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N, uint32_t K,
+                    int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias, uint32_t ldr,
+                    uint32_t rgroup, ucn_stream_t stream);
 /* ucn_wgrad_f32: GW[N, K] = GY[M, N]^T X[M, K] (the weight gradient of the layer above) and, if gb != NULL, gb[N] = column sums of GY
  *   (its bias gradient), reduction over the M samples in fixed-order partial sums (deterministic).  `ws`: ucn_wgrad_f32_ws_floats floats.
  *   N, K, ldg, ldx multiples of 4, GY and X 16-byte aligned. */

@@ -65,6 +65,21 @@ def test_gemm_f32_mask_epilogue(M, N, K, ldm_extra):
     assert torch.equal(acc_got, torch.where(mask > 0, acc_plain, torch.zeros_like(acc_plain)))
 
 
+@pytest.mark.parametrize("M,N,K,group", [(120 * 700, 128, 256, 120), (4096, 256, 64, 128), (1000, 6, 256, 7)])
+def test_gemm_f32_row_group_bias(M, N, K, group):
+    """rowbias: + rowbias[row // group] before the ReLU -- the per-RAY term of the sky NeRF's view layer under a per-sample GEMM."""
+    from ucnerf_amd.internal import dense_f32 as D
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    rb = torch.randn((M + group - 1) // group, N, device="cuda", generator=g)
+    got = D.gemm(x, w, b, D.RELU, rowbias=rb, rgroup=group)
+    want = torch.relu(x.double() @ w.double().t() + b.double() + rb.double().repeat_interleave(group, dim=0)[:M])
+    scale = (x.double().abs() @ w.double().abs().t()).max().item() + 1.0
+    assert float((got.double() - want).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 4, 256), (8191, 256, 544), (4096, 64, 32), (100000, 256, 256), (31, 12, 28), (262144, 128, 284)])
 def test_wgrad_f32_against_float64_and_deterministic(M, N, K):
     from ucnerf_amd.internal import dense_f32 as D

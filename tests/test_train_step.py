@@ -1104,6 +1104,43 @@ def test_fused_heads_tail_matches_the_eager_form():
 
 
 @pytest.mark.gpu
+def test_fp32_sky_chain_node_matches_the_layer_by_layer_route_and_torch(monkeypatch):
+    """_SkyTrunkF32 (r05: the sky NeRF's dense layers of the fp32 step as one autograd node, bias / ReLU / ReLU derivative / per-ray
+    direction term as epilogues of csrc/gemm_f32.hip) against (a) the r04 route, one hip_linear per layer with autograd's own
+    threshold_backward, and (b) the reference formulation with torch's library ops (models.py:743-850: concatenations, nn.Linear):
+    same pixels, same parameter gradients to fp32 reassociation."""
+    from ucnerf_amd.internal import sky, train_graph as tg
+    torch.manual_seed(11)
+    net = sky.NeRF(D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True).cuda()
+    net.alpha_linear.bias.data.fill_(0.05)                  # a live sky (see bench.build_model)
+    n = 700
+    g = torch.Generator(device="cuda").manual_seed(12)
+    o = torch.randn(n, 3, device="cuda", generator=g) * 0.1
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda", generator=g), dim=-1)
+    cam = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda", generator=g), dim=-1)
+    far = torch.full((n, 1), 8.0, device="cuda")
+    up = torch.randn(n, 3, device="cuda", generator=g)
+
+    def run(chain, library):
+        monkeypatch.setenv("UCN_SKY_F32_CHAIN", "1" if chain else "0")
+        monkeypatch.setenv("UCN_F32_LIBRARY", "1" if library else "0")
+        net.zero_grad(set_to_none=True)
+        out = tg.sky_forward(net, o, d, cam, far)
+        (out * up).sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}
+    ref_out, ref_g = run(False, True)
+    lay_out, lay_g = run(False, False)
+    ch_out, ch_g = run(True, False)
+    assert float((ch_out - ref_out).abs().max()) <= 2e-5 and float((ch_out - lay_out).abs().max()) <= 2e-5
+    assert set(ch_g) == set(ref_g) and len(ch_g) == 24
+    for k in ref_g:
+        scale = float(ref_g[k].abs().max()) + 1e-12
+        # a pre-activation within an ulp of 0 may fall on either side of the ReLU in two fp32 evaluations: single elements, bounded
+        assert float((ch_g[k] - ref_g[k]).abs().max()) <= 2e-3 * scale, (k, float((ch_g[k] - ref_g[k]).abs().max()), scale)
+        assert float((ch_g[k] - lay_g[k]).abs().max()) <= 2e-3 * scale, k
+
+
+@pytest.mark.gpu
 def test_fp32_training_step_runs_no_library_gemm():
     """VERDICT r03 missing #2: the NON-autocast training step (the reference's shipped precision, scripts/train_waymo.sh:3) -- fields, sky
     NeRF and colour-correction head -- runs every dense layer on csrc/gemm_f32.hip: a profiler trace of one forward + backward holds
@@ -1138,7 +1175,8 @@ def test_fp32_training_step_runs_no_library_gemm():
         loss = step()
         torch.cuda.synchronize()
     names = {e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA}
-    lib = sorted(x for x in names if x.startswith("Cijk_") or "gemm" in x.lower().replace("k_gemm_f32", ""))
+    # (this repo's own kernels: k_gemm_f32<...>, k_gemm_f32_res<...>, both taking a `GemmOut` argument)
+    lib = sorted(x for x in names if x.startswith("Cijk_") or "gemm" in x.lower().replace("k_gemm_f32", "").replace("gemmout", ""))
     assert not lib, lib
     assert any("k_gemm_f32" in x for x in names) and any("k_wgrad_f32" in x for x in names), sorted(names)[:40]
     assert np.isfinite(float(loss.detach()))

@@ -121,7 +121,7 @@ SIGNATURES = {
     "ucn_wgrad_ws_floats": [c_u32, c_u32, c_u64],
     "ucn_wgrad_bf16": [c_vp, c_u32, c_u32, c_vp, c_u32, c_u32, c_vp, c_u32, c_u32, c_u64, c_vp, c_vp, c_vp],
     "ucn_gemm_f32": [c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp],
-    "ucn_gemm_f32_masked": [c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp, c_u32, c_vp],
+    "ucn_gemm_f32_ex": [c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_vp],
     "ucn_wgrad_f32_ws_floats": [c_u32, c_u32, c_u64],
     "ucn_wgrad_f32": [c_vp, c_u32, c_vp, c_u32, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_marching_cubes_ws_bytes": [c_u32, c_u32, c_u32],

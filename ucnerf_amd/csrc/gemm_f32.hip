@@ -36,12 +36,14 @@ constexpr uint32_t kGemmAccum = 1u, kGemmRelu = 2u, kGemmMask = 4u, kGemmVec = 1
 // output columns per register quad, i.e. ONE 16-byte piece per quad instead of four 4-byte pieces spread over four rows.
 struct GemmOut {
     const float *bias, *mask;      // mask: y = mask[row][col] > 0 ? y : 0 (the ReLU derivative of the layer below, fused into its d X GEMM)
+    const float *rbias;            // row-group bias [M / rgroup, N]: + rbias[row / rgroup][col] (a per-RAY term under a per-sample GEMM)
     float *Y;
-    uint32_t ldy, ldm, M, N, flags;
+    uint32_t ldy, ldm, ldr, rgroup, M, N, flags;
 };
 
 __device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
     if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (o.rbias) { const float4 bv = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(row / o.rgroup) * o.ldr + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
     if (o.flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (o.flags & kGemmMask) {
         const float4 m = *reinterpret_cast<const float4 *>(o.mask + (size_t)row * o.ldm + col);
@@ -69,6 +71,7 @@ __device__ __forceinline__ void gemm_store_direct(const f32x16 (&acc)[NT], const
             for (uint32_t c = 0; c < 4; c++) {
                 if (col + c >= o.N) break;
                 float y = e[c] + (o.bias ? o.bias[col + c] : 0.f);
+                if (o.rbias) y += o.rbias[(size_t)(orow / o.rgroup) * o.ldr + col + c];
                 if (o.flags & kGemmRelu) y = fmaxf(y, 0.f);
                 if ((o.flags & kGemmMask) && !(o.mask[(size_t)orow * o.ldm + col + c] > 0.f)) y = 0.f;
                 yo[c] = y;
@@ -476,8 +479,9 @@ static int gemm_num_cus() {
     return n;
 }
 
-extern "C" int ucn_gemm_f32_masked(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
-                                   uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, ucn_stream_t stream) {
+extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
+                               uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias,
+                               uint32_t ldr, uint32_t rgroup, ucn_stream_t stream) {
     UCN_REQUIRE(X && W && Y, "gemm_f32: null pointer argument");
     UCN_REQUIRE(K % 4u == 0u && ldx % 4u == 0u && ldw % 4u == 0u && ldx >= K && ldw >= K && ldy >= N,
                 "gemm_f32: K, ldx, ldw must be multiples of 4 (16-byte operand loads) and cover the operands (K %u ldx %u ldw %u N %u ldy %u)",
@@ -485,12 +489,14 @@ extern "C" int ucn_gemm_f32_masked(const float *X, uint32_t ldx, const float *W,
     UCN_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15u) == 0u, "gemm_f32: X and W must be 16-byte aligned");
     UCN_REQUIRE((flags & ~7) == 0, "gemm_f32: flags = UCN_GEMM_ACCUMULATE | UCN_GEMM_RELU | UCN_GEMM_MASK");
     UCN_REQUIRE(!(flags & (int)kGemmMask) || (mask && ldm >= N), "gemm_f32: UCN_GEMM_MASK needs a mask [M, N] (ldm %u N %u)", ldm, N);
+    UCN_REQUIRE(!rowbias || (rgroup > 0 && ldr >= N), "gemm_f32: a row-group bias needs rgroup > 0 and ldr >= N (rgroup %u ldr %u N %u)", rgroup, ldr, N);
     if (M == 0 || N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nt = N <= 32u ? 1u : N <= 64u ? 2u : N <= 128u ? 4u : 8u;
     const bool vec = N % 4u == 0u && ldy % 4u == 0u && ((uintptr_t)Y & 15u) == 0u && (!bias || ((uintptr_t)bias & 15u) == 0u) &&
-                     (!(flags & (int)kGemmMask) || (ldm % 4u == 0u && ((uintptr_t)mask & 15u) == 0u));
-    GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, Y, ldy, ldm, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
+                     (!(flags & (int)kGemmMask) || (ldm % 4u == 0u && ((uintptr_t)mask & 15u) == 0u)) &&
+                     (!rowbias || (ldr % 4u == 0u && ((uintptr_t)rowbias & 15u) == 0u));
+    GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
     // whole weight resident (persistent waves) when it fits beside the staging tiles and there are tiles for every wave
     const uint32_t kq = ucn_div_up(K, 32) * 8u, nc = nt * 32u;
     const size_t res_lds = (size_t)kq * (nc + 1u) * 16u + (nt >= 2u ? 8u * 8u * (nc + 4u) * 4u : 0u);
@@ -532,7 +538,7 @@ extern "C" int ucn_gemm_f32_masked(const float *X, uint32_t ldx, const float *W,
 extern "C" int ucn_gemm_f32(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
                             uint32_t K, int flags, float *Y, uint32_t ldy, ucn_stream_t stream) {
     UCN_REQUIRE((flags & ~3) == 0, "gemm_f32: flags = UCN_GEMM_ACCUMULATE | UCN_GEMM_RELU");
-    return ucn_gemm_f32_masked(X, ldx, W, ldw, bias, M, N, K, flags, Y, ldy, nullptr, 0, stream);
+    return ucn_gemm_f32_ex(X, ldx, W, ldw, bias, M, N, K, flags, Y, ldy, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 extern "C" uint64_t ucn_wgrad_f32_ws_floats(uint32_t N, uint32_t K, uint64_t M) {

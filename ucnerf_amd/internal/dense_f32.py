@@ -47,9 +47,10 @@ def _rows(t):
     return out
 
 
-def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None):
-    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (ReLU); x / w as returned by _rows (equal padded K).  `out` may be a column view.
-    mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below): out = mask > 0 ? out : 0 in the epilogue."""
+def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None, rgroup=0):
+    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (+ rowbias[row // rgroup]) (ReLU); x / w as returned by _rows (equal padded K).
+    `out` may be a column view.  mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below): out = mask > 0 ? out : 0
+    as the last step of the epilogue."""
     lib = _lib.load()
     M, K = x.shape
     N = w.shape[0] if n_out is None else n_out
@@ -57,13 +58,18 @@ def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None):
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     assert out.stride(1) == 1 or N == 1
-    if mask is None:
+    if mask is None and rowbias is None:
         _lib.check(lib.ucn_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
                                     out.data_ptr(), out.stride(0), _lib.stream()))
-    else:
+        return out
+    if mask is not None:
         assert mask.dtype == torch.float32 and mask.shape[0] == M and mask.shape[1] >= N and (mask.stride(1) == 1 or N == 1)
-        _lib.check(lib.ucn_gemm_f32_masked(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags) | MASK,
-                                           out.data_ptr(), out.stride(0), mask.data_ptr(), mask.stride(0), _lib.stream()))
+        flags = int(flags) | MASK
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rgroup > 0 and rowbias.shape[0] * rgroup >= M and rowbias.shape[1] >= N and rowbias.stride(1) == 1
+    _lib.check(lib.ucn_gemm_f32_ex(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
+                                   out.data_ptr(), out.stride(0), _lib.ptr(mask), 0 if mask is None else mask.stride(0),
+                                   _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), int(rgroup), _lib.stream()))
     return out
 
 

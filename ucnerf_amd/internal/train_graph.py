@@ -885,6 +885,84 @@ def hash_decay(mlp):
     return _HashDecay.apply(enc.embeddings, enc._offsets_np)
 
 
+class _SkyTrunkF32(torch.autograd.Function):
+    """The sky NeRF's dense layers (models.py:743-820) of the fp32 training step as ONE autograd node over csrc/gemm_f32.hip (r05): the
+    eight 256-wide layers (skip into layer 5 as a second accumulating GEMM on the padded points), the density row, the view layer with
+    feature_linear composed in (Mv) and its per-RAY direction term as the GEMM's row-group bias, the rgb row.  Every bias + ReLU is a
+    GEMM epilogue, and every ReLU derivative is the MASK epilogue of the d X GEMM that produces the layer's output gradient (mask = the
+    layer's stored output) -- no elementwise pass over an [M, 256] tensor is left (r04: threshold_backward 4.4 ms, adds 1.3 ms, ReLU /
+    bias kernels 2.0 ms of the 60 ms step).  Each activation is stored once (fp32, [M, 256]); two [M, 256] gradient buffers ping-pong.
+    Inputs: pts4 [M, 4] (points padded with a zero column; no gradient), per_ray [n, 128], the layer parameters."""
+
+    @staticmethod
+    def forward(ctx, pts4, per_ray, Mv, bv, Wa, ba, Wr, br, *wb):
+        G = dense_f32.gemm
+        Ws, bs = wb[0::2], wb[1::2]
+        M, n = pts4.shape[0], per_ray.shape[0]
+        group = M // n
+        pad4 = lambda w: torch.nn.functional.pad(w, (0, 4 - w.shape[1] % 4)) if w.shape[1] % 4 else w
+        hs = []
+        h = G(pts4, pad4(Ws[0].detach()).contiguous(), bs[0].detach(), dense_f32.RELU)
+        hs.append(h)
+        for i in range(1, 8):
+            W = Ws[i].detach()
+            if i == 5:                                                      # [pts | h] -> two column blocks of the weight
+                y = G(h, W[:, 3:].contiguous(), bs[i].detach())
+                h = G(pts4, pad4(W[:, :3]).contiguous(), None, dense_f32.ACCUMULATE | dense_f32.RELU, out=y)
+            else:
+                h = G(h, W.contiguous(), bs[i].detach(), dense_f32.RELU)
+            hs.append(h)
+        sigma = G(h, Wa.detach().contiguous(), ba.detach())                                    # [M, 1]
+        hv = G(h, Mv.detach().contiguous(), bv.detach(), dense_f32.RELU, rowbias=per_ray.detach().contiguous(), rgroup=group)    # [M, 128]
+        rgbl = G(hv, Wr.detach().contiguous(), br.detach())                                    # [M, 3] logits
+        ctx.save_for_backward(pts4, Mv, Wa, Wr, hv, *hs, *Ws)
+        ctx.group = group
+        return sigma, rgbl
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgbl):
+        G, WG = dense_f32.gemm, dense_f32.wgrad
+        saved = ctx.saved_tensors
+        pts4, Mv, Wa, Wr, hv = saved[:5]
+        hs, Ws = saved[5:13], saved[13:21]
+        M, dev = pts4.shape[0], pts4.device
+        n = M // ctx.group
+        g4 = torch.zeros(M, 4, device=dev)
+        g4[:, :3] = g_rgbl
+        gs4 = torch.zeros(M, 4, device=dev)
+        gs4[:, :1] = g_sigma
+        padT = lambda w: torch.nn.functional.pad(w.detach().t(), (0, 4 - w.shape[0] % 4)).contiguous() if w.shape[0] % 4 else w.detach().t().contiguous()
+        # rgb row
+        gWr4, gbr4 = WG(g4, hv, True)
+        gWr, gbr = gWr4[:3], gbr4[:3]
+        dv = G(g4, padT(Wr), mask=hv)                                                          # d (view layer pre-activation) [M, 128]
+        gMv, gbv = WG(dv, hs[7], True)
+        g_per_ray = dv.reshape(n, ctx.group, -1).sum(dim=1)
+        # into h7: view layer + density row, masked by h7 > 0 after the sum
+        d = G(dv, Mv.detach().t().contiguous())
+        gWa4, gba4 = WG(gs4, hs[7], True)
+        gWa, gba = gWa4[:1], gba4[:1]
+        d = G(gs4, padT(Wa), None, dense_f32.ACCUMULATE, out=d, mask=hs[7])
+        del dv
+        gW, gb = [None] * 8, [None] * 8
+        for i in range(7, 0, -1):
+            W = Ws[i].detach()
+            if i == 5:
+                gWh, gb[i] = WG(d, hs[4], True)
+                gWp = WG(d, pts4, False)[0]
+                gW[i] = torch.cat([gWp[:, :3], gWh], dim=1)
+                d = G(d, W[:, 3:].t().contiguous(), mask=hs[4])
+            else:
+                gW[i], gb[i] = WG(d, hs[i - 1], True)
+                d = G(d, W.t().contiguous(), mask=hs[i - 1])
+        gW0, gb[0] = WG(d, pts4, True)
+        gW[0] = gW0[:, :3]
+        out = [None, g_per_ray, gMv, gbv, gWa, gba, gWr, gbr]
+        for i in range(8):
+            out += [gW[i], gb[i]]
+        return tuple(out)
+
+
 def sky_forward(net, origins, directions, cam_dirs, far):
     """models.py:852-904 + :743-850 with torch ops (training only; rendering uses csrc/sky.hip)."""
     n = origins.shape[0]
@@ -901,14 +979,6 @@ def sky_forward(net, origins, directions, cam_dirs, far):
         # layer 5, [feature | view encoding] into the views layer) are products by column blocks of the weight instead -- the
         # direction block is per RAY ([n, 27] against [n * 120, 283] rows)
         lin = dense_f32.hip_linear
-        h = pts
-        for i in range(8):
-            L = net.pts_linears[i]
-            if i == 5:
-                h = torch.relu(lin(h, L.weight[:, 3:], L.bias) + lin(pts, L.weight[:, :3]))
-            else:
-                h = lin(h, L.weight, L.bias, relu=True)
-        sigma = lin(h, net.alpha_linear.weight, net.alpha_linear.bias)
         Lv, Lf = net.views_linears[0], net.feature_linear
         Wf_in = Lf.out_features
         # feature_linear has no activation (models.py:806): composed into the views layer, Mv = Wv[:, :256] Wf -- formed with
@@ -916,8 +986,24 @@ def sky_forward(net, origins, directions, cam_dirs, far):
         Mv = lin(Lv.weight[:, :Wf_in], Lf.weight.t())                                      # [128, 256]
         cb = lin(Lf.bias[None, :], Lv.weight[:, :Wf_in])                                   # Wv[:, :256] b_f   [1, 128]
         per_ray = lin(venc[:, 0, :], Lv.weight[:, Wf_in:]) + cb                            # the same encoding for a ray's 120 samples
-        h = torch.relu(lin(h, Mv, Lv.bias) + per_ray[:, None, :])
-        rgb = torch.sigmoid(lin(h, net.rgb_linear.weight, net.rgb_linear.bias))
+        if os.environ.get("UCN_SKY_F32_CHAIN", "1") == "1":
+            # r05: one autograd node, bias / ReLU / ReLU-derivative / per-ray term as GEMM epilogues (_SkyTrunkF32)
+            pts4 = F.pad(pts.reshape(-1, 3), (0, 1))
+            wb = [t for L in net.pts_linears for t in (L.weight, L.bias)]
+            sigma, rgbl = _SkyTrunkF32.apply(pts4, per_ray, Mv, Lv.bias, net.alpha_linear.weight, net.alpha_linear.bias,
+                                             net.rgb_linear.weight, net.rgb_linear.bias, *wb)
+            sigma, rgb = sigma.reshape(n, 120, 1), torch.sigmoid(rgbl.reshape(n, 120, 3))
+        else:                                                                              # r04: layer by layer (A/B, cross-check)
+            h = pts
+            for i in range(8):
+                L = net.pts_linears[i]
+                if i == 5:
+                    h = torch.relu(lin(h, L.weight[:, 3:], L.bias) + lin(pts, L.weight[:, :3]))
+                else:
+                    h = lin(h, L.weight, L.bias, relu=True)
+            sigma = lin(h, net.alpha_linear.weight, net.alpha_linear.bias)
+            h = torch.relu(lin(h, Mv, Lv.bias) + per_ray[:, None, :])
+            rgb = torch.sigmoid(lin(h, net.rgb_linear.weight, net.rgb_linear.bias))
     else:
         h = pts
         for i in range(8):
