@@ -651,7 +651,8 @@ for bf16 in (False, True):
     a, a_opt, la = run("all_reduce", bf16)
     b, b_opt, lb = run("reduce_scatter", bf16)
     tables = [k for k, p in b.named_parameters() if getattr(p, "_ucn_sharded", False)]
-    assert sorted(tables) == ["nerf_mlp.encoder.embeddings", "prop_mlp_0.encoder.embeddings"], tables
+    # (the tiny spec's tables are small: with the 16 K threshold of this test the three widest dense weights are sharded as well)
+    assert {"nerf_mlp.encoder.embeddings", "prop_mlp_0.encoder.embeddings"} <= set(tables), tables
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         # the table gradient's `split` parts meet in the table through float atomics: a step is reproducible to fp32
         # reassociation, not bit for bit; Adam's normalised update turns a 1e-7 gradient difference into <= lr * 1e-3 here
@@ -666,8 +667,8 @@ for bf16 in (False, True):
         dist.all_gather(both, chk)
         assert torch.equal(both[0], both[1]), (k, both)
     # moments for this rank's half only
-    numels = sorted(s["exp_avg"].numel() for s in b_opt.state.values())[-2:]
     full_numels = sorted(dict(b.named_parameters())[k].numel() for k in tables)
+    numels = sorted(s["exp_avg"].numel() for s in b_opt.state.values())[-len(tables):]
     assert numels == [x // 2 for x in full_numels], (numels, full_numels)
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)

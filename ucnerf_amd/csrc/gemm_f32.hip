@@ -26,6 +26,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// the same instruction with the accumulator PINNED to the accumulation registers ("a" class): the 64-row shape of k_gemm_f32 holds 256
+// accumulator registers, exactly the AGPR half of the file -- left to the allocator they were split over both halves and ~1500
+// v_accvgpr_read / _write / _mov per chunk shuffled them around the MFMAs (r05 first build)
+__device__ __forceinline__ void mfma32x2_acc(float a, float b, f32x16 &c) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ float f4e(const float4 &v, uint32_t s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
 constexpr uint32_t kGemmAccum = 1u, kGemmRelu = 2u, kGemmMask = 4u, kGemmVec = 16u;
@@ -138,8 +144,13 @@ __device__ __forceinline__ void gemm_init_acc(f32x16 (&acc)[NT], const GemmOut &
 }
 
 // ---- k_gemm_f32: the weight streams through LDS in chunks of 4 CQ k (any N, K) ------------------------------------------------------
-// CQ = k quads per chunk (8: 32 k, 16: 64 k), OCC = workgroups per CU the register budget is cut for (2: <= 256 registers).
-template <uint32_t NT, uint32_t CQ, uint32_t OCC>
+// CQ = k quads per chunk (8: 32 k), OCC = workgroups per CU the register budget is cut for, RT = 32-row tiles per wave.
+//   <NT, 8, 2, 1>: 4 waves x 32 rows, two workgroups per CU (<= 256 registers): one workgroup's first-touch reads, stores and chunk
+//                  barriers sit behind the other one's MFMAs.
+//   <8, 8, 1, 2>:  4 waves x 64 rows x 256 columns, 256 accumulator registers, one workgroup per CU (the shape of the vendor library's
+//                  256 x 256 macro tile): every weight operand read from LDS and every staged weight quad feeds TWO MFMAs, a barrier
+//                  per 16 K MFMA cycles instead of 8 K.
+template <uint32_t NT, uint32_t CQ, uint32_t OCC, uint32_t RT>
 __global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__ X, uint32_t ldx, const float *__restrict__ W, uint32_t ldw,
                                                        uint32_t K, GemmOut o) {
     constexpr uint32_t NC = NT * 32u, QS = NC + 1u;                // columns per pass; float4 stride between the k quads (+1: the
@@ -148,15 +159,21 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__
     constexpr uint32_t WPT = NC * CQ / 256u;                       // float4 of a weight chunk per thread
     constexpr uint32_t WPP = WPT >= 4u ? 4u : WPT, PARTS = WPT / WPP;    // staged through registers in pieces of <= 4 float4
     static_assert(PARTS * 2u <= NP || PARTS == 1u, "a piece is requested before one quad pair and written behind the next");
+    static_assert(RT == 1u || RT == 2u, "one or two 32-row tiles per wave");
     extern __shared__ float4 s_w[];                                // [2 buffers][CQ quads][QS]
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, kk = lane >> 5;
-    const uint32_t m0 = blockIdx.x * 128u + wave * 32u, n0 = blockIdx.y * NC;
-    const uint32_t row = m0 + i < o.M ? m0 + i : o.M - 1u;         // rows past the end: clamped loads, no stores
-    const float *xrow = X + (size_t)row * ldx;
-    f32x16 acc[NT];
-    gemm_init_acc<NT>(acc, o, m0 + i, n0, kk);
+    const uint32_t m0 = blockIdx.x * (128u * RT) + wave * (32u * RT), n0 = blockIdx.y * NC;
+    const float *xrow[RT];
+#pragma unroll
+    for (uint32_t r = 0; r < RT; r++) {
+        const uint32_t row = m0 + 32u * r + i < o.M ? m0 + 32u * r + i : o.M - 1u;      // rows past the end: clamped loads, no stores
+        xrow[r] = X + (size_t)row * ldx;
+    }
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (uint32_t r = 0; r < RT; r++) gemm_init_acc<NT>(acc[r], o, m0 + 32u * r + i, n0, kk);
     const uint32_t nchunks = (K + CK - 1u) / CK;
-    float4 wreg[WPP], a_cur[NP], a_nxt[NP];
+    float4 wreg[WPP], a_cur[RT][NP], a_nxt[RT][NP];
     // Every load of the loop is UNCONDITIONAL (clamped address, value zeroed by a select where it is consumed): a predicated load
     // compiles to a branch around it, and behind a branch the compiler's wait-count pass no longer knows how many loads are in flight --
     // it put `s_waitcnt vmcnt(0)` in front of the first MFMA of every chunk, i.e. the just-requested weights' full L2 latency.
@@ -178,92 +195,87 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__
             s_w[((c & 1u) * CQ + q) * QS + n] = v;
         }
     };
-    auto load_a = [&](uint32_t c, float4 (&a)[NP]) {
+    auto load_a = [&](uint32_t c, float4 (&a)[RT][NP]) {
 #pragma unroll
-        for (uint32_t p = 0; p < NP; p++) {
-            const uint32_t k = c * CK + 4u * (2u * p + kk);
-            a[p] = *reinterpret_cast<const float4 *>(xrow + (k < K ? k : 0u));      // k >= K: the weight quad is zero, and so is this one below
-        }
+        for (uint32_t r = 0; r < RT; r++)
+#pragma unroll
+            for (uint32_t p = 0; p < NP; p++) {
+                const uint32_t k = c * CK + 4u * (2u * p + kk);
+                a[r][p] = *reinterpret_cast<const float4 *>(xrow[r] + (k < K ? k : 0u));      // k >= K: zeroed below
+            }
     };
-    auto zero_tail = [&](uint32_t c, float4 (&a)[NP]) {                             // (0 x inf = NaN: both operands of a padding quad are zeroed)
+    auto zero_tail = [&](uint32_t c, float4 (&a)[RT][NP]) {                         // (0 x inf = NaN: both operands of a padding quad are zeroed)
         if (c * CK + CK <= K) return;                                               // uniform: whole chunks skip the selects
 #pragma unroll
-        for (uint32_t p = 0; p < NP; p++) {
-            const bool live = c * CK + 4u * (2u * p + kk) < K;
-            a[p].x = live ? a[p].x : 0.f; a[p].y = live ? a[p].y : 0.f; a[p].z = live ? a[p].z : 0.f; a[p].w = live ? a[p].w : 0.f;
-        }
+        for (uint32_t r = 0; r < RT; r++)
+#pragma unroll
+            for (uint32_t p = 0; p < NP; p++) {
+                const bool live = c * CK + 4u * (2u * p + kk) < K;
+                float4 &v = a[r][p];
+                v.x = live ? v.x : 0.f; v.y = live ? v.y : 0.f; v.z = live ? v.z : 0.f; v.w = live ? v.w : 0.f;
+            }
     };
 #pragma unroll
     for (uint32_t part = 0; part < PARTS; part++) { load_w(0, part); store_w(0, part); }
     load_a(0, a_cur);
     zero_tail(0, a_cur);
     __syncthreads();
-    // (UCN_EXP_GEMM_*: timing-only experiment builds, tools/build_variant.sh -- results are garbage by construction)
-#ifdef UCN_EXP_GEMM_NOLDS
-    float4 b_stale[NT];
-#pragma unroll
-    for (uint32_t t = 0; t < NT; t++) b_stale[t] = s_w[kk * QS + 32u * t + i];
-#endif
     for (uint32_t c = 0; c < nchunks; c++) {
         // (the loads of the last chunk's iteration re-read chunk 0: harmless, unconditional -- see above)
         const uint32_t cn = c + 1u < nchunks ? c + 1u : 0u;
-#ifndef UCN_EXP_GEMM_NOX
         load_a(cn, a_nxt);
-#endif
         const float4 *buf = s_w + (c & 1u) * CQ * QS;
         float4 b[NT];
 #pragma unroll
         for (uint32_t p = 0; p < NP; p++) {
             // the next chunk's weights: piece j requested before quad pair 2 j and written behind pair 2 j + 1 -- into the OTHER
             // buffer, whose last readers passed the barrier of chunk c - 1
-#ifndef UCN_EXP_GEMM_NOW
             if ((p & 1u) == 0u && p / 2u < PARTS) load_w(cn, p / 2u);
-#endif
-#ifdef UCN_EXP_GEMM_NOLDS
-#pragma unroll
-            for (uint32_t t = 0; t < NT; t++) { b[t] = b_stale[t]; asm volatile("" : "+v"(b[t].x)); }
-#else
             if (p == 0u) {
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++) b[t] = buf[kk * QS + 32u * t + i];
             }
-#endif
             // the weight operands of the NEXT quad pair are requested tile by tile, each right behind the last MFMA that reads the
-            // register quad it lands in (s = 3): 7 MFMAs (~450 cycles) of cover per ds_read_b128 and no second set of registers
+            // register quad it lands in (s = 3): 7 RT MFMAs (>= 450 cycles) of cover per ds_read_b128 and no second set of registers
 #pragma unroll
             for (uint32_t s = 0; s < 4; s++)
 #pragma unroll
                 for (uint32_t t = 0; t < NT; t++) {
-                    acc[t] = mfma32x2(f4e(b[t], s), f4e(a_cur[p], s), acc[t]);
-#ifndef UCN_EXP_GEMM_NOLDS
+#pragma unroll
+                    for (uint32_t r = 0; r < RT; r++) {
+                        if constexpr (RT == 2u) mfma32x2_acc(f4e(b[t], s), f4e(a_cur[r][p], s), acc[r][t]);
+                        else acc[r][t] = mfma32x2(f4e(b[t], s), f4e(a_cur[r][p], s), acc[r][t]);
+                    }
                     if (s == 3u && p + 1u < NP) {
                         b[t] = buf[(2u * (p + 1u) + kk) * QS + 32u * t + i];
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#endif
                 }
-#ifndef UCN_EXP_GEMM_NOW
             if (((p & 1u) == 1u || NP == 1u) && p / 2u < PARTS && c + 1u < nchunks) store_w(c + 1u, p / 2u);
-#endif
         }
-#ifndef UCN_EXP_GEMM_NOBAR
         __syncthreads();
-#endif
-#ifndef UCN_EXP_GEMM_NOX
 #pragma unroll
-        for (uint32_t p = 0; p < NP; p++) a_cur[p] = a_nxt[p];
+        for (uint32_t r = 0; r < RT; r++)
+#pragma unroll
+            for (uint32_t p = 0; p < NP; p++) a_cur[r][p] = a_nxt[r][p];
         zero_tail(c + 1u, a_cur);
-#endif
     }
     // Full tiles with 16-byte-aligned rows go through LDS (the weight buffers are free after the last barrier), two passes of 16 rows
-    // per wave (16 rows x NC floats x 4 waves = the launch reserves max(weight buffers, 4 such tiles)).
-    if constexpr (NT >= 2u) {
-        if ((o.flags & kGemmVec) && n0 + NC <= o.N) {
-            gemm_store_staged<NT, 16u>(acc, o, reinterpret_cast<float *>(s_w) + wave * 16u * (NC + 4u), m0, n0, lane);
-            return;
-        }
+    // per wave and row tile (16 rows x NC floats x 4 waves = the launch reserves max(weight buffers, 4 such tiles)).
+    // (the epilogue's bounds are made opaque HERE: its ~70 loop-invariant column / row predicates were hoisted above the chunk loop and
+    // held in scalar registers across it -- 210 of them spilled into vector lanes, which the 64-row shape does not have to spare)
+    GemmOut oe = o;
+    asm volatile("" : "+s"(oe.N), "+s"(oe.M), "+s"(oe.flags));
+    if constexpr (RT == 2u) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // inline-asm MFMAs: their result latency (16 passes) is not known to the hazard recogniser
+    const bool staged = NT >= 2u && (oe.flags & kGemmVec) && n0 + NC <= oe.N;
+    float *tile = reinterpret_cast<float *>(s_w) + wave * 16u * (NC + 4u);
+    if constexpr (RT == 1u) {
+        if (staged) gemm_store_staged<NT, 16u>(acc[0], oe, tile, m0, n0, lane);
+        else gemm_store_direct<NT>(acc[0], oe, m0 + i, n0, kk);
+    } else {
+        if (staged) { gemm_store_staged<NT, 16u>(acc[0], oe, tile, m0, n0, lane); gemm_store_staged<NT, 16u>(acc[1], oe, tile, m0 + 32u, n0, lane); }
+        else { gemm_store_direct<NT>(acc[0], oe, m0 + i, n0, kk); gemm_store_direct<NT>(acc[1], oe, m0 + 32u + i, n0, kk); }
     }
-    gemm_store_direct<NT>(acc, o, m0 + i, n0, kk);
 }
 
 // ---- k_gemm_f32_res: the WHOLE weight resident in LDS, persistent waves (r05) -------------------------------------------------------
@@ -515,18 +527,21 @@ extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uin
         UCN_LAUNCH_CHECK("gemm_f32 (resident)");
         return 0;
     }
-    const dim3 grid(ucn_div_up(M, 128), ucn_div_up(N, nt * 32u));
-    static const int variant = getenv("UCN_GEMM_VARIANT") ? atoi(getenv("UCN_GEMM_VARIANT")) : 0;       // experiment switch
+    static const int variant = getenv("UCN_GEMM_VARIANT") ? atoi(getenv("UCN_GEMM_VARIANT")) : 0;       // A/B switch (tools/gemm_f32_bench.py)
+    // UCN_GEMM_VARIANT=2: 64-row waves, one workgroup per CU (the library's macro-tile shape).  MEASURED SLOWER (80.8 / 99.6 TF at
+    // K = 256 / 544 against 93.9 / 120.5 for two 32-row workgroups per CU, profiles/r05/gemm_f32_variants.txt): with one wave per SIMD
+    // every LDS / barrier / first-touch bubble is exposed, which the vendor kernel avoids by hand-scheduled assembly.  Kept as the A/B.
+    const uint32_t rt = (nt == 8u && variant == 2) ? 2u : 1u;
+    const dim3 grid(ucn_div_up(M, 128u * rt), ucn_div_up(N, nt * 32u));
 #define UCN_LDS(NT, CQ) (2u * CQ * (NT * 32u + 1u) * 16u > 4u * 16u * (NT * 32u + 4u) * 4u ? 2u * CQ * (NT * 32u + 1u) * 16u : 4u * 16u * (NT * 32u + 4u) * 4u)
-#define UCN_G(NT, CQ, OCC) hipLaunchKernelGGL((k_gemm_f32<NT, CQ, OCC>), grid, dim3(256), UCN_LDS(NT, CQ), st, X, ldx, W, ldw, K, o)
+#define UCN_G(NT, CQ, OCC, RT) hipLaunchKernelGGL((k_gemm_f32<NT, CQ, OCC, RT>), grid, dim3(256), UCN_LDS(NT, CQ), st, X, ldx, W, ldw, K, o)
     switch (nt) {
-        case 1: UCN_G(1, 8, 2); break;
-        case 2: UCN_G(2, 8, 2); break;
-        case 4: UCN_G(4, 8, 2); break;
+        case 1: UCN_G(1, 8, 2, 1); break;
+        case 2: UCN_G(2, 8, 2, 1); break;
+        case 4: UCN_G(4, 8, 2, 1); break;
         default:
-            if (variant == 1) UCN_G(8, 16, 1);
-            else if (variant == 2) UCN_G(8, 8, 1);
-            else UCN_G(8, 8, 2);
+            if (rt == 2u) UCN_G(8, 8, 1, 2);
+            else UCN_G(8, 8, 2, 1);
             break;
     }
 #undef UCN_G

@@ -307,38 +307,36 @@ class _ColourMLPComposed(torch.autograd.Function):
     the 256 -> 64 dgrad behind them become two 256 -> 64 dgrads, two 256 x 256 weight gradients become 256 x 64."""
 
     @staticmethod
-    def forward(ctx, h0, A0, pr0, W1h, A1, pr1, N, S):
-        lib = _lib.load()
+    def forward(ctx, h0, A0, pr0, W1h, A1, pr1, Wr, br, N, S):
+        # r05: the per-ray terms are the GEMMs' row-group bias, the ReLUs their epilogue, and the rgb row (models.py:663) sits inside the
+        # node so that its d X GEMM can carry h2's ReLU derivative as a mask epilogue (r04: ucn_bias_relu / ucn_relu_backward_reduce passes)
         R, G = dense_f32._rows, dense_f32.gemm
-        NW = W1h.shape[0]
-        h0, A0, A1, W1h = R(h0), R(A0), R(A1), R(W1h)
+        h0, A0, A1, W1h, Wr = R(h0), R(A0), R(A1), R(W1h), R(Wr)
         pr0, pr1 = pr0.contiguous(), pr1.contiguous()
-        h1 = G(h0, A0)
-        _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, 0, _lib.stream()))
+        h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
         h2 = G(h1, W1h)
-        G(h0, A1, flags=dense_f32.ACCUMULATE, out=h2)
-        _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, 0, _lib.stream()))
-        ctx.save_for_backward(h0, h1, h2, A0, A1, W1h)
-        ctx.meta = (N, S, NW)
-        return h2
+        G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
+        rgbl = G(h2, Wr, br.float().contiguous())
+        ctx.save_for_backward(h0, h1, h2, A0, A1, W1h, Wr)
+        ctx.meta = (N, S, W1h.shape[0])
+        return rgbl
 
     @staticmethod
-    def backward(ctx, g_h2):
-        lib = _lib.load()
-        h0, h1, h2, A0, A1, W1h = ctx.saved_tensors
+    def backward(ctx, g_rgbl):
+        h0, h1, h2, A0, A1, W1h, Wr = ctx.saved_tensors
         N, S, NW = ctx.meta
         R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
-        g = g_h2.float().contiguous()
-        d1 = torch.empty_like(g)
-        r1 = torch.empty(N, NW, device=g.device)
-        _lib.check(lib.ucn_relu_backward_reduce(g.data_ptr(), h2.data_ptr(), d1.data_ptr(), r1.data_ptr(), N, S, NW, 0, _lib.stream()))
-        d0 = G(d1, R(W1h.t()))
-        r0 = torch.empty(N, NW, device=g.device)
-        _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, 0, _lib.stream()))
+        n_rgb = Wr.shape[0]
+        g4 = R(g_rgbl.float())                                                     # [M, 3 -> 4]
+        gWr4, gbr4 = WG(g4, h2, True)
+        d1 = G(g4, R(Wr.t()), mask=h2)                                             # d (layer 1 pre-activation)
+        r1 = d1.view(N, S, NW).sum(dim=1)
+        d0 = G(d1, R(W1h.t()), mask=h1)
+        r0 = d0.view(N, S, NW).sum(dim=1)
         gA0, gA1, gW1h = WG(d0, h0)[0], WG(d1, h0)[0], WG(d1, h1)[0]
         gh0 = G(d0, R(A0.t()))
         G(d1, R(A1.t()), flags=dense_f32.ACCUMULATE, out=gh0)
-        return gh0, gA0, r0, gW1h, gA1, r1, None, None
+        return gh0, gA0, r0, gW1h, gA1, r1, gWr4[:n_rgb], gbr4[:n_rgb], None, None
 
 
 # ------------------------------------------------------------------ fused bf16 forward of the NeRF field's dense layers
@@ -767,10 +765,10 @@ def field_heads(mlp, feat, viewdirs, N, S):
         A0, A1 = lin(W0x, Wd1t), lin(W1x, Wd1t)                                                  # W_ix Wd1   [NW, 64]
         pr0 = lin(enc, W0e, l0.bias) + lin(d1l.bias[None, :], W0x)                               # [N, NW] + [1, NW]
         pr1 = lin(enc, W1e, l1.bias) + lin(d1l.bias[None, :], W1x)
-        h = _ColourMLPComposed.apply(h0, A0, pr0, W1h, A1, pr1, N, S)
+        rgbl = _ColourMLPComposed.apply(h0, A0, pr0, W1h, A1, pr1, mlp.rgb_layer.weight, mlp.rgb_layer.bias, N, S)
         raw = lin(h0, d1l.weight[:1], d1l.bias[:1])                                              # feature 0 of the bottleneck (models.py:508)
         density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
-        rgb = torch.sigmoid(mlp.rgb_premultiplier * lin(h, mlp.rgb_layer.weight, mlp.rgb_layer.bias).reshape(N, S, -1) + mlp.rgb_bias)
+        rgb = torch.sigmoid(mlp.rgb_premultiplier * rgbl.reshape(N, S, -1) + mlp.rgb_bias)
         return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
     x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
     if mlp.disable_rgb:
