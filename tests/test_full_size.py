@@ -482,9 +482,10 @@ def test_config3_five_camera_frame_row_tiles_vs_oracle():
     out = models.render_image(model, bench.Ranks(1, 0), batch, False, 1.0, cfg, verbose=False, eval_camidx=0)
     got = out["rgb"].reshape(n, 3).float().cpu()
     assert torch.isfinite(got).all()
-    # the five cameras really differ (a frame_rays that repeated camera 0 five times would pass a per-ray oracle check)
-    o = batch["origins"].reshape(5, -1, 3)[:, 0]
-    assert float((o[1:] - o[:-1]).norm(dim=-1).min()) > 1e-3
+    # the five cameras really differ -- a rig: one position, five yaw angles (bench.frame_cameras) -- a frame_rays that repeated
+    # camera 0 five times would pass a per-ray oracle check
+    c = batch["cam_dirs"].reshape(5, -1, 3)[:, 0]
+    assert float((c[:, None, :] - c[None, :, :]).norm(dim=-1)[~torch.eye(5, dtype=torch.bool, device=dev)].min()) > 0.1
     idx = torch.linspace(0, n - 1, 2048).long()
     flat = {k: v.reshape(n, -1)[idx.to(dev)].cpu() for k, v in batch.items() if k != "rand_vec"}
     noise = [rm.LevelNoise(rand_vec=rand_vec[idx, 3 * l:3 * l + 3]) for l in range(2)]

@@ -654,10 +654,15 @@ for bf16 in (False, True):
     # (the tiny spec's tables are small: with the 16 K threshold of this test the three widest dense weights are sharded as well)
     assert {"nerf_mlp.encoder.embeddings", "prop_mlp_0.encoder.embeddings"} <= set(tables), tables
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-        # the table gradient's `split` parts meet in the table through float atomics (DESIGN.md): a step is reproducible to fp32
-        # reassociation, not bit for bit; Adam's normalised update turns a 1e-7 gradient difference into <= lr * 1e-3 here
-        d = float((p.detach() - q.detach()).abs().max())
-        assert d <= (2e-5 if not bf16 else 2e-3), (bf16, k, d)
+        # The table gradient's `split` parts meet in the table through float atomics (DESIGN.md): a backward is reproducible to fp32
+        # reassociation, not bit for bit, and Adam's normalised update (lr * m / sqrt(v): +-lr on the first step whatever |g| is)
+        # turns a rounding-level difference of a near-zero gradient element into a difference of up to lr in that element -- so
+        # single elements are not comparable between ANY two runs.  The three-step UPDATE as a whole is: relative L2 <= 1e-2
+        # (a shard stepped twice, not at all, or with the other rank's rows would move it by O(1)).
+        init = sd[k].to(p.device)
+        ua, ub = (p.detach() - init).double(), (q.detach() - init).double()
+        rel = float((ua - ub).norm() / (ua.norm() + 1e-30))
+        assert rel <= (1e-2 if not bf16 else 5e-2), (bf16, k, rel)
     assert all(abs(x - y) <= (1e-5 if not bf16 else 2e-2) * abs(x) for x, y in zip(la, lb)), (la, lb)
     # identical tables on both ranks: every element is stepped on exactly one rank and all-gathered
     for k in tables:
