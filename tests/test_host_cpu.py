@@ -11,6 +11,15 @@ import numpy as np
 import pytest
 import torch
 
+
+
+def H_free_port():
+    """a TCP port nobody is listening on right now (fixed pid-derived ports collided with lingering sockets of earlier runs)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -150,7 +159,7 @@ print("OK", rank)
 def test_all_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    port = str(H_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -244,7 +253,7 @@ def test_reduce_scatter_gradient_exchange_equals_all_reduce_world_size_2_gloo(tm
     interchangeable through gathered_state_dict()."""
     script = tmp_path / "worker.py"
     script.write_text(EXCHANGE_WORKER)
-    port = str(31500 + os.getpid() % 2000)
+    port = str(H_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]

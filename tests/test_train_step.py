@@ -15,6 +15,15 @@ import torch
 import helpers as H
 from oracle import raymarch as rm
 
+
+
+def H_free_port():
+    """a TCP port nobody is listening on right now (fixed pid-derived ports collided with lingering sockets of earlier runs)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 CASES = [("train_step.npz", {}), ("train_step_sky.npz", dict(model_sky=True, brightness_correction=True))]
 CFG = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
                             anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
@@ -614,7 +623,7 @@ def test_ddp_training_step_two_ranks(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ddp_train_worker.py"
     script.write_text(DDP_TRAIN_WORKER)
-    port = str(33500 + os.getpid() % 2000)
+    port = str(H_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -692,7 +701,7 @@ def test_reduce_scatter_gradient_exchange_on_the_training_step_two_ranks(tmp_pat
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "sharded_worker.py"
     script.write_text(SHARDED_WORKER)
-    port = str(35500 + os.getpid() % 2000)
+    port = str(H_free_port())
     procs = [subprocess.Popen([sys.executable, str(script), repo, port, str(r)], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]

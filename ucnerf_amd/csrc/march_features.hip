@@ -465,7 +465,11 @@ __device__ __forceinline__ void level_scatter(const UcnLevel &lv, float *__restr
 // it splits back uniquely into (a, b) as long as each channel's FINAL sum fits int32.  That is guaranteed, not hoped for: the
 // addends of a sample are (w_k damp / 6) g_c with sum_k w_k = 1, damp <= 1, six points -- their absolute values sum to at most
 // |g_c|, so any row's |sum| <= L1 = sum over the task's samples of |g| (accumulated by the mask pass); the task scales its
-// gradients by the power of two that puts L1 at <= 2^30 (rounding adds <= 1/2 per addend, < 2^24 addends per task).  The
+// gradients by the power of two that puts L1 at <= 2^30.  Rounding adds <= 1/2 per addend and a task has <= 48 B addends per row at
+// the very worst (6 points x 8 corners of every one of its B <= 2^22 samples landing on ONE row): 2^30 + 24 x 2^22 < 2^30.1 < 2^31
+// (the host entry asserts exactly this inequality).  A non-finite gradient among the task's samples poisons the task's WHOLE row
+// block on that level with NaN (the float rows poison the touched rows only; after the reference's nan_to_num, train_utils.py:342,
+// both lose that step's gradient for those rows -- a superset here, never a silently dropped NaN).  The
 // accumulator type selects the mode: `float` rows (exact fp32 adds, the fp32 route and every test of it) or `FxLane` rows.
 struct FxLane { float raw; };                                  // same size as float: row / channel pointer arithmetic is shared
 template <typename A> constexpr bool kFixed = false;
@@ -1070,7 +1074,11 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
     if (b < 8) task_counter[b] = 0u;                      // the compacted kernel's persistent workgroups pull tasks from here
     __shared__ float s_l1[UCN_MAX_LEVELS][4];             // per level: the four waves' sums of max_c |g| (fixed-point bound)
     if ((threadIdx.x & 63u) < UCN_MAX_LEVELS) s_l1[threadIdx.x & 63u][threadIdx.x >> 6] = 0.0f;   // own column (a wave past the end leaves zeros)
-    if ((b & ~(size_t)63) >= B) return;                   // whole waves only: the bit planes below are built by wave ballots
+    // whole waves only (the bit planes below are built by wave ballots); a wave past the end skips the body but still reaches the
+    // barrier of the l1_partial reduction at the bottom (an early `return` left the barrier to part of the workgroup)
+    const bool live_wave = (b & ~(size_t)63) < B;
+    do {
+    if (!live_wave) break;
     const bool valid = b < B;
     const size_t bb = valid ? b : B - 1;                  // lanes past the end recompute the last sample and store nothing
     const uint32_t ray = (uint32_t)(bb / S), s = (uint32_t)(bb - (size_t)ray * S);
@@ -1178,6 +1186,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             }
         }
     }
+    } while (false);
     if (l1_partial) {
         __syncthreads();
         if (threadIdx.x < lvls.L)                           // fixed order: deterministic
@@ -1828,11 +1837,11 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
                 int x;
                 (void)frexpf(l1, &x);                                              // l1 = m 2^x, m in [0.5, 1): l1 <= 2^x
                 int e = 30 - x;
-                e = e > 120 ? 120 : (e < -96 ? -96 : e);
+                e = e > 120 ? 120 : (e < -100 ? -100 : e);                          // x <= 128 (l1 <= 3e38): e >= -98, never clamped from below
                 gscale = ldexpf(1.0f, e);
                 ginv = ldexpf(1.0f, -e);
             } else if (!(l1 <= 3.0e38f)) {
-                ginv = __builtin_nanf("");                                         // a non-finite gradient on this level: every row the task touches becomes NaN
+                ginv = __builtin_nanf("");                                         // a non-finite gradient on this level: every row of the task's block becomes NaN (flush below)
             }
         }
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale)
@@ -1865,7 +1874,7 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
             unsigned long long *words = reinterpret_cast<unsigned long long *>(s_acc);
             for (uint32_t i = threadIdx.x; i < nrows * C / 2u; i += 1024u) {
                 const unsigned long long w = words[i];
-                if (w != 0ull) {
+                if (w != 0ull || ginv != ginv) {                 // poisoned task: a NaN addend packs as 0, so untouched-looking rows are flushed too
                     words[i] = 0ull;
                     float a, b;
                     fixed_unpack(w, ginv, a, b);
@@ -2366,8 +2375,10 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     if (N == 0) return 0;
     const size_t B = (size_t)N * S;
     UCN_REQUIRE(B <= 0xFFFFFF00ull, "march_features_backward: too many samples in one call (%zu)", B);
-    // fixed-point row blocks pack channel PAIRS and bound a task by < 2^24 addends: C = 1 and huge calls keep float rows
+    // fixed-point row blocks pack channel PAIRS and bound a row's rounding slack by 24 B (48 B addends x 1/2) on top of the 2^30
+    // target: C = 1 and calls with 2^30 + 24 B >= 2^31 keep float rows
     const bool fixed = want_fixed && lv.C % 2u == 0u && B <= (1ull << 22);
+    static_assert((1ull << 30) + 24ull * (1ull << 22) < (1ull << 31), "fixed-point row blocks: int32 headroom");
     const RayInputs in{sdist, near_, far_, origins, directions, basis, radii, flip, spin};
     const HexPattern hx = make_hex();
     const GradStrides gs = grad_strides(layout, B, lv.L, lv.C);

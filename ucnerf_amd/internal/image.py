@@ -41,7 +41,11 @@ class MetricHarness:
         try:
             import lpips
             self._lpips = lpips.LPIPS(net="vgg")
-        except (ImportError, OSError):                      # package or weights absent: 'lpips' is reported as nan (key always present)
+        except Exception as e:                              # noqa: BLE001 -- package or weights absent, a corrupt / partial weight cache
+            # (RuntimeError / pickle errors from torch.load), version skew (AttributeError): 'lpips' is reported as nan, key always
+            # present (a narrower guard crashed eval.py / train.py at harness construction); the reason is logged once
+            import warnings
+            warnings.warn(f"MetricHarness: LPIPS unavailable ({type(e).__name__}: {e}); 'lpips' will be nan", stacklevel=2)
             self._lpips = None
 
     def __call__(self, rgb_pred, rgb_gt, name_fn=lambda s: s):
@@ -50,7 +54,8 @@ class MetricHarness:
         res[name_fn('lpips')] = float('nan')                  # the reference always returns the key (image.py:127-133)
         if self._lpips is not None:
             # image.py:119-120: the prediction is clipped before quantisation, the ground truth is quantised as it is
-            gt_ = ((torch.as_tensor(rgb_gt).float().cpu() * 255).to(torch.uint8).float() / 255).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
+            # (numpy's astype(uint8) wraps values >= 256 where torch's .to(uint8) is implementation-defined: wrap explicitly)
+            gt_ = (torch.remainder((torch.as_tensor(rgb_gt).float().cpu() * 255).trunc(), 256).to(torch.uint8).float() / 255).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
             pr_ = ((torch.as_tensor(rgb_pred).float().cpu().clamp(0, 1) * 255).to(torch.uint8).float() / 255).permute(2, 0, 1).unsqueeze(0) * 2 - 1.0
             res[name_fn('lpips')] = float(self._lpips(gt_, pr_).detach().item())
         return res
