@@ -88,30 +88,33 @@ __device__ __forceinline__ void gemm_store_direct(const f32x16 (&acc)[NT], const
 
 // Staged form (full tiles, 16-byte-aligned rows): a direct store instruction is 32 rows x two 16-byte pieces = 64 partial-line
 // requests; written to the wave's own LDS tile as [row][column] and read back row-contiguous, a store instruction covers whole
-// 128-byte lines (64 lanes x 16 B = 1 KiB of one or two rows) -- the K = 64 layer went from 1.4 to ~3 TB/s of stores.
-// SR rows per pass (the tile is SR x (NC + 4) floats), 32 / SR passes.
-template <uint32_t NT, uint32_t SR>
+// 128-byte lines -- the K = 64 layer went from 1.4 to ~3 TB/s of stores.  COLUMN blocks of 64 (two 32-column tiles) per pass (r05): every
+// lane writes its row's 8 quads of the block (8 full-width ds_write_b128), the wave reads 32 rows x 256 B back as 8 float4 per lane and
+// stores 4 rows x two whole lines per instruction.  (r04 / first r05 form: ROW blocks -- only the lanes of the pass's rows wrote, so a
+// tile cost 32 / SR x 4 NT quarter- or half-empty ds_write_b128: 128 per 32 x 256 tile at SR = 8, 40 % of the CU's LDS time.)
+// The tile is 32 x (64 + 4) floats = 8.5 KiB per wave.
+constexpr uint32_t kStageFloats = 32u * 68u;
+template <uint32_t NT>
 __device__ __forceinline__ void gemm_store_staged(const f32x16 (&acc)[NT], const GemmOut &o, float *tile, uint32_t m0, uint32_t n0,
                                                   uint32_t lane) {
-    constexpr uint32_t NC = NT * 32u, RS = NC + 4u;                // row stride in floats (+4: the rows of a write fall on 8 bank groups)
-    static_assert(SR * (NC / 4u) % 64u == 0u, "a pass is a whole number of wave-wide float4 reads");
+    static_assert(NT % 2u == 0u, "column blocks of two tiles");
+    constexpr uint32_t RS = 68u;                                   // row stride in floats (64 + 4: the rows of a write fall on different bank groups)
     const uint32_t i = lane & 31u, kk = lane >> 5;
 #pragma unroll
-    for (uint32_t pass = 0; pass < 32u / SR; pass++) {
-        if (i / SR == pass) {
+    for (uint32_t cb = 0; cb < NT / 2u; cb++) {
 #pragma unroll
-            for (uint32_t t = 0; t < NT; t++)
+        for (uint32_t t2 = 0; t2 < 2; t2++)
 #pragma unroll
-                for (uint32_t g = 0; g < 4; g++) {
-                    float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
-                    *reinterpret_cast<float4 *>(tile + (i % SR) * RS + 32u * t + 8u * g + 4u * kk) = v;
-                }
-        }
+            for (uint32_t g = 0; g < 4; g++) {
+                const f32x16 &a = acc[2u * cb + t2];
+                *reinterpret_cast<float4 *>(tile + i * RS + 32u * t2 + 8u * g + 4u * kk) =
+                    make_float4(a[4u * g], a[4u * g + 1u], a[4u * g + 2u], a[4u * g + 3u]);
+            }
         wave_lds_handoff();
 #pragma unroll
-        for (uint32_t u = 0; u < SR * (NC / 4u) / 64u; u++) {
-            const uint32_t f = lane + 64u * u, r = f / (NC / 4u), c4 = f % (NC / 4u);
-            const uint32_t ro = m0 + SR * pass + r, col = n0 + 4u * c4;
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t f = lane + 64u * u, r = f >> 4, c4 = f & 15u;
+            const uint32_t ro = m0 + r, col = n0 + 64u * cb + 4u * c4;
             float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
             if (ro < o.M) *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = gemm_finish(v, o, ro, col);
         }
@@ -260,22 +263,24 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__
             for (uint32_t p = 0; p < NP; p++) a_cur[r][p] = a_nxt[r][p];
         zero_tail(c + 1u, a_cur);
     }
-    // Full tiles with 16-byte-aligned rows go through LDS (the weight buffers are free after the last barrier), two passes of 16 rows
-    // per wave and row tile (16 rows x NC floats x 4 waves = the launch reserves max(weight buffers, 4 such tiles)).
+    // Full tiles with 16-byte-aligned rows go through LDS (the weight buffers are free after the last barrier; a wave's staging tile is
+    // 8.5 KiB, the launch reserves max(weight buffers, 4 such tiles)).
     // (the epilogue's bounds are made opaque HERE: its ~70 loop-invariant column / row predicates were hoisted above the chunk loop and
     // held in scalar registers across it -- 210 of them spilled into vector lanes, which the 64-row shape does not have to spare)
     GemmOut oe = o;
     asm volatile("" : "+s"(oe.N), "+s"(oe.M), "+s"(oe.flags));
     if constexpr (RT == 2u) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // inline-asm MFMAs: their result latency (16 passes) is not known to the hazard recogniser
     const bool staged = NT >= 2u && (oe.flags & kGemmVec) && n0 + NC <= oe.N;
-    float *tile = reinterpret_cast<float *>(s_w) + wave * 16u * (NC + 4u);
-    if constexpr (RT == 1u) {
-        if (staged) gemm_store_staged<NT, 16u>(acc[0], oe, tile, m0, n0, lane);
-        else gemm_store_direct<NT>(acc[0], oe, m0 + i, n0, kk);
-    } else {
-        if (staged) { gemm_store_staged<NT, 16u>(acc[0], oe, tile, m0, n0, lane); gemm_store_staged<NT, 16u>(acc[1], oe, tile, m0 + 32u, n0, lane); }
-        else { gemm_store_direct<NT>(acc[0], oe, m0 + i, n0, kk); gemm_store_direct<NT>(acc[1], oe, m0 + 32u + i, n0, kk); }
+    float *tile = reinterpret_cast<float *>(s_w) + wave * kStageFloats;
+    if constexpr (NT >= 2u) {
+        if (staged) {
+            gemm_store_staged<NT>(acc[0], oe, tile, m0, n0, lane);
+            if constexpr (RT == 2u) gemm_store_staged<NT>(acc[1], oe, tile, m0 + 32u, n0, lane);
+            return;
+        }
     }
+    gemm_store_direct<NT>(acc[0], oe, m0 + i, n0, kk);
+    if constexpr (RT == 2u) gemm_store_direct<NT>(acc[1], oe, m0 + 32u + i, n0, kk);
 }
 
 // ---- k_gemm_f32_res: the WHOLE weight resident in LDS, persistent waves (r05) -------------------------------------------------------
@@ -287,8 +292,8 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_f32(const float *__restrict__
 template <uint32_t NT, uint32_t PD>
 __global__ __launch_bounds__(512) void k_gemm_f32_res(const float *__restrict__ X, uint32_t ldx, const float *__restrict__ W, uint32_t ldw,
                                                       uint32_t K, GemmOut o) {
-    constexpr uint32_t NC = NT * 32u, QS = NC + 1u, SR = 8u;
-    extern __shared__ float4 s_w[];                                // [KQ quads][QS], then 8 staging tiles of SR x (NC + 4) floats
+    constexpr uint32_t NC = NT * 32u, QS = NC + 1u;
+    extern __shared__ float4 s_w[];                                // [KQ quads][QS], then 8 staging tiles of kStageFloats
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, kk = lane >> 5;
     const uint32_t nchunks = (K + 31u) / 32u, KQ = nchunks * 8u;
     for (uint32_t idx = threadIdx.x; idx < NC * KQ; idx += 512u) {
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(512) void k_gemm_f32_res(const float *__restrict__ 
         s_w[q * QS + n] = (n < o.N && 4u * q < K) ? *reinterpret_cast<const float4 *>(W + (size_t)n * ldw + 4u * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    float *tile = reinterpret_cast<float *>(s_w + KQ * QS) + wave * SR * (NC + 4u);
+    float *tile = reinterpret_cast<float *>(s_w + KQ * QS) + wave * kStageFloats;
     const uint32_t ntiles = (o.M + 31u) / 32u, gw = blockIdx.x * 8u + wave, GW = gridDim.x * 8u;
     float4 a[PD + 1u][4];
     uint32_t pt = gw, pc = 0;                                      // prefetch cursor: (tile, chunk)
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(512) void k_gemm_f32_res(const float *__restrict__ 
                 for (uint32_t p = 0; p < 4; p++) a[d][p] = a[d + 1u][p];
         }
         if constexpr (NT >= 2u) {
-            if ((o.flags & kGemmVec) && NC <= o.N) { gemm_store_staged<NT, SR>(acc, o, tile, m0, 0u, lane); continue; }
+            if ((o.flags & kGemmVec) && NC <= o.N) { gemm_store_staged<NT>(acc, o, tile, m0, 0u, lane); continue; }
         }
         gemm_store_direct<NT>(acc, o, m0 + i, 0u, kk);
     }
@@ -511,7 +516,7 @@ extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uin
     GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
     // whole weight resident (persistent waves) when it fits beside the staging tiles and there are tiles for every wave
     const uint32_t kq = ucn_div_up(K, 32) * 8u, nc = nt * 32u;
-    const size_t res_lds = (size_t)kq * (nc + 1u) * 16u + (nt >= 2u ? 8u * 8u * (nc + 4u) * 4u : 0u);
+    const size_t res_lds = (size_t)kq * (nc + 1u) * 16u + (nt >= 2u ? 8u * kStageFloats * 4u : 0u);
     const uint32_t ntiles = ucn_div_up(M, 32);
     static const bool no_res = getenv("UCN_GEMM_NO_RESIDENT") != nullptr;            // A/B switch (tools/gemm_f32_bench.py)
     if (N <= nc && res_lds <= 150u * 1024u && ntiles >= 64u && !no_res) {
@@ -533,7 +538,7 @@ extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uin
     // every LDS / barrier / first-touch bubble is exposed, which the vendor kernel avoids by hand-scheduled assembly.  Kept as the A/B.
     const uint32_t rt = (nt == 8u && variant == 2) ? 2u : 1u;
     const dim3 grid(ucn_div_up(M, 128u * rt), ucn_div_up(N, nt * 32u));
-#define UCN_LDS(NT, CQ) (2u * CQ * (NT * 32u + 1u) * 16u > 4u * 16u * (NT * 32u + 4u) * 4u ? 2u * CQ * (NT * 32u + 1u) * 16u : 4u * 16u * (NT * 32u + 4u) * 4u)
+#define UCN_LDS(NT, CQ) (2u * CQ * (NT * 32u + 1u) * 16u > 4u * kStageFloats * 4u ? 2u * CQ * (NT * 32u + 1u) * 16u : 4u * kStageFloats * 4u)
 #define UCN_G(NT, CQ, OCC, RT) hipLaunchKernelGGL((k_gemm_f32<NT, CQ, OCC, RT>), grid, dim3(256), UCN_LDS(NT, CQ), st, X, ldx, W, ldw, K, o)
     switch (nt) {
         case 1: UCN_G(1, 8, 2, 1); break;
