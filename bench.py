@@ -670,11 +670,11 @@ def main():
             gather["traffic_detail"] = live
         if live is None:
             try:
-                tj = json.load(open(os.path.join(REPO, "profiles", "r02c" if args.autocast else "r04", "traffic_autocast.json" if args.autocast else "traffic.json")))
+                tj = json.load(open(os.path.join(REPO, "profiles", "r02c" if args.autocast else "r05", "traffic_autocast.json" if args.autocast else "traffic.json")))
                 if abs(gather["rays_per_launch"] - tj["rays_per_launch"]) < 0.5 and (not args.autocast or model.autocast_bf16_features):
                     gather["traffic"] = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
                     gather["traffic_note"] = ("NOT live (rocprofv3 unavailable or a pass failed): bytes per launch from the committed rocprofv3 PMC "
-                                              "passes of this command (profiles/r04/traffic.json, profiles/r02c/traffic_autocast.json): FETCH_SIZE + WRITE_SIZE")
+                                              "passes of this command (profiles/r05/traffic.json, profiles/r02c/traffic_autocast.json): FETCH_SIZE + WRITE_SIZE")
             except (OSError, KeyError, ValueError):
                 pass
         split = model.nerf_mlp.mlp_mode == 1
