@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "mlp_ring.h"
+#include "wave_dpp.h"
 
 namespace {
 
@@ -67,13 +68,21 @@ __device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequen
 // P output tiles (a PAIR, or one) from NT_IN input tiles: acc[o2] += A(frag) . in[it][s], fragments [it][s][o2] from
 // stream position G0.  The two tiles of a pair alternate (two MFMAs into the same accumulator do not issue back to
 // back); only the pair's 32 accumulator registers are live, the caller converts / stores it before the next pair.
-template <int P, int NT_IN, int G0, class RING>
+// SC::before(G) = vector-memory STORE instructions the wave has issued (at least; since ring_start) before the MFMA of stream position G:
+// the ring's chunk boundaries then let exactly those that are younger than the awaited chunk stay in flight (Ring::boundary, EXTRA)
+struct NoStoreCount { static constexpr int before(int) { return 0; } };
+template <int P, int NT_IN, int G0, class SC = NoStoreCount, class RING>
 __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
         constexpr int CH = RING::kChunk, NW = RING::kWaves;     // a wave issues one DMA piece per NW fragments
-        if constexpr (G % CH == 0 && G / CH >= 1) ring.template boundary<G / CH>();
+        if constexpr (G % CH == 0 && G / CH >= 1) {
+            // the last piece of chunk G / CH was issued in front of the MFMA of position Gp (or by ring_start)
+            constexpr int c = G / CH, Gp = (c - RING::kLeadChunks) * CH + CH - NW;
+            constexpr int extra = SC::before(G) - (c >= RING::kLeadChunks ? SC::before(Gp) : 0);
+            ring.template boundary<c, extra>();
+        }
         if constexpr (G % NW == 0) ring.template piece<G / CH + RING::kLeadChunks, (G % CH) / NW>();
         acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
         // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
@@ -134,11 +143,44 @@ __device__ __forceinline__ void store_pair(uint16_t *__restrict__ dst, uint32_t 
     const auto p2x = __builtin_amdgcn_permlane32_swap(a1.x, b1.x, false, false), p2y = __builtin_amdgcn_permlane32_swap(a1.y, b1.y, false, false);
     const auto p3x = __builtin_amdgcn_permlane32_swap(a1.z, b1.z, false, false), p3y = __builtin_amdgcn_permlane32_swap(a1.w, b1.w, false, false);
     if (!live) return;
+#ifdef UCN_EXP_NOSTORE      // timing-only experiment build: what do the activation stores (and the waits they widen) cost?
+    return;
+#endif
     uint4 *p = reinterpret_cast<uint4 *>(dst + (size_t)sample * width + 32 * (tp + h));
     p[0] = make_uint4(p0x[0], p0y[0], p0x[1], p0y[1]);      // features 0-3 (lane j's piece 0), 4-7 (lane j + 32's piece 0)
     p[1] = make_uint4(p1x[0], p1y[0], p1x[1], p1y[1]);      // 8-11, 12-15
     p[2] = make_uint4(p2x[0], p2y[0], p2x[1], p2y[1]);      // 16-19, 20-23
     p[3] = make_uint4(p3x[0], p3y[0], p3x[1], p3y[1]);      // 24-27, 28-31
+}
+// ... and the same pair through the wave's own LDS tile (r05; kernels that run ONE workgroup per CU have the room): the per-lane form
+// above is 4 store instructions of 64 separate 16-byte requests each (a lane = a row), 256 texture-address cycles per pair and wave --
+// with four waves per CU as long as the pair's 32 MFMAs take, i.e. the training kernels were bound by the address unit, not by bytes
+// (without the stores the sky forward kernel runs 1.29 ms instead of 1.89).  Here a lane writes its eight 8-byte pieces to row j of a
+// [32][128 B + 16] tile (no lane swaps), the wave reads the tile back row-contiguous and stores 8 rows x one whole 128-byte line per
+// instruction: 8 requests instead of 64.  `sample0` = the wave's first sample, `n_rows` = how many of its 32 rows exist.
+constexpr int kStageRow = 144;                                       // bytes
+constexpr int kStageTile = 32 * kStageRow;                           // 4.5 KiB per wave
+__device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, uint16_t *__restrict__ dst, uint32_t width, uint32_t sample0,
+                                                  uint32_t n_rows, int tp, int lane, const bf8 (&t0)[2], const bf8 (&t1)[2]) {
+    const int j = lane & 31, h = lane >> 5;
+    wave_lds_handoff();                                               // the previous pair's reads are done
+    uint8_t *row = tile + j * kStageRow + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint4 lo = __builtin_bit_cast(uint4, t == 0 ? t0[0] : t1[0]), hi = __builtin_bit_cast(uint4, t == 0 ? t0[1] : t1[1]);
+        // bf8 [0] = features {0-3, 8-11} + 4h, [1] = {16-19, 24-27} + 4h of the tile: 8-byte pieces at byte 2 x feature
+        *reinterpret_cast<uint2 *>(row + 64 * t + 0) = make_uint2(lo.x, lo.y);
+        *reinterpret_cast<uint2 *>(row + 64 * t + 16) = make_uint2(lo.z, lo.w);
+        *reinterpret_cast<uint2 *>(row + 64 * t + 32) = make_uint2(hi.x, hi.y);
+        *reinterpret_cast<uint2 *>(row + 64 * t + 48) = make_uint2(hi.z, hi.w);
+    }
+    wave_lds_handoff();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = 8u * i + ((uint32_t)lane >> 3), c = (uint32_t)lane & 7u;
+        const uint4 v = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
+        if (r < n_rows) *reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c) = v;
+    }
 }
 template <bool PAIR>
 __device__ __forceinline__ void store_two(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h, const bf8 (&t0)[2],

@@ -187,8 +187,13 @@ struct Ring {
     __device__ __forceinline__ void issue_chunk() {
         rstatic_for<kPiecesPerChunk>([&](auto i) { piece<C, i.value>(); });
     }
-    // first read of chunk C: everything up to and including chunk C has landed for every wave
-    template <int C>
+    // first read of chunk C: everything up to and including chunk C has landed for every wave.
+    // EXTRA (r05): vector-memory instructions OTHER than this ring's DMA that the wave is known to have issued AFTER the last piece of
+    // chunk C (activation stores of a training kernel).  vmcnt counts stores too and retires in issue order, so "chunk C has landed"
+    // is "at most (later pieces + EXTRA) operations outstanding".  Without it the wait also drains those stores -- each a ~1 us
+    // round trip to L2 -- at every chunk boundary (every ~0.2 us): the sky training kernels spent their whole duration there.  A LOWER
+    // bound is safe (a smaller count only waits longer); the counter is 6 bits.
+    template <int C, int EXTRA = 0>
     __device__ __forceinline__ void boundary() {
         // DMA instructions of this wave that may still be in flight: those of the chunks behind C that have been
         // issued so far, i.e. chunks C+1 .. C+kLead-1 (chunk C+kLead is issued while C is read)
@@ -202,7 +207,8 @@ struct Ring {
             static_assert(STAGE <= (LEAD - 1) * kPiecesPerChunk, "staged pieces would be written after they are needed");
             if constexpr (C == 0) ring_wait_lds<0>();
         } else {
-            ring_wait_vm<later * kPiecesPerChunk>();
+            constexpr int allowed = later * kPiecesPerChunk + (EXTRA > 0 ? EXTRA : 0);
+            ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
         }
         // bare barrier: __syncthreads() adds a fence whose lgkmcnt(0) would drain the operand pipe.  LDS is coherent
         // within the CU and every wave has waited for its own DMA; the slot being refilled was last read a chunk ago.

@@ -27,7 +27,42 @@ namespace {
 
 constexpr int kTrFrags = 984;                                           // fragments of either stream
 constexpr int kTrPadded = (kTrFrags + kTChunk - 1) / kTChunk * kTChunk; // 992
-using STRing = Ring<kTrPadded, kTChunk, 4, kTSlots, kTLead>;
+// ring geometry per kernel (slots x 16 KiB, chunks requested LEAD ahead): the field kernels' 4 x 16 KiB / 2 ahead is cut for two
+// workgroups per CU; UCN_SKY_{FWD,BWD}_{SLOTS,LEAD} are build knobs (tools/build_variant.sh)
+#ifndef UCN_SKY_FWD_SLOTS
+#define UCN_SKY_FWD_SLOTS 6
+#endif
+#ifndef UCN_SKY_FWD_LEAD
+#define UCN_SKY_FWD_LEAD 4
+#endif
+#ifndef UCN_SKY_BWD_SLOTS
+#define UCN_SKY_BWD_SLOTS kTSlots
+#endif
+#ifndef UCN_SKY_BWD_LEAD
+#define UCN_SKY_BWD_LEAD kTLead
+#endif
+constexpr int kFwdSlots = UCN_SKY_FWD_SLOTS, kBwdSlots = UCN_SKY_BWD_SLOTS;
+static_assert(UCN_SKY_FWD_SLOTS >= UCN_SKY_FWD_LEAD + 2 && UCN_SKY_BWD_SLOTS >= UCN_SKY_BWD_LEAD + 2, "a chunk is refilled two boundaries after its last reader");
+// UCN_SKY_{FWD,BWD}_STAGE: 0 = the weight stream reaches LDS by LDS-DMA (global_load_lds), n > 0 = by plain 16-byte loads into n staging
+// registers per lane and ds_write_b128 n pieces later (mlp_ring.h)
+#ifndef UCN_SKY_FWD_STAGE
+#define UCN_SKY_FWD_STAGE 0
+#endif
+#ifndef UCN_SKY_BWD_STAGE
+#define UCN_SKY_BWD_STAGE 0
+#endif
+#ifndef UCN_SKY_FWD_WAVES
+#define UCN_SKY_FWD_WAVES 4
+#endif
+constexpr int kFwdWaves = UCN_SKY_FWD_WAVES;
+using STRing = Ring<kTrPadded, kTChunk, UCN_SKY_FWD_WAVES, UCN_SKY_FWD_SLOTS, UCN_SKY_FWD_LEAD, UCN_SKY_FWD_STAGE>;
+// waves per workgroup of the backward kernel: 8 waves share ONE weight ring, so the LDS-DMA stream (the whole 1 MB of fragments per
+// pass; ~25 GB/s per CU is what the DMA path lands) is paid once per 256 samples instead of once per 128
+#ifndef UCN_SKY_BWD_WAVES
+#define UCN_SKY_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = UCN_SKY_BWD_WAVES;
+using SBRing = Ring<kTrPadded, kTChunk, UCN_SKY_BWD_WAVES, UCN_SKY_BWD_SLOTS, UCN_SKY_BWD_LEAD, UCN_SKY_BWD_STAGE>;
 // forward stream positions (A-fragments [otp][it][s][o2]): pts_linears 1..4, 5 (9 input tiles), 6, 7, views (9 tiles)
 constexpr int kFL[7] = {0, 128, 256, 384, 512, 656, 784};
 constexpr int kFV = 912;
@@ -55,20 +90,52 @@ struct SkyTrainArgs {
 // sky_far = 1.5 * near[0] with near = batch.far (models.py:328-330), read on the device: no host sync in the step
 __device__ __forceinline__ float inv_sky_far_of(const float *far_) { return 1.0f / (1.5f * far_[0]); }
 
+// activation stores of the forward kernel in stream order: every output PAIR of a hidden layer ends with store_pair = 4 global stores
+// (layers 1..7: four pairs each at kFL[li] + (pr + 1) * 4 NT_IN; views layer: two pairs of 36 fragments).  Layer 0's stores and the
+// per-layer mask stores are not counted (a lower bound is safe, see Ring::boundary).
+struct FwdStores {
+    static constexpr int before(int G) {
+        int n = 0;
+        for (int li = 0; li < 7; li++) {
+            const int nt = li == 4 ? 9 : 8;
+            for (int pr = 0; pr < 4; pr++) n += (kFL[li] + (pr + 1) * nt * 4 <= G) ? 4 : 0;
+        }
+        for (int pr = 0; pr < 2; pr++) n += (kFV + (pr + 1) * 36 <= G) ? 4 : 0;
+        return n;
+    }
+};
+
 template <int P>
 __device__ __forceinline__ bf8 (&pick9(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
     if constexpr (P == 0) return a;
     else return b;
 }
 
-__global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring (64 KiB) + side table (14 KiB)
-    const float *side = s_w + kTSlots * kTChunk * 256;
+// UCN_SKY_FWD_OCC: workgroups per CU the register budget of the forward kernel is cut for (build knob, tools/build_variant.sh).
+// r05: ONE.  At two per CU (256 registers) the kernel spilled 190 registers to scratch (in + out activation tiles 136, a pair's
+// accumulators 32, the store's lane-swap temporaries 32, ring + geometry ~30), and every scratch reload made the compiler put
+// `s_waitcnt vmcnt(0)` in front of it (96 inside the chain) -- each draining the weight stream's look-ahead: 2.39 ms.  One workgroup
+// per CU with the whole register file: no scratch, 1.89 ms; + a 6-slot ring requested 4 chunks ahead, the chunk waits counting the
+// activation stores that are younger than the awaited chunk (Ring::boundary EXTRA), and the pairs stored through LDS as whole lines
+// (store_pair_staged): 1.79 ms (profiles/r05/sky_train_variants.txt).  Measured and NOT kept: an 8-slot ring 6 ahead (1.83), a
+// per-layer [M, 256] activation layout (1.79: DRAM page locality is not it), 8-wave workgroups sharing one ring in the backward
+// (2.06 against 1.81), the register-staged weight stream instead of LDS-DMA (2.8).  Without its activation stores the kernel takes
+// 1.29 ms, and its counters (profiles/r05/pmc_sky.txt) show the texture-data path busy 99 % of the duration at 18 % MFMA-busy: the
+// LDS-DMA weight stream (1 MB per 128 samples; ~25 GB/s per CU is what that path lands) shares it with the stores.
+#ifndef UCN_SKY_FWD_OCC
+#define UCN_SKY_FWD_OCC 1
+#endif
+__global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 : UCN_SKY_FWD_OCC) void k_sky_train_fwd(SkyTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring + side table (14 KiB) [+ 4 staging tiles]
+    const float *side = s_w + kFwdSlots * kTChunk * 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const uint32_t M = a.N * (uint32_t)kSkySamples;
-    const uint32_t b0 = (blockIdx.x * 4u + wave) * 32u;
+    const uint32_t b0 = (blockIdx.x * (uint32_t)kFwdWaves + wave) * 32u;
+    constexpr bool kStaged = UCN_SKY_FWD_OCC == 1;                 // one workgroup per CU: the activation pairs leave through LDS (bf_tiles.h)
+    uint8_t *stage = reinterpret_cast<uint8_t *>(s_w + kFwdSlots * kTChunk * 256 + kSideFloats) + wave * kStageTile;
+    const uint32_t n_rows = b0 < M ? (M - b0 < 32u ? M - b0 : 32u) : 0u;
     const bool live = b0 + j < M;
     const uint32_t b = live ? b0 + j : M - 1;
     const uint32_t ray = b / kSkySamples, s = b - ray * kSkySamples;
@@ -99,11 +166,11 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
 
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
-        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kTSlots * kTChunk) * 1024u;
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
         const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int piece = k * 4 + wave;
+        for (int k = 0; k < (kSideFloats / 256 + kFwdWaves - 1) / kFwdWaves; k++) {
+            const int piece = k * kFwdWaves + wave;
             if (piece < kSideFloats / 256)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                              :
@@ -130,7 +197,14 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
             XA[t][1] = to_b(acc, 1, true);
             if (t % 2 == 0) mk[t / 2] = mask16(acc);
             else mk[t / 2] |= mask16(acc) << 16;
-            if (t % 2 == 1) store_two<true>(row, kActLd, b, t - 1, h, XA[t - 1], XA[t], live);
+            if (t % 2 == 1) {
+#ifdef UCN_EXP_COMPACT_ACT
+                if constexpr (kStaged) store_pair_staged(stage, row, 256, b0, n_rows, t - 1, lane, XA[t - 1], XA[t]);
+#else
+                if constexpr (kStaged) store_pair_staged(stage, row, kActLd, b0, n_rows, t - 1, lane, XA[t - 1], XA[t]);
+#endif
+                else store_two<true>(row, kActLd, b, t - 1, h, XA[t - 1], XA[t], live);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (live) a.mask[((size_t)0 * M + b) * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -153,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
                 zero_acc(cur[0]);
                 zero_acc(cur[1]);
             }
-            tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4, FwdStores>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
             if constexpr (li == 6) {                              // alpha head on the fp32 ReLU output of layer 7
                 alpha_partial<2 * pr, 0>(cur[0], pa, sig);
                 alpha_partial<2 * pr, 1>(cur[0], pa, sig);
@@ -166,7 +240,12 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
                 out[2 * pr + o][1] = to_b(cur[o], 1, true);
             }
             mk[pr] = mask16(cur[0]) | (mask16(cur[1]) << 16);
-            store_two<true>(row + (li + 1) * kActBlock, kActLd, b, 2 * pr, h, out[2 * pr], out[2 * pr + 1], live);
+#ifdef UCN_EXP_COMPACT_ACT   // timing-only experiment: every layer its own [M, 256] matrix (the host still reads the interleaved layout: results garbage)
+            if constexpr (kStaged) store_pair_staged(stage, row + (size_t)(li + 1) * M * 256, 256, b0, n_rows, 2 * pr, lane, out[2 * pr], out[2 * pr + 1]);
+#else
+            if constexpr (kStaged) store_pair_staged(stage, row + (li + 1) * kActBlock, kActLd, b0, n_rows, 2 * pr, lane, out[2 * pr], out[2 * pr + 1]);
+#endif
+            else store_two<true>(row + (li + 1) * kActBlock, kActLd, b, 2 * pr, h, out[2 * pr], out[2 * pr + 1], live);
             // a pair's epilogue (conversion, mask, store) is finished before the next pair's chain starts: left to itself the
             // scheduler carries accumulators and store operands across (588 bytes of scratch per lane at the 256-register cap)
             __builtin_amdgcn_sched_barrier(0);
@@ -184,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
         f32x16 v[2];
         zero_acc(v[0]);
         zero_acc(v[1]);
-        tile_pair<2, 9, kFV + pr * 36>(ring, v, h7);
+        tile_pair<2, 9, kFV + pr * 36, FwdStores>(ring, v, h7);
         bf8 hv[2][2];
 #pragma unroll
         for (int o = 0; o < 2; o++) {
@@ -199,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void k_sky_train_fwd(SkyTrainArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         mkv[pr] = mask16(v[0]) | (mask16(v[1]) << 16);
-        store_two<true>(row + kActHv, kActLd, b, 2 * pr, h, hv[0], hv[1], live);
+        if constexpr (kStaged) store_pair_staged(stage, row + kActHv, kActLd, b0, n_rows, 2 * pr, lane, hv[0], hv[1]);
+        else store_two<true>(row + kActHv, kActLd, b, 2 * pr, h, hv[0], hv[1], live);
     });
     if (live) a.mask_v[(size_t)b * 2 + h] = make_uint2(mkv[0], mkv[1]);
     c0 = xor32_sum(c0); c1 = xor32_sum(c1); c2 = xor32_sum(c2);
@@ -223,15 +303,18 @@ __device__ __forceinline__ bf8 (&pick8(bf8 (&a)[8][2], bf8 (&b)[8][2]))[8][2] {
     else return b;
 }
 
-__global__ __launch_bounds__(256, 2) void k_sky_train_bwd(SkyTrainBwdArgs a) {
+#ifndef UCN_SKY_BWD_OCC
+#define UCN_SKY_BWD_OCC 2
+#endif
+__global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 : UCN_SKY_BWD_OCC) void k_sky_train_bwd(SkyTrainBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
+    const uint32_t s0 = (blockIdx.x * (uint32_t)kBwdWaves + wave) * 32u + j;
     const bool live = s0 < a.M;
     const uint32_t b = live ? s0 : a.M - 1;
-    STRing ring(reinterpret_cast<const float *>(a.packed + kPkBwd), s_w, lane, wave);
+    SBRing ring(reinterpret_cast<const float *>(a.packed + kPkBwd), s_w, lane, wave);
     ring_start(ring);
     // ---- the head gradients as one input tile: columns 0..3 = d logits (r, g, b), d sigma -- registers 0..3 of wave half 0
     //      in accumulator order and in natural order alike
@@ -475,8 +558,8 @@ extern "C" int ucn_sky_train_fwd(const void *packed, const float *origins, const
     SkyTrainArgs a{reinterpret_cast<const uint8_t *>(packed), aux_ws, origins, directions, far_, t_vals, N, raw,
                    reinterpret_cast<uint16_t *>(act), reinterpret_cast<uint4 *>(mask), reinterpret_cast<uint2 *>(mask_v)};
     const uint64_t M = (uint64_t)N * kSkySamples;
-    const size_t lds = ((size_t)kTSlots * kTChunk * 256 + kSideFloats) * sizeof(float);
-    hipLaunchKernelGGL(k_sky_train_fwd, dim3(ucn_div_up(M, 128)), dim3(256), lds, st, a);
+    const size_t lds = ((size_t)kFwdSlots * kTChunk * 256 + kSideFloats) * sizeof(float) + (UCN_SKY_FWD_OCC == 1 ? kFwdWaves * kStageTile : 0);
+    hipLaunchKernelGGL(k_sky_train_fwd, dim3(ucn_div_up(M, 32 * kFwdWaves)), dim3(64 * kFwdWaves), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite_dev, dim3(ucn_div_up(N, 64)), dim3(64), 0, st, raw, directions, far_, t_vals, N, sky_rgb_out);
     UCN_LAUNCH_CHECK("sky_train_fwd");
     return 0;
@@ -494,7 +577,7 @@ extern "C" int ucn_sky_train_bwd(const void *packed, const float *g_sky_rgb, con
                        g_raw_ws);
     SkyTrainBwdArgs a{reinterpret_cast<const uint8_t *>(packed), g_raw_ws, reinterpret_cast<const uint4 *>(mask),
                       reinterpret_cast<const uint2 *>(mask_v), reinterpret_cast<uint16_t *>(grad), (uint32_t)M};
-    hipLaunchKernelGGL(k_sky_train_bwd, dim3(ucn_div_up(M, 128)), dim3(256), (size_t)kTSlots * kTChunk * 1024, st, a);
+    hipLaunchKernelGGL(k_sky_train_bwd, dim3(ucn_div_up(M, 32 * kBwdWaves)), dim3(64 * kBwdWaves), (size_t)kBwdSlots * kTChunk * 1024, st, a);
     UCN_LAUNCH_CHECK("sky_train_bwd");
     return 0;
 }
