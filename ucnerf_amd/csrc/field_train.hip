@@ -83,8 +83,19 @@ static_assert(IRing::kChunks * IRing::kChunk <= kFwdPadded, "the packed forward 
 template <bool AUX> struct FwdShape { using ring = FRing; static constexpr int waves = 4, wgs = UCN_TRAIN_FWD_WGS; };
 template <> struct FwdShape<true> { using ring = IRing; static constexpr int waves = kInferWaves, wgs = kInferWaves == 4 ? 2 : 1; };
 
-template <int NTF, bool AUX = false>   // feature tiles: F <= 32 * NTF
+// SIDE (r05, training form): the layer biases and the wave's two per-ray rows (pr0 / pr1: all 32 samples of a wave belong to one ray
+// when S % 32 == 0) are copied to LDS ONCE, before the chain, and every pair's accumulator start comes from there.  As global loads
+// inside the chain (r02-r04) each of the 12 pair starts carried a compiler-inserted `s_waitcnt vmcnt(0)` in front of its first MFMA
+// -- the compiler cannot see the hand-placed LDS-DMA stream, so its wait drained the whole weight look-ahead, twelve times per pass.
+#ifndef UCN_TRAIN_FWD_SIDE
+#define UCN_TRAIN_FWD_SIDE 1
+#endif
+constexpr int kSideBias = 16 + 64, kSideWave = 128;                    // float4: [bias_d0 (16) | bias_d1 (64)], then per wave [pr0 (64) | pr1 (64)]
+constexpr size_t kFwdSideBytes = (size_t)(kSideBias + 4 * kSideWave) * 16;
+
+template <int NTF, bool AUX = false, bool SIDE = false>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void k_train_fwd(TrainFwdArgs aa) {
+    static_assert(!(AUX && SIDE), "the side table is the training form's");
     TrainFwdArgs a = aa;
     if constexpr (AUX) a.store = 0;
     else a.level_dim = 0;                 // the training form reads sample-major features (checked by the entry point)
@@ -99,6 +110,22 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
     typename FwdShape<AUX>::ring ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
     ring_start(ring);
+    const float *side_b0 = nullptr, *side_b1 = nullptr, *side_p0 = nullptr, *side_p1 = nullptr;
+    if constexpr (SIDE) {
+        float4 *side = reinterpret_cast<float4 *>(s_w + kTSlots * kTChunk * 256);
+        if (threadIdx.x < 16) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d0)[threadIdx.x];
+        else if (threadIdx.x < (uint32_t)kSideBias) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d1)[threadIdx.x - 16];
+        const uint32_t w0 = (blockIdx.x * 4u + wave) * 32u;                                     // the wave's first sample: its ray is every lane's
+        const uint32_t wray = (w0 < a.M ? w0 : a.M - 1) / a.S;
+        float4 *wp = side + kSideBias + wave * kSideWave;
+        wp[lane] = reinterpret_cast<const float4 *>(a.pr0)[(size_t)wray * 64 + lane];
+        wp[64 + lane] = reinterpret_cast<const float4 *>(a.pr1)[(size_t)wray * 64 + lane];
+        ring_wait_lds<0>();                                                                     // written before boundary<0>'s barrier
+        side_b0 = reinterpret_cast<const float *>(side);
+        side_b1 = side_b0 + 64;
+        side_p0 = reinterpret_cast<const float *>(wp);
+        side_p1 = side_p0 + 256;
+    }
 
     // ---- features: lane (j, h) supplies k = 16 s + 8 h + e of its sample
     bf8 fin[NTF][2];
@@ -162,8 +189,8 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     }
     {
         f32x16 a0[2];
-        load_acc(a.bias_d0 + (0 * 2 + h) * 16, a0[0]);
-        load_acc(a.bias_d0 + (1 * 2 + h) * 16, a0[1]);
+        load_acc((SIDE ? side_b0 : a.bias_d0) + (0 * 2 + h) * 16, a0[0]);
+        load_acc((SIDE ? side_b0 : a.bias_d0) + (1 * 2 + h) * 16, a0[1]);
         tile_pair<2, NTF, 0>(ring, a0, fin);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -178,8 +205,8 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     sfor<4>([&](auto pp) {
         constexpr int p = pp.value;
         f32x16 acc[2];
-        load_acc(a.bias_d1 + ((2 * p) * 2 + h) * 16, acc[0]);
-        load_acc(a.bias_d1 + ((2 * p + 1) * 2 + h) * 16, acc[1]);
+        load_acc((SIDE ? side_b1 : a.bias_d1) + ((2 * p) * 2 + h) * 16, acc[0]);
+        load_acc((SIDE ? side_b1 : a.bias_d1) + ((2 * p + 1) * 2 + h) * 16, acc[1]);
         tile_pair<2, 2, G1 + 8 * p>(ring, acc, h0);
         bf8 xp[2][2];
 #pragma unroll
@@ -207,8 +234,13 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                 zero_acc(acc[0]);
                 zero_acc(acc[1]);
             } else {
-                load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
-                load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+                if constexpr (SIDE) {
+                    load_acc(side_p0 + (2 * p) * 32 + h * 16, acc[0]);
+                    load_acc(side_p0 + (2 * p + 1) * 32 + h * 16, acc[1]);
+                } else {
+                    load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+                    load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+                }
             }
             tile_pair<2, 2 + NA, G2 + P2 * p>(ring, acc, reinterpret_cast<const bf8(&)[2 + NA][2]>(hin[8]));
 #pragma unroll
@@ -232,8 +264,13 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                 zero_acc(acc[0]);
                 zero_acc(acc[1]);
             } else {
-                load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
-                load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+                if constexpr (SIDE) {
+                    load_acc(side_p1 + (2 * p) * 32 + h * 16, acc[0]);
+                    load_acc(side_p1 + (2 * p + 1) * 32 + h * 16, acc[1]);
+                } else {
+                    load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p) * 32 + h * 16, acc[0]);
+                    load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
+                }
             }
             tile_pair<2, 10 + NA, G3 + (P3 + 4) * p>(ring, acc, hin);
             bf8 hp[2][2];
@@ -319,6 +356,15 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
     }
     const uint4 mk2 = a.m2[(size_t)sample * 2 + h], mk1 = a.m1[(size_t)sample * 2 + h];
     const uint32_t mk0 = a.m0[(size_t)sample * 2 + h];
+    // the density head's gradient, fetched HERE with the masks (r05): as a global load in the middle of the chain it carried a
+    // compiler-inserted `s_waitcnt vmcnt(0)` that drained the weight stream's look-ahead (the compiler cannot see the LDS-DMA)
+    float gr_head = 0.0f;
+    if (a.graw && h == 0) {
+        // head: d softplus(z) / dz = sigmoid(z) = -expm1(-softplus(z)) (no cancellation in empty space), from the saved density; rounded to bf16 like
+        // the gradient the per-layer path hands to the bottleneck's GEMM
+        if (a.head) gr_head = (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (-expm1f(-a.density[sample])));
+        else gr_head = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+    }
     const uint32_t m2w[4] = {mk2.x, mk2.y, mk2.z, mk2.w}, m1w[4] = {mk1.x, mk1.y, mk1.z, mk1.w};
     ring.template boundary<0>();
     // stream positions: Wr^T: 4 pairs x 4 | W1h^T: 4 pairs x 32 | 4 x ([W1x^T | W0x^T] pair: 64, then Wd1^T's fragments for the
@@ -368,11 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         tile_pair<2, 16, H2 + 72 * p>(ring, acc, din);
         if constexpr (p == 0) {
             if (a.graw && h == 0) {
-                // head: d softplus(z) / dz = sigmoid(z) = -expm1(-softplus(z)) (no cancellation in empty space), from the saved density; rounded to bf16 like
-                // the gradient the per-layer path hands to the bottleneck's GEMM
-                float gr;
-                if (a.head) gr = (float)(__bf16)(reinterpret_cast<const float *>(a.graw)[sample] * (-expm1f(-a.density[sample])));
-                else gr = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(a.graw)[sample] << 16);
+                const float gr = gr_head;
                 acc[0][0] += gr;
                 // (r04) the density head's gradient at the bottleneck's feature 0, kept as column 3 of dy: with gx not stored the
                 // host forms its share of d W_d1[0, :] and d b_d1[0] from dy[:, 3]^T h0 (wave half 0 holds feature 0 of its sample in register 0 of tile 0)
@@ -458,6 +500,10 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
         const size_t ilds = (size_t)IRing::kSlots * IRing::kChunk * 1024;
         if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((k_train_fwd<2, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
+    } else if (UCN_TRAIN_FWD_SIDE && S % 32u == 0u && (((uintptr_t)bias_d0 | (uintptr_t)bias_d1 | (uintptr_t)pr0 | (uintptr_t)pr1) & 15u) == 0u) {
+        // a wave's 32 samples are one ray's: biases + the wave's per-ray rows from an LDS side table (see k_train_fwd, SIDE)
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false, true>), grid, dim3(256), lds + kFwdSideBytes, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false, true>), grid, dim3(256), lds + kFwdSideBytes, (hipStream_t)stream, a);
     } else {
         if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
