@@ -338,6 +338,13 @@ __global__ __launch_bounds__(256) void k_field_mlp_h(MlpArgs a) {
     if constexpr (STAGE > 0) ring.drain();          // the side table came by DMA
     ring.template boundary<0>();                    // side table + chunk 0 landed (the later chunks stay in flight)
     UCN_STAMP(1);
+    if constexpr (RGB) {
+        // (r05) the direction tile's loads are PINNED as landed here, at the top where the stream is only just starting: left to the compiler
+        // their wait sits in front of the tile's first use, behind the density stage -- a `s_waitcnt vmcnt(3..0)` that, counted against a
+        // hardware counter full of LDS-DMA pieces the compiler cannot see, drained the whole weight look-ahead once per pass
+#pragma unroll
+        for (int r = 0; r < 16; r++) asm volatile("" : "+v"(ev[r]));
+    }
     const float in_scale = side[129];
 
     // ---- density layer 0: F -> 64, ReLU (accumulators start from the bias tiles)
@@ -516,6 +523,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void k_field_mlp_h8(MlpArgs a) {
     UCN_STAMP8(1);
     ring.template boundary<0>();
     UCN_STAMP8(2);
+    // (r05) the direction tile's loads are PINNED as landed here, at the top where the stream is only just starting: left to the compiler
+    // their wait sits in front of the tile's first use, behind the density stage -- a `s_waitcnt vmcnt(3..0)` that, counted against a
+    // hardware counter full of LDS-DMA pieces the compiler cannot see, drained the whole weight look-ahead once per pass
+#pragma unroll
+    for (int r = 0; r < 16; r++) asm volatile("" : "+v"(ev[r]));
     const float in_scale = side[129];
 
     f32x16 acc[2];
