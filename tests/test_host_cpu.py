@@ -191,7 +191,12 @@ class Field(torch.nn.Module):
 def run(mode):
     torch.manual_seed(0)
     model = Field()
+    if rank == 1:                                                    # a rank that starts from other weights: wrapping must bring rank 0's
+        with torch.no_grad():
+            model.table.add_(1.0); model.lin.weight.add_(1.0)
     ddp = ud.wrap_ddp(model, grad_exchange=mode, shard_min_numel=1024)
+    ref = Field()
+    assert torch.equal(model.table, ref.table) and torch.equal(model.lin.weight, ref.lin.weight), "the state of rank 0 was not broadcast"
     assert ddp.grad_exchange == mode
     params = list(model.parameters())
     sharded = [p for p in params if getattr(p, "_ucn_sharded", False)]

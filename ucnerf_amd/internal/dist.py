@@ -91,6 +91,10 @@ def wrap_ddp(model, device_ids=None, grad_exchange="all_reduce", shard_min_numel
         sharded = sharded_parameters(model, world, shard_min_numel)
         for _, p in sharded:
             p._ucn_sharded = True
+            # DDP broadcasts rank 0's module state at construction -- but not what it is told to ignore: keep its "every rank starts
+            # from rank 0's weights" guarantee for the tables too (one broadcast per table, once)
+            dist.broadcast(p.data, src=dist.get_global_rank(opts["process_group"], 0) if opts.get("process_group") is not None else 0,
+                           group=opts.get("process_group"))
         DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [n for n, _ in sharded])
     ddp = DistributedDataParallel(model, device_ids=device_ids, **opts)
     ddp.grad_exchange = grad_exchange
