@@ -519,19 +519,34 @@ __device__ __forceinline__ void lds_row_add(A *acc_, uint32_t r, const float (&v
 // several consecutive samples (the compacted kernel) keeps merging across them.
 // (A rows-only pre-pass that drops samples without a corner in this block was tried: with 64 lanes per wave
 //  some lane almost always stays, so the wave pays the pre-pass AND the full path -- 25 % slower.)
+// C > 2 (r05; the reference's own waymo.gin grid is C = 4): the run keeps ONE summed corner weight per row instead of C values -- 16
+// registers of state instead of 8 + 8 C -- and is flushed at the end of every sample with that sample's gradient (v = weight x g), so
+// it no longer merges ACROSS samples.  With v[8][4] the kernel's 128-register budget (1024 threads) did not hold a run, the next item's
+// prefetched geometry and a point's corner arithmetic together: the C = 4 instantiation spilled 405 registers, 500 of its 1561 scratch
+// accesses in run_flush alone, inside the item loops of every coarse level (the whole proposal grid of waymo.gin).
 template <uint32_t C>
 struct RowRun {
+    static constexpr bool kLean = C > 2;
     uint32_t cur[8];
-    float v[8][C];
+    float v[8][kLean ? 1 : C];
     bool have;
 };
 
 template <uint32_t C, typename A>
-__device__ __forceinline__ void run_flush(A *__restrict__ acc, uint32_t row_lo, uint32_t nrows, const RowRun<C> &run) {
+__device__ __forceinline__ void run_flush(A *__restrict__ acc, uint32_t row_lo, uint32_t nrows, const RowRun<C> &run, const float (&gout)[C]) {
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
         const uint32_t r = run.cur[k] - row_lo;
-        if (r < nrows) lds_row_add<C, false>(acc, r, run.v[k]);
+        if (r < nrows) {
+            if constexpr (RowRun<C>::kLean) {
+                float val[C];
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) val[c] = run.v[k][0] * gout[c];
+                lds_row_add<C, false>(acc, r, val);
+            } else {
+                lds_row_add<C, false>(acc, r, run.v[k]);
+            }
+        }
     }
 }
 
@@ -550,16 +565,24 @@ __device__ __forceinline__ void run_merge_sample(const UcnLevel &lv, A *__restri
             bool same = run.have;
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) same = same && rows[k] == run.cur[k];
-            if (run.have && !same) run_flush<C>(acc, row_lo, nrows, run);
+            if (run.have && !same) run_flush<C>(acc, row_lo, nrows, run, gout);
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
                 const float wd = w[k] * damp;
+                if constexpr (RowRun<C>::kLean) {
+                    run.v[k][0] = same ? run.v[k][0] + wd : wd;
+                } else {
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) run.v[k][c] = same ? run.v[k][c] + wd * gout[c] : wd * gout[c];
+                    for (uint32_t c = 0; c < C; c++) run.v[k][c] = same ? run.v[k][c] + wd * gout[c] : wd * gout[c];
+                }
                 run.cur[k] = rows[k];
             }
             run.have = true;
         }
+    }
+    if constexpr (RowRun<C>::kLean) {                                 // the run's weights belong to THIS sample's gradient
+        if (run.have) run_flush<C>(acc, row_lo, nrows, run, gout);
+        run.have = false;
     }
 }
 
@@ -573,7 +596,7 @@ __device__ __forceinline__ void level_scatter_block(const UcnLevel &lv, A *__res
         RowRun<C> run;
         run.have = false;
         run_merge_sample<C, HASHED, POW2>(lv, acc, row_lo, nrows, u, rs, gout, run);
-        if (run.have) run_flush<C>(acc, row_lo, nrows, run);
+        if (run.have) run_flush<C>(acc, row_lo, nrows, run, gout);
         return;
     }
 #pragma unroll
@@ -1499,7 +1522,9 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, A *__restrict__ s_
                 // across them; the next item's geometry is requested before the current one is scattered
                 RowRun<C> run;
                 run.have = false;
-                float un[6][3], rsn[6], gn[C];
+                float un[6][3], rsn[6], gn[C], glast[C];               // glast: the gradient of the sample the open run belongs to (C <= 2: unused by the flush)
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) glast[c] = 0.0f;
                 cmp_fetch<C, HASHED, POW2, true>(q[(head + kPer * lane) & (kQueue - 1u)], kPer * lane < avail, B, gl, geom, un, rsn, gn, gscale);
 #pragma unroll 1
                 for (uint32_t k = 0; k < kPer; k++) {
@@ -1517,7 +1542,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, A *__restrict__ s_
                         cmp_fetch<C, HASHED, POW2, true>(q[(head + idx + 1u) & (kQueue - 1u)], idx + 1u < avail, B, gl, geom, un, rsn, gn, gscale);
                     if (idx < avail) run_merge_sample<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, uc, rsc, gc, run);
                 }
-                if (run.have) run_flush<C>(s_acc, row_lo, nrows, run);
+                if (run.have) run_flush<C>(s_acc, row_lo, nrows, run, glast);   // (lean runs are closed by run_merge_sample: never open here)
             } else {
                 // two items per lane: both items' loads are in flight before the first scatter starts
 #ifdef UCN_EXP_SCAN_ONLY                                                    // experiment build: what the mask scan alone costs
