@@ -116,11 +116,18 @@ def _check_fp32(spec, want_l, want_g, got_l, got_g, table_bar):
 def _check_bf16(want_l, want_g, got_l, got_g):
     for k, v in want_l.items():
         assert abs(got_l[k] - v) <= 3e-2 * abs(v) + 1e-6, (k, got_l[k], v)
+    worst = (1.0, None, 0.0, None)
     for name, w in want_g.items():
         g, w = got_g[name].double().reshape(-1), w.double().reshape(-1)
         cos = float((g * w).sum() / (g.norm() * w.norm() + 1e-30))
+        ratio = float(g.norm()) / float(w.norm())
+        if cos < worst[0]:
+            worst = (cos, name, worst[2], worst[3])
+        if abs(ratio - 1.0) > worst[2]:
+            worst = (worst[0], worst[1], abs(ratio - 1.0), name)
         assert cos >= 0.99, (name, cos)
-        assert abs(float(g.norm()) / float(w.norm()) - 1.0) <= 5e-2, (name, float(g.norm()), float(w.norm()))
+        assert abs(ratio - 1.0) <= 5e-2, (name, float(g.norm()), float(w.norm()))
+    print(f"bf16 route vs oracle: lowest cosine {worst[0]:.5f} ({worst[1]}), largest norm deviation {worst[2]:.4f} ({worst[3]})")
 
 
 def _table_bar(name, lvl):
@@ -128,7 +135,7 @@ def _table_bar(name, lvl):
     # levels a row sees a handful of samples and the gradient reaching it went through the 16-level featurisation's
     # noise floor (DESIGN.md "Parity analysis": 1e-7 differences in a sample position, amplified by resolutions up to
     # 2^19), so single rows move by percents while the level's sums hold.
-    return 2e-2 if lvl < 4 else 1e-1
+    return 3e-2 if lvl < 4 else 1e-1        # measured 0.4 - 1.4 % / 1.4 - 3.4 % (profiles/r05/full_train_test_vs_oracle.txt)
 
 
 def test_config2_training_step_full_tables_vs_oracle_autograd():
