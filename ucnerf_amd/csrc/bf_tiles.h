@@ -92,6 +92,92 @@ __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf
 #endif
     });
 }
+// ---- the same pair for TWO sample tiles of the wave (64 samples; r05) ------------------------------------------------------------------
+// Every weight fragment read from LDS feeds two MFMAs, so the LDS-DMA stream (what the training kernels are bound by: ~10 B per clock
+// and CU land) and the LDS operand reads are paid once per 64 samples.  Both tiles' in AND out activations are 256 registers plus 64
+// of accumulators: the kernel needs the whole 512-entry file and its two halves used on purpose -- the compiler's MFMA takes its A / B
+// operands from arch VGPRs only and copied every operand parked in the accumulation half back per use (4600 v_accvgpr moves and 41
+// registers of scratch in the first build, each scratch reload a vmcnt(0) that drains the stream's look-ahead).  Here the MFMA is inline
+// assembly with the classes written out: accumulators and ONE of the two activation buffers live in AGPRs (the hardware reads B
+// operands from either half), the other buffer and everything the VALU touches in VGPRs.  What the compiler no longer knows it cannot
+// guard: the caller puts the MFMA -> VALU read wait states behind a chain (pair_settle) itself.
+template <bool INA>
+__device__ __forceinline__ void mfma_bf_cls(f32x16 &acc, const bf8 &w, const bf8 &in) {
+    if constexpr (INA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(in));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(in));
+}
+template <bool INA>
+__device__ __forceinline__ void mfma_bf_cls_first(f32x16 &acc, const bf8 &w, const bf8 &in) {     // acc = A . B (+ 0)
+    if constexpr (INA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "a"(in));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(in));
+}
+// an 8-pass MFMA's result is readable by the VALU 11 wait states after issue (the hazard the compiler inserts s_nop for when it knows
+// the instruction); 16 + 8 covers the last four of the chain
+__device__ __forceinline__ void pair_settle(f32x16 (&a0)[2], f32x16 (&a1)[2]) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a0[0]), "+a"(a0[1]), "+a"(a1[0]), "+a"(a1[1]));
+}
+// ... and a VALU write (v_accvgpr_mov / _write of a bias start, the conversions that produce B operands) must be 2 wait states old when
+// an MFMA reads the register (seen: element 0 of every biased pair's accumulator, copied right in front of the chain, read stale)
+__device__ __forceinline__ void pair_ready(f32x16 (&a0)[2], f32x16 (&a1)[2]) {
+    asm volatile("s_nop 7" : "+a"(a0[0]), "+a"(a0[1]), "+a"(a1[0]), "+a"(a1[1]));
+}
+__device__ __forceinline__ bf8 to_agpr(bf8 v) {
+    asm volatile("" : "+a"(v));
+    return v;
+}
+constexpr int kWAhead = 3;                  // weight fragments requested ahead of their MFMAs (4 register slots)
+// request fragment GF: the ring's housekeeping rides on the requests (as pipe_fetch of mlp_ring.h).  It executes in front of the
+// MFMAs of position GF - kWAhead, so the activation stores issued before it are SC::before(GF - kWAhead).
+template <int GF, int NG, class SC, class RING>
+__device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[4]) {
+    if constexpr (GF < NG) {
+        constexpr int CH = RING::kChunk, NW = RING::kWaves;
+        if constexpr (GF % CH == 0 && GF / CH >= 1) {
+            constexpr int c = GF / CH, Gp = (c - RING::kLeadChunks) * CH + CH - NW;
+            constexpr int extra = SC::before(GF - kWAhead) - (c >= RING::kLeadChunks ? SC::before(Gp - kWAhead) : 0);
+            ring.template boundary<c, extra>();
+        }
+        if constexpr (GF % NW == 0) ring.template piece<GF / CH + RING::kLeadChunks, (GF % CH) / NW>();
+        wp[GF % 4] = __builtin_bit_cast(bf8, ring.template group<GF>());
+    }
+}
+// tile_pair with the fragment pipe (r05): the plain form above issues "one operand read, one MFMA" and the register allocator gives every
+// read the SAME four registers -- read, wait for it, MFMA: with one wave per SIMD the LDS latency stands in front of every MFMA (a pair's
+// 32 MFMAs took ~1900 cycles instead of 1024).  Here fragment G + kWAhead is requested in front of the MFMA of G (program order pinned
+// by a scheduling barrier per step), the pipe lives across pairs and layers.
+template <int P, int NT_IN, int G0, int NG, class SC, class RING>
+__device__ __forceinline__ void tile_pair_pf(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
+    sfor<NT_IN * 2 * P>([&](auto i) {
+        constexpr int I = i.value, G = G0 + I;
+        constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
+        frag_fetch<G + kWAhead, NG, SC>(ring, wp);
+        acc[o2] = mfma_bf(wp[G % 4], in[it][s], acc[o2]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+// acc{0,1}[o2] (+)= A(frag) . in{0,1}: tiles 0..7 of the input from in (class INA), tile 8 (NT_IN = 9) = the per-ray tile, always AGPRs
+template <int NT_IN, int G0, int NG, bool INA, bool ZERO, class SC, class RING>
+__device__ __forceinline__ void tile_pair2(RING &ring, bf8 (&wp)[4], f32x16 (&acc0)[2], f32x16 (&acc1)[2], const bf8 (&in0)[8][2],
+                                           const bf8 (&in1)[8][2], const bf8 (&aux0)[2], const bf8 (&aux1)[2]) {
+    sfor<NT_IN * 4>([&](auto i) {
+        constexpr int I = i.value, G = G0 + I;
+        constexpr int o2 = I % 2, s = (I / 2) % 2, it = I / 4;
+        frag_fetch<G + kWAhead, NG, SC>(ring, wp);
+        if constexpr (it < 8) {
+            if constexpr (ZERO && I < 2) {
+                mfma_bf_cls_first<INA>(acc0[o2], wp[G % 4], in0[it][s]);
+                mfma_bf_cls_first<INA>(acc1[o2], wp[G % 4], in1[it][s]);
+            } else {
+                mfma_bf_cls<INA>(acc0[o2], wp[G % 4], in0[it][s]);
+                mfma_bf_cls<INA>(acc1[o2], wp[G % 4], in1[it][s]);
+            }
+        } else {
+            mfma_bf_cls<true>(acc0[o2], wp[G % 4], aux0[s]);
+            mfma_bf_cls<true>(acc1[o2], wp[G % 4], aux1[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
 // bit r = accumulator register r is positive (the ReLU mask of the lane's 16 features of a tile).  One v_alignbit_b32 per
 // register shifts its SIGN bit into the word ((m << 1) | sign), registers taken from 15 down to 0, then one inversion: 17 VALU
 // instructions per tile where compare + select + or took 48 (the training kernels' masks were 2700 of the sky forward's 5600
@@ -179,7 +265,11 @@ __device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, ui
     for (int i = 0; i < 4; i++) {
         const uint32_t r = 8u * i + ((uint32_t)lane >> 3), c = (uint32_t)lane & 7u;
         const uint4 v = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
+#ifndef UCN_EXP_NOSTORE
         if (r < n_rows) *reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c) = v;
+#else
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
     }
 }
 template <bool PAIR>

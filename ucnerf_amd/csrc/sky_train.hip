@@ -105,6 +105,12 @@ struct FwdStores {
     }
 };
 
+struct FwdStoresNeg { static constexpr int before(int G) { return G < 0 ? 0 : FwdStores::before(G); } };
+constexpr int kFwdFrags = kFV + 72;              // fragments the forward chain consumes
+// UCN_SKY_FWD_PIPE: fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
+#ifndef UCN_SKY_FWD_PIPE
+#define UCN_SKY_FWD_PIPE 1
+#endif
 template <int P>
 __device__ __forceinline__ bf8 (&pick9(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
     if constexpr (P == 0) return a;
@@ -125,6 +131,9 @@ __device__ __forceinline__ bf8 (&pick9(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
 #ifndef UCN_SKY_FWD_OCC
 #define UCN_SKY_FWD_OCC 1
 #endif
+#ifndef UCN_SKY_FWD_STAGED
+#define UCN_SKY_FWD_STAGED (UCN_SKY_FWD_OCC == 1)
+#endif
 __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 : UCN_SKY_FWD_OCC) void k_sky_train_fwd(SkyTrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring + side table (14 KiB) [+ 4 staging tiles]
     const float *side = s_w + kFwdSlots * kTChunk * 256;
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
     const int j = lane & 31, h = lane >> 5;
     const uint32_t M = a.N * (uint32_t)kSkySamples;
     const uint32_t b0 = (blockIdx.x * (uint32_t)kFwdWaves + wave) * 32u;
-    constexpr bool kStaged = UCN_SKY_FWD_OCC == 1;                 // one workgroup per CU: the activation pairs leave through LDS (bf_tiles.h)
+    constexpr bool kStaged = UCN_SKY_FWD_STAGED;                   // the activation pairs leave through LDS (bf_tiles.h)
     uint8_t *stage = reinterpret_cast<uint8_t *>(s_w + kFwdSlots * kTChunk * 256 + kSideFloats) + wave * kStageTile;
     const uint32_t n_rows = b0 < M ? (M - b0 < 32u ? M - b0 : 32u) : 0u;
     const bool live = b0 + j < M;
@@ -210,6 +219,9 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
         if (live) a.mask[((size_t)0 * M + b) * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
     }
 
+    constexpr bool kPipe = UCN_SKY_FWD_PIPE;
+    bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
+    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags, FwdStoresNeg>(ring, wp); });
     float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;
     sfor<7>([&](auto lic) {
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
                 zero_acc(cur[0]);
                 zero_acc(cur[1]);
             }
-            tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4, FwdStores>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            if constexpr (kPipe) tile_pair_pf<2, NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags, FwdStoresNeg>(ring, wp, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            else tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4, FwdStores>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
             if constexpr (li == 6) {                              // alpha head on the fp32 ReLU output of layer 7
                 alpha_partial<2 * pr, 0>(cur[0], pa, sig);
                 alpha_partial<2 * pr, 1>(cur[0], pa, sig);
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
                 out[2 * pr + o][1] = to_b(cur[o], 1, true);
             }
             mk[pr] = mask16(cur[0]) | (mask16(cur[1]) << 16);
+            asm volatile("" : "+v"(mk[pr]));                      // computed HERE: left alone it may sink into the `live` block at the layer's end
 #ifdef UCN_EXP_COMPACT_ACT   // timing-only experiment: every layer its own [M, 256] matrix (the host still reads the interleaved layout: results garbage)
             if constexpr (kStaged) store_pair_staged(stage, row + (size_t)(li + 1) * M * 256, 256, b0, n_rows, 2 * pr, lane, out[2 * pr], out[2 * pr + 1]);
 #else
@@ -263,7 +277,8 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
         f32x16 v[2];
         zero_acc(v[0]);
         zero_acc(v[1]);
-        tile_pair<2, 9, kFV + pr * 36, FwdStores>(ring, v, h7);
+        if constexpr (kPipe) tile_pair_pf<2, 9, kFV + pr * 36, kFwdFrags, FwdStoresNeg>(ring, wp, v, h7);
+        else tile_pair<2, 9, kFV + pr * 36, FwdStores>(ring, v, h7);
         bf8 hv[2][2];
 #pragma unroll
         for (int o = 0; o < 2; o++) {
@@ -288,6 +303,212 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
         *reinterpret_cast<float4 *>(a.raw + (size_t)b * 4) = make_float4(c0 + brgb[0], c1 + brgb[1], c2 + brgb[2], sig);
 }
 
+// ---- the forward kernel with TWO sample tiles per wave (UCN_SKY_FWD_TILES = 2; r05) ------------------------------------------------
+// Same chain, same stream, same outputs; a wave carries 64 samples and every weight fragment feeds two MFMAs (bf_tiles.h tile_pair2):
+// the 1 MB weight stream is paid once per 256 samples of a workgroup.  Register plan per lane (one workgroup per CU, 512 registers):
+//   AGPRs: activation buffer A of both tiles (128) + the per-ray tiles (16) + a pair's accumulators (64)
+//   VGPRs: activation buffer B of both tiles (128) + the fragment pipe (16) + epilogue temporaries
+// Layer li reads A and writes B (li even) or reads B and writes A (li odd; the VALU's results are moved over, 128 v_accvgpr_write).
+struct FwdStores2 { static constexpr int before(int G) { return G < 0 ? 0 : 2 * FwdStores::before(G); } };
+#ifndef UCN_SKY_FWD_TILES
+#define UCN_SKY_FWD_TILES 1
+#endif
+template <int P>
+__device__ __forceinline__ bf8 (&pick8(bf8 (&a)[8][2], bf8 (&b)[8][2]))[8][2] {
+    if constexpr (P == 0) return a;
+    else return b;
+}
+__global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring + side table + 4 staging tiles
+    const float *side = s_w + kFwdSlots * kTChunk * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t M = a.N * (uint32_t)kSkySamples;
+    uint8_t *stage = reinterpret_cast<uint8_t *>(s_w + kFwdSlots * kTChunk * 256 + kSideFloats) + wave * kStageTile;
+    uint32_t b0[2], n_rows[2], b[2];
+    bool live[2];
+    float px[2], py[2], pz[2];
+    bf8 XA[2][8][2], XB[2][8][2], AUX[2][2];      // XA, AUX: AGPRs (only ever operands of the class-annotated MFMA); XB: VGPRs
+    uint16_t *row = a.act;
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        b0[st] = ((blockIdx.x * 4u + wave) * 2u + st) * 32u;
+        n_rows[st] = b0[st] < M ? (M - b0[st] < 32u ? M - b0[st] : 32u) : 0u;
+        live[st] = b0[st] + j < M;
+        b[st] = live[st] ? b0[st] + j : M - 1;
+        const uint32_t ray = b[st] / kSkySamples, s = b[st] - ray * kSkySamples;
+        const float tv = a.t_vals[s];
+        const float z = a.far_[ray] * (1.0f - tv) + inv_sky_far_of(a.far_) * tv;          // models.py:872
+        px[st] = a.origins[ray * 3 + 0] + a.dirs[ray * 3 + 0] * z;
+        py[st] = a.origins[ray * 3 + 1] + a.dirs[ray * 3 + 1] * z;
+        pz[st] = a.origins[ray * 3 + 2] + a.dirs[ray * 3 + 2] * z;
+        f32x16 av;
+        const float4 *ap = reinterpret_cast<const float4 *>(a.aux + (size_t)ray * 32 + 4 * h);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const float4 v = ap[2 * r4];
+            av[4 * r4 + 0] = v.x; av[4 * r4 + 1] = v.y; av[4 * r4 + 2] = v.z; av[4 * r4 + 3] = v.w;
+        }
+        if (h == 0) { av[0] = px[st]; av[1] = py[st]; av[2] = pz[st]; }
+        bf8 t[2] = {to_b(av, 0, false), to_b(av, 1, false)};
+        store_tile(row + kActAux, kActLd, b[st], 0, h, t, live[st]);
+        AUX[st][0] = to_agpr(t[0]);
+        AUX[st][1] = to_agpr(t[1]);
+    }
+    STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
+    {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
+        const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
+        const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
+#pragma unroll
+        for (int k = 0; k < (kSideFloats / 256 + 3) / 4; k++) {
+            const int piece = k * 4 + wave;
+            if (piece < kSideFloats / 256)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                             :
+                             : "s"(lside + piece * 1024u), "v"(lane * 16u), "s"(gside + piece * 256)
+                             : "memory");
+        }
+    }
+    ring_start(ring);
+    ring.template boundary<0>();                    // side table + chunk 0 landed
+
+    // ---- layer 0 (3 -> 256), fp32 on the VALU, rounded into XA
+    {
+        const float4 *p0 = reinterpret_cast<const float4 *>(side + kSL0) + h;
+        uint32_t mk[2][4];
+        sfor<4>([&](auto pc) {
+            constexpr int pr = pc.value;
+            sfor<2>([&](auto stc) {
+                constexpr int st = stc.value;
+                bf8 o[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int t = 2 * pr + q;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float4 w = p0[(t * 16 + r) * 2];
+                        acc[r] = fmaf(w.z, pz[st], fmaf(w.y, py[st], fmaf(w.x, px[st], w.w)));
+                    }
+                    o[q][0] = to_b(acc, 0, true);
+                    o[q][1] = to_b(acc, 1, true);
+                    if (q == 0) mk[st][pr] = mask16(acc);
+                    else mk[st][pr] |= mask16(acc) << 16;
+                }
+                asm volatile("" : "+v"(mk[st][pr]));              // computed HERE (left alone it sinks into the `live` block at the layer's end,
+                //                                                   the pair's 32 accumulator values with it: 536 bytes of scratch)
+                store_pair_staged(stage, row, kActLd, b0[st], n_rows[st], 2 * pr, lane, o[0], o[1]);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    XA[st][2 * pr + q][0] = to_agpr(o[q][0]);
+                    XA[st][2 * pr + q][1] = to_agpr(o[q][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+            if (live[st]) a.mask[((size_t)0 * M + b[st]) * 2 + h] = make_uint4(mk[st][0], mk[st][1], mk[st][2], mk[st][3]);
+    }
+
+    bf8 wp[4];
+    sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags, FwdStores2>(ring, wp); });
+    float sig[2] = {0.0f, 0.0f};                                  // alpha head partials (this lane's 128 neurons)
+    const float *pa = side + kSAlpha + h;
+    sfor<7>([&](auto lic) {
+        constexpr int li = lic.value, NT_IN = li == 4 ? 9 : 8;
+        constexpr bool INA = li % 2 == 0;                         // reads XA, writes XB
+        bf8 (&in0)[8][2] = pick8<li % 2>(XA[0], XB[0]);
+        bf8 (&in1)[8][2] = pick8<li % 2>(XA[1], XB[1]);
+        bf8 (&out0)[8][2] = pick8<(li + 1) % 2>(XA[0], XB[0]);
+        bf8 (&out1)[8][2] = pick8<(li + 1) % 2>(XA[1], XB[1]);
+        uint32_t mk[2][4];
+        sfor<4>([&](auto pc) {
+            constexpr int pr = pc.value;
+            f32x16 c0[2], c1[2];
+            constexpr bool ZERO = kBiasIdx[li] < 0;
+            if constexpr (!ZERO) {
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr, c0[0], h);
+                side_bias_tile(side, kSB + kBiasIdx[li] * 256, 2 * pr + 1, c0[1], h);
+#pragma unroll
+                for (int r = 0; r < 16; r++) { c1[0][r] = c0[0][r]; c1[1][r] = c0[1][r]; }
+                pair_ready(c0, c1);
+            } else {
+                asm volatile("s_nop 7");
+            }
+            tile_pair2<NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags, INA, ZERO, FwdStores2>(ring, wp, c0, c1, in0, in1, AUX[0], AUX[1]);
+            pair_settle(c0, c1);
+            sfor<2>([&](auto stc) {
+                constexpr int st = stc.value;
+                f32x16 (&c)[2] = *(st == 0 ? &c0 : &c1);
+                if constexpr (li == 6) {                          // alpha head on the fp32 ReLU output of layer 7
+                    alpha_partial<2 * pr, 0>(c[0], pa, sig[st]); alpha_partial<2 * pr, 1>(c[0], pa, sig[st]);
+                    alpha_partial<2 * pr + 1, 0>(c[1], pa, sig[st]); alpha_partial<2 * pr + 1, 1>(c[1], pa, sig[st]);
+                }
+                bf8 o[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) { o[q][0] = to_b(c[q], 0, true); o[q][1] = to_b(c[q], 1, true); }
+                mk[st][pr] = mask16(c[0]) | (mask16(c[1]) << 16);
+                asm volatile("" : "+v"(mk[st][pr]));
+                store_pair_staged(stage, row + (li + 1) * kActBlock, kActLd, b0[st], n_rows[st], 2 * pr, lane, o[0], o[1]);
+                bf8 (&out)[8][2] = *(st == 0 ? &out0 : &out1);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    out[2 * pr + q][0] = INA ? o[q][0] : to_agpr(o[q][0]);
+                    out[2 * pr + q][1] = INA ? o[q][1] : to_agpr(o[q][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+            if (live[st]) a.mask[((size_t)(li + 1) * M + b[st]) * 2 + h] = make_uint4(mk[st][0], mk[st][1], mk[st][2], mk[st][3]);
+    });
+    // ---- views layer: [h7 (8 tiles) | aux] -> 128, 2 pair chains; h7 = XB (7 layers), then the rgb head per pair
+    sig[0] = xor32_sum(sig[0]) + side[kSAlpha + 256];
+    sig[1] = xor32_sum(sig[1]) + side[kSAlpha + 256];
+    const float4 *prgb = reinterpret_cast<const float4 *>(side + kSRgb) + h;
+    float cc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    uint32_t mkv[2][2];
+    sfor<2>([&](auto pc) {
+        constexpr int pr = pc.value;
+        f32x16 v0[2], v1[2];
+        asm volatile("s_nop 7");
+        tile_pair2<9, kFV + pr * 36, kFwdFrags, false, true, FwdStores2>(ring, wp, v0, v1, XB[0], XB[1], AUX[0], AUX[1]);
+        pair_settle(v0, v1);
+        sfor<2>([&](auto stc) {
+            constexpr int st = stc.value;
+            f32x16 (&v)[2] = *(st == 0 ? &v0 : &v1);
+            bf8 hv[2][2];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                hv[o][0] = to_b(v[o], 0, true);
+                hv[o][1] = to_b(v[o], 1, true);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float4 w = prgb[((2 * pr + o) * 16 + r) * 2];
+                    const float x = fmaxf(v[o][r], 0.0f);
+                    cc[st][0] = fmaf(x, w.x, cc[st][0]); cc[st][1] = fmaf(x, w.y, cc[st][1]); cc[st][2] = fmaf(x, w.z, cc[st][2]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mkv[st][pr] = mask16(v[0]) | (mask16(v[1]) << 16);
+            asm volatile("" : "+v"(mkv[st][pr]));
+            store_pair_staged(stage, row + kActHv, kActLd, b0[st], n_rows[st], 2 * pr, lane, hv[0], hv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    const float *brgb = side + kSRgb + 512;
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        if (live[st]) a.mask_v[(size_t)b[st] * 2 + h] = make_uint2(mkv[st][0], mkv[st][1]);
+        const float r0 = xor32_sum(cc[st][0]), r1 = xor32_sum(cc[st][1]), r2 = xor32_sum(cc[st][2]);
+        if (live[st] && h == 0)
+            *reinterpret_cast<float4 *>(a.raw + (size_t)b[st] * 4) = make_float4(r0 + brgb[0], r1 + brgb[1], r2 + brgb[2], sig[st]);
+    }
+}
+
 struct SkyTrainBwdArgs {
     const uint8_t *packed;
     const float *graw;           // [M, 4] fp32: d loss / d (colour logits, sigma)
@@ -297,11 +518,6 @@ struct SkyTrainBwdArgs {
     uint32_t M;
 };
 
-template <int P>
-__device__ __forceinline__ bf8 (&pick8(bf8 (&a)[8][2], bf8 (&b)[8][2]))[8][2] {
-    if constexpr (P == 0) return a;
-    else return b;
-}
 
 #ifndef UCN_SKY_BWD_OCC
 #define UCN_SKY_BWD_OCC 2
@@ -558,8 +774,11 @@ extern "C" int ucn_sky_train_fwd(const void *packed, const float *origins, const
     SkyTrainArgs a{reinterpret_cast<const uint8_t *>(packed), aux_ws, origins, directions, far_, t_vals, N, raw,
                    reinterpret_cast<uint16_t *>(act), reinterpret_cast<uint4 *>(mask), reinterpret_cast<uint2 *>(mask_v)};
     const uint64_t M = (uint64_t)N * kSkySamples;
-    const size_t lds = ((size_t)kFwdSlots * kTChunk * 256 + kSideFloats) * sizeof(float) + (UCN_SKY_FWD_OCC == 1 ? kFwdWaves * kStageTile : 0);
-    hipLaunchKernelGGL(k_sky_train_fwd, dim3(ucn_div_up(M, 32 * kFwdWaves)), dim3(64 * kFwdWaves), lds, st, a);
+    const size_t lds = ((size_t)kFwdSlots * kTChunk * 256 + kSideFloats) * sizeof(float) + (UCN_SKY_FWD_STAGED ? kFwdWaves * kStageTile : 0);
+    const char *tiles_env = getenv("UCN_SKY_FWD_TILES");        // per call: the A/B tools flip it inside one process
+    const int tiles = tiles_env ? atoi(tiles_env) : UCN_SKY_FWD_TILES;
+    if (tiles == 2 && UCN_SKY_FWD_OCC == 1 && kFwdWaves == 4) hipLaunchKernelGGL(k_sky_train_fwd2, dim3(ucn_div_up(M, 256)), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_sky_train_fwd, dim3(ucn_div_up(M, 32 * kFwdWaves)), dim3(64 * kFwdWaves), lds, st, a);
     hipLaunchKernelGGL(k_sky_composite_dev, dim3(ucn_div_up(N, 64)), dim3(64), 0, st, raw, directions, far_, t_vals, N, sky_rgb_out);
     UCN_LAUNCH_CHECK("sky_train_fwd");
     return 0;
