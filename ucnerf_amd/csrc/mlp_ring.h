@@ -193,6 +193,8 @@ struct Ring {
     // is "at most (later pieces + EXTRA) operations outstanding".  Without it the wait also drains those stores -- each a ~1 us
     // round trip to L2 -- at every chunk boundary (every ~0.2 us): the sky training kernels spent their whole duration there.  A LOWER
     // bound is safe (a smaller count only waits longer); the counter is 6 bits.
+    bool count_stores = true;   // wave-uniform: false for a wave whose tile is ragged or dead -- its conditional stores may not issue,
+    //                             the EXTRA count would then let the wave pass before its DMA pieces have landed
     template <int C, int EXTRA = 0>
     __device__ __forceinline__ void boundary() {
         // DMA instructions of this wave that may still be in flight: those of the chunks behind C that have been
@@ -208,7 +210,12 @@ struct Ring {
             if constexpr (C == 0) ring_wait_lds<0>();
         } else {
             constexpr int allowed = later * kPiecesPerChunk + (EXTRA > 0 ? EXTRA : 0);
-            ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
+            if constexpr (EXTRA > 0) {
+                if (count_stores) ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
+                else ring_wait_vm<later * kPiecesPerChunk>();
+            } else {
+                ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
+            }
         }
         // bare barrier: __syncthreads() adds a fence whose lgkmcnt(0) would drain the operand pipe.  LDS is coherent
         // within the CU and every wave has waited for its own DMA; the slot being refilled was last read a chunk ago.

@@ -35,11 +35,14 @@ constexpr int kTrPadded = (kTrFrags + kTChunk - 1) / kTChunk * kTChunk; // 992
 #ifndef UCN_SKY_FWD_LEAD
 #define UCN_SKY_FWD_LEAD 4
 #endif
+#ifndef UCN_SKY_BWD_OCC
+#define UCN_SKY_BWD_OCC 1
+#endif
 #ifndef UCN_SKY_BWD_SLOTS
-#define UCN_SKY_BWD_SLOTS kTSlots
+#define UCN_SKY_BWD_SLOTS (UCN_SKY_BWD_OCC == 1 ? 6 : kTSlots)
 #endif
 #ifndef UCN_SKY_BWD_LEAD
-#define UCN_SKY_BWD_LEAD kTLead
+#define UCN_SKY_BWD_LEAD (UCN_SKY_BWD_OCC == 1 ? 4 : kTLead)
 #endif
 constexpr int kFwdSlots = UCN_SKY_FWD_SLOTS, kBwdSlots = UCN_SKY_BWD_SLOTS;
 static_assert(UCN_SKY_FWD_SLOTS >= UCN_SKY_FWD_LEAD + 2 && UCN_SKY_BWD_SLOTS >= UCN_SKY_BWD_LEAD + 2, "a chunk is refilled two boundaries after its last reader");
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
     store_tile(row + kActAux, kActLd, b, 0, h, XA[8], live);
 
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
+    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
         const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
         const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
         AUX[st][1] = to_agpr(t[1]);
     }
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
+    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows[0]) == 32u && __builtin_amdgcn_readfirstlane(n_rows[1]) == 32u;
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
         const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
         const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
@@ -519,43 +524,80 @@ struct SkyTrainBwdArgs {
 };
 
 
+// UCN_SKY_BWD_OCC: workgroups per CU the backward kernel's registers are cut for.  r05: ONE, as the forward kernel and for the same
+// reasons -- the whole register file (every layer's ReLU masks preloaded: no compiler-visible load, hence no compiler-placed vmcnt,
+// inside the weight stream), the fragment pipe (tile_pair_pf), a 6-slot ring 4 chunks ahead, pairs stored as whole lines through LDS
+// and counted at the chunk waits.
 #ifndef UCN_SKY_BWD_OCC
-#define UCN_SKY_BWD_OCC 2
+#define UCN_SKY_BWD_OCC 1
 #endif
+#ifndef UCN_SKY_BWD_PIPE
+#define UCN_SKY_BWD_PIPE (UCN_SKY_BWD_OCC == 1)
+#endif
+#ifndef UCN_SKY_BWD_STAGED
+#define UCN_SKY_BWD_STAGED (UCN_SKY_BWD_OCC == 1)
+#endif
+// gradient-tile stores of the backward kernel in stream order: 4 per pair (staged or per lane alike)
+struct BwdStores {
+    static constexpr int before(int G) {
+        if (G < 0) return 0;
+        int n = 0;
+        for (int pr = 0; pr < 2; pr++) n += (kGV + 4 * (pr + 1) <= G) ? 4 : 0;
+        for (int pr = 0; pr < 4; pr++) n += (kG7 + 20 * (pr + 1) <= G) ? 4 : 0;
+        for (int q = 1; q < 8; q++)
+            for (int pr = 0; pr < 4; pr++) n += (kGL + 128 * (q - 1) + 32 * (pr + 1) <= G) ? 4 : 0;
+        return n;
+    }
+};
 __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 : UCN_SKY_BWD_OCC) void k_sky_train_bwd(SkyTrainBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring [+ one staging tile per wave]
+    constexpr bool kPipe = UCN_SKY_BWD_PIPE, kStaged = UCN_SKY_BWD_STAGED, kPreMask = UCN_SKY_BWD_OCC == 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t s0 = (blockIdx.x * (uint32_t)kBwdWaves + wave) * 32u + j;
+    const uint32_t b0 = (blockIdx.x * (uint32_t)kBwdWaves + wave) * 32u;
+    const uint32_t n_rows = b0 < a.M ? (a.M - b0 < 32u ? a.M - b0 : 32u) : 0u;
+    const uint32_t s0 = b0 + j;
     const bool live = s0 < a.M;
     const uint32_t b = live ? s0 : a.M - 1;
+    uint8_t *stage = reinterpret_cast<uint8_t *>(s_w + kBwdSlots * kTChunk * 256) + wave * kStageTile;
+    uint4 mall[8];                                                // kPreMask: every layer's ReLU masks, before the stream starts
+    if constexpr (kPreMask) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) mall[l] = a.mask[((size_t)l * a.M + b) * 2 + h];
+    }
+    const uint2 mv = a.mask_v[(size_t)b * 2 + h];
+    uint4 mcur = kPreMask ? mall[7] : a.mask[((size_t)7 * a.M + b) * 2 + h];
+    float4 ghead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (h == 0) ghead = *reinterpret_cast<const float4 *>(a.graw + (size_t)b * 4);
+    if constexpr (kPreMask) {                                     // the loads above are complete before the first DMA piece is counted
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     SBRing ring(reinterpret_cast<const float *>(a.packed + kPkBwd), s_w, lane, wave);
+    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
     ring_start(ring);
     // ---- the head gradients as one input tile: columns 0..3 = d logits (r, g, b), d sigma -- registers 0..3 of wave half 0
     //      in accumulator order and in natural order alike
     bf8 dv[5][2];                      // tiles 0..3: dv (filled below), 4: the head-gradient tile
     {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (h == 0) {
-            const float4 g = *reinterpret_cast<const float4 *>(a.graw + (size_t)b * 4);
-            v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w;
-        }
+        if (h == 0) { v[0] = ghead.x; v[1] = ghead.y; v[2] = ghead.z; v[3] = ghead.w; }
         dv[4][0] = pack8(v);
         const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         dv[4][1] = pack8(z);
         store_tile(a.dl + kDlG, kDlLd, b, 0, h, dv[4], live);
     }
-    const uint2 mv = a.mask_v[(size_t)b * 2 + h];
-    uint4 mcur = a.mask[((size_t)7 * a.M + b) * 2 + h];
     ring.template boundary<0>();
+    bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
+    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kTrFrags, BwdStores>(ring, wp); });
     // ---- through the rgb layer and the views layer's ReLU
     sfor<2>([&](auto pc) {
         constexpr int pr = pc.value;
         f32x16 acc[2];
         zero_acc(acc[0]);
         zero_acc(acc[1]);
-        tile_pair<2, 1, kGV + 4 * pr>(ring, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
+        if constexpr (kPipe) tile_pair_pf<2, 1, kGV + 4 * pr, kTrFrags, BwdStores>(ring, wp, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
+        else tile_pair<2, 1, kGV + 4 * pr>(ring, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
         const uint32_t mw = pr == 0 ? mv.x : mv.y;
 #pragma unroll
         for (int o = 0; o < 2; o++) {
@@ -563,7 +605,9 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
             dv[2 * pr + o][0] = to_b_masked(acc[o], 0, bits);
             dv[2 * pr + o][1] = to_b_masked(acc[o], 1, bits);
         }
-        store_two<true>(a.dl + kDlV, kDlLd, b, 2 * pr, h, dv[2 * pr], dv[2 * pr + 1], live);
+        if constexpr (kStaged) store_pair_staged(stage, a.dl + kDlV, kDlLd, b0, n_rows, 2 * pr, lane, dv[2 * pr], dv[2 * pr + 1]);
+        else store_two<true>(a.dl + kDlV, kDlLd, b, 2 * pr, h, dv[2 * pr], dv[2 * pr + 1], live);
+        __builtin_amdgcn_sched_barrier(0);
     });
     // ---- through the (composed) views layer and the alpha head into h7, then down the trunk.  Stage q = 0..7 produces
     //      d_{7-q}: q = 0 reads [dv | g] (5 tiles), the others the previous stage's 8 tiles; DA / DB ping-pong.
@@ -571,23 +615,30 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
     sfor<8>([&](auto qc) {
         constexpr int q = qc.value, l = 7 - q;
         bf8 (&out)[8][2] = pick8<q % 2>(DA, DB);
-        const uint4 mk = mcur;
-        if constexpr (l > 0) mcur = a.mask[((size_t)(l - 1) * a.M + b) * 2 + h];       // the next stage's masks, one stage ahead
+        const uint4 mk = kPreMask ? mall[l] : mcur;
+        if constexpr (l > 0 && !kPreMask) mcur = a.mask[((size_t)(l - 1) * a.M + b) * 2 + h];   // the next stage's masks, one stage ahead
         const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
         sfor<4>([&](auto pc) {
             constexpr int pr = pc.value;
             f32x16 acc[2];
             zero_acc(acc[0]);
             zero_acc(acc[1]);
-            if constexpr (q == 0) tile_pair<2, 5, kG7 + 20 * pr>(ring, acc, dv);
-            else tile_pair<2, 8, kGL + 128 * (q - 1) + 32 * pr>(ring, acc, pick8<(q + 1) % 2>(DA, DB));
+            if constexpr (kPipe) {
+                if constexpr (q == 0) tile_pair_pf<2, 5, kG7 + 20 * pr, kTrFrags, BwdStores>(ring, wp, acc, dv);
+                else tile_pair_pf<2, 8, kGL + 128 * (q - 1) + 32 * pr, kTrFrags, BwdStores>(ring, wp, acc, pick8<(q + 1) % 2>(DA, DB));
+            } else {
+                if constexpr (q == 0) tile_pair<2, 5, kG7 + 20 * pr>(ring, acc, dv);
+                else tile_pair<2, 8, kGL + 128 * (q - 1) + 32 * pr>(ring, acc, pick8<(q + 1) % 2>(DA, DB));
+            }
 #pragma unroll
             for (int o = 0; o < 2; o++) {
                 const uint32_t bits = (mw[pr] >> (16 * o)) & 0xFFFFu;
                 out[2 * pr + o][0] = to_b_masked(acc[o], 0, bits);
                 out[2 * pr + o][1] = to_b_masked(acc[o], 1, bits);
             }
-            store_two<true>(a.dl + l * 256, kDlLd, b, 2 * pr, h, out[2 * pr], out[2 * pr + 1], live);
+            if constexpr (kStaged) store_pair_staged(stage, a.dl + l * 256, kDlLd, b0, n_rows, 2 * pr, lane, out[2 * pr], out[2 * pr + 1]);
+            else store_two<true>(a.dl + l * 256, kDlLd, b, 2 * pr, h, out[2 * pr], out[2 * pr + 1], live);
+            __builtin_amdgcn_sched_barrier(0);
         });
     });
 }
@@ -796,7 +847,8 @@ extern "C" int ucn_sky_train_bwd(const void *packed, const float *g_sky_rgb, con
                        g_raw_ws);
     SkyTrainBwdArgs a{reinterpret_cast<const uint8_t *>(packed), g_raw_ws, reinterpret_cast<const uint4 *>(mask),
                       reinterpret_cast<const uint2 *>(mask_v), reinterpret_cast<uint16_t *>(grad), (uint32_t)M};
-    hipLaunchKernelGGL(k_sky_train_bwd, dim3(ucn_div_up(M, 32 * kBwdWaves)), dim3(64 * kBwdWaves), (size_t)kBwdSlots * kTChunk * 1024, st, a);
+    hipLaunchKernelGGL(k_sky_train_bwd, dim3(ucn_div_up(M, 32 * kBwdWaves)), dim3(64 * kBwdWaves),
+                       (size_t)kBwdSlots * kTChunk * 1024 + (UCN_SKY_BWD_STAGED ? kBwdWaves * kStageTile : 0), st, a);
     UCN_LAUNCH_CHECK("sky_train_bwd");
     return 0;
 }
