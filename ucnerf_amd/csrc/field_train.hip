@@ -45,6 +45,10 @@ struct TrainFwdArgs {
 };
 
 
+// UCN_TRAIN_PIPE (r05): weight fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
+#ifndef UCN_TRAIN_PIPE
+#define UCN_TRAIN_PIPE 1
+#endif
 #ifndef UCN_TRAIN_PAIR_FWD
 #define UCN_TRAIN_PAIR_FWD 1
 #endif
@@ -62,6 +66,11 @@ using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;                  
 constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 4 * 12 + 4 * 48;     // with the direction tile in the stream (inference): 276 / 280
 constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 288
 using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
+template <int P, int NT_IN, int G0, int NG, class RING>
+__device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
+    if constexpr (UCN_TRAIN_PIPE != 0) tile_pair_pf<P, NT_IN, G0, NG, NoStoreCount>(ring, wp, acc, in);
+    else tile_pair<P, NT_IN, G0>(ring, acc, in);
+}
 
 
 #ifndef UCN_TRAIN_FWD_WGS
@@ -177,6 +186,9 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     constexpr int NA = AUX ? 1 : 0;                        // extra input tiles of the colour layers
     constexpr int P2 = (2 + NA) * 4, P3 = (10 + NA) * 4;   // fragments per output pair of L2' / L3'
     constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 4 * P2;
+    constexpr int NGF = G3 + 4 * (P3 + 4);                 // fragments this kernel consumes
+    bf8 wp[4];                                             // fragment pipe
+    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF, NoStoreCount>(ring, wp); });
     // ---- density layer 0
     bf8 hin[10 + NA][2];                   // tiles 0..7: h1 (filled below), 8..9: h0, (10: the ray's direction tile)
     bf8 (&h0)[2][2] = reinterpret_cast<bf8(&)[2][2]>(hin[8]);
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
         f32x16 a0[2];
         load_acc((SIDE ? side_b0 : a.bias_d0) + (0 * 2 + h) * 16, a0[0]);
         load_acc((SIDE ? side_b0 : a.bias_d0) + (1 * 2 + h) * 16, a0[1]);
-        tile_pair<2, NTF, 0>(ring, a0, fin);
+        tile_pair_sel<2, NTF, 0, NGF>(ring, wp, a0, fin);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             h0[t][0] = to_b(a0[t], 0, true);
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
         f32x16 acc[2];
         load_acc((SIDE ? side_b1 : a.bias_d1) + ((2 * p) * 2 + h) * 16, acc[0]);
         load_acc((SIDE ? side_b1 : a.bias_d1) + ((2 * p + 1) * 2 + h) * 16, acc[1]);
-        tile_pair<2, 2, G1 + 8 * p>(ring, acc, h0);
+        tile_pair_sel<2, 2, G1 + 8 * p, NGF>(ring, wp, acc, h0);
         bf8 xp[2][2];
 #pragma unroll
         for (int o = 0; o < 2; o++) {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                     load_acc(a.pr0 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
                 }
             }
-            tile_pair<2, 2 + NA, G2 + P2 * p>(ring, acc, reinterpret_cast<const bf8(&)[2 + NA][2]>(hin[8]));
+            tile_pair_sel<2, 2 + NA, G2 + P2 * p, NGF>(ring, wp, acc, reinterpret_cast<const bf8(&)[2 + NA][2]>(hin[8]));
 #pragma unroll
             for (int o = 0; o < 2; o++) {
                 hin[2 * p + o][0] = to_b(acc[o], 0, true);
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                     load_acc(a.pr1 + ((size_t)ray * 8 + 2 * p + 1) * 32 + h * 16, acc[1]);
                 }
             }
-            tile_pair<2, 10 + NA, G3 + (P3 + 4) * p>(ring, acc, hin);
+            tile_pair_sel<2, 10 + NA, G3 + (P3 + 4) * p, NGF>(ring, wp, acc, hin);
             bf8 hp[2][2];
 #pragma unroll
             for (int o = 0; o < 2; o++) {
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
             f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
             zero_acc(yo[0]);
-            tile_pair<1, 2, G3 + (P3 + 4) * p + P3>(ring, yo, hp);
+            tile_pair_sel<1, 2, G3 + (P3 + 4) * p + P3, NGF>(ring, wp, yo, hp);
             y3[0] += yo[0][0]; y3[1] += yo[0][1]; y3[2] += yo[0][2];
         });
         if (live && a.store) a.m2[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -370,6 +382,9 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
     // stream positions: Wr^T: 4 pairs x 4 | W1h^T: 4 pairs x 32 | 4 x ([W1x^T | W0x^T] pair: 64, then Wd1^T's fragments for the
     // two gx tiles just finished: 8) | Wd0^T
     constexpr int H1 = 16, H2 = H1 + 128, H4 = H2 + 4 * 72;
+    constexpr int NGF = H4 + 4 * NTF;                      // fragments this kernel consumes
+    bf8 wp[4];                                             // fragment pipe
+    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF, NoStoreCount>(ring, wp); });
     bf8 din[16][2];                          // tiles 0..7: d1, 8..15: d0  (the order of [W1x^T | W0x^T])
     // ---- through the rgb layer and the second hidden layer's ReLU
     sfor<4>([&](auto pp) {
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         f32x16 acc[2];
         zero_acc(acc[0]);
         zero_acc(acc[1]);
-        tile_pair<2, 1, 4 * p>(ring, acc, gin);
+        tile_pair_sel<2, 1, 4 * p, NGF>(ring, wp, acc, gin);
 #pragma unroll
         for (int o = 0; o < 2; o++) {
             const uint32_t bits = (m2w[p] >> (16 * o)) & 0xFFFFu;
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         f32x16 acc[2];
         zero_acc(acc[0]);
         zero_acc(acc[1]);
-        tile_pair<2, 8, H1 + 32 * p>(ring, acc, reinterpret_cast<const bf8(&)[8][2]>(din[0]));
+        tile_pair_sel<2, 8, H1 + 32 * p, NGF>(ring, wp, acc, reinterpret_cast<const bf8(&)[8][2]>(din[0]));
 #pragma unroll
         for (int o = 0; o < 2; o++) {
             const uint32_t bits = (m1w[p] >> (16 * o)) & 0xFFFFu;
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
         f32x16 acc[2];
         zero_acc(acc[0]);
         zero_acc(acc[1]);
-        tile_pair<2, 16, H2 + 72 * p>(ring, acc, din);
+        tile_pair_sel<2, 16, H2 + 72 * p, NGF>(ring, wp, acc, din);
         if constexpr (p == 0) {
             if (a.graw && h == 0) {
                 const float gr = gr_head;
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
             gp[o][1] = to_b(acc[o], 1, false);
         }
         if (a.gx) store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gx, 256, sample, 2 * p, h, gp[0], gp[1], live);                  // (r04: gx = NULL -- the bottleneck's weight gradient is formed from d0^T h0, d1^T h0)
-        tile_pair<2, 2, H2 + 72 * p + 64>(ring, a0, gp);
+        tile_pair_sel<2, 2, H2 + 72 * p + 64, NGF>(ring, wp, a0, gp);
     });
     // ---- ReLU of h0
     bf8 gh0[2][2];
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
     f32x16 gf[NTF];
 #pragma unroll
     for (int ft = 0; ft < NTF; ft++) zero_acc(gf[ft]);
-    tile_pair<NTF, 2, H4>(ring, gf, gh0);
+    tile_pair_sel<NTF, 2, H4, NGF>(ring, wp, gf, gh0);
     if (live) {
 #pragma unroll
         for (int ft = 0; ft < NTF; ft++)
