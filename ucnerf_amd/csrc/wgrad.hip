@@ -42,81 +42,149 @@ __device__ __forceinline__ uint64_t tr_read(uint32_t lds_byte) {
     return v;
 }
 
+// r05: how a stage's 35 KB reach LDS.  Before, all of it travelled through 5 x 16 bytes of registers per thread and only ONE stage
+// could be in flight: 35 KB per CU against ~2 us of loaded HBM latency is 8.3 bytes per clock and CU, 57 % of the HBM roofline, which is
+// what the kernel reached (233 us per 983 k x (256 + 288) pass); a second register set does not fit beside the 144 accumulator
+// registers.  Now the B image arrives by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), three stages ahead in a
+// four-buffer ring, and the A image keeps the register path with two stages in flight.  (Everything by DMA was measured first: that
+// path lands ~1 KB per 100 cycles and CU whatever the instruction carries -- 401 us with one row per instruction.)  A DMA instruction
+// fills 1 KB of CONSECUTIVE image bytes, each lane fetching whatever chunk belongs there (pad bytes: the row's first chunk again).
+// All loads are inline assembly and waited for by hand: vmcnt retires in issue order, an iteration issues [A(st + 2), B(st + 3)], so
+// "A(st + 1) and everything older has landed" is "at most |B(st + 2)| + |A(st + 2)| + |B(st + 3)| of my operations outstanding".
+// Every wave always issues its full share (rows outside the slab are clamped into the matrix and zeroed after landing), so the
+// counts hold in the first and last stages too.
+constexpr int kWgBStages = 4;               // B image ring: one being read, three in flight
+constexpr int wg_stride_b(int ntb) { return ntb == 1 ? 64 : (ntb <= 5 ? 320 : 576); }   // >= 64 ntb and = 64 mod 256 (bank spread)
+// The A image's staging registers are v240 .. v255 BY NAME (set S, chunk i: v[240 + 8 S + 4 i ..+3]): between the load's issue and
+// its wait a whole stage passes, and a register the compiler knows as an asm OUTPUT is one it may copy or spill in that window --
+// before the data is there.  The kernel's allocatable registers end at v239 (amdgpu_num_vgpr), the asm statements name the rest.
+template <int S, int I>
+__device__ __forceinline__ void wg_load_a(const uint16_t *p) {
+    static_assert(S >= 0 && S < 2 && I >= 0 && I < 2, "two sets of two chunks");
+#define UCN_WG_LD(R0, R1, R2, R3) asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off" : : "v"(p) : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
+    if constexpr (S == 0 && I == 0) UCN_WG_LD(240, 241, 242, 243);
+    if constexpr (S == 0 && I == 1) UCN_WG_LD(244, 245, 246, 247);
+    if constexpr (S == 1 && I == 0) UCN_WG_LD(248, 249, 250, 251);
+    if constexpr (S == 1 && I == 1) UCN_WG_LD(252, 253, 254, 255);
+#undef UCN_WG_LD
+}
+template <int S, int I>
+__device__ __forceinline__ void wg_store_a(uint32_t lds_byte) {
+#define UCN_WG_ST(R0, R3) asm volatile("ds_write_b128 %0, v[" #R0 ":" #R3 "]" : : "v"(lds_byte) : "memory")
+    if constexpr (S == 0 && I == 0) UCN_WG_ST(240, 243);
+    if constexpr (S == 0 && I == 1) UCN_WG_ST(244, 247);
+    if constexpr (S == 1 && I == 0) UCN_WG_ST(248, 251);
+    if constexpr (S == 1 && I == 1) UCN_WG_ST(252, 255);
+#undef UCN_WG_ST
+}
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int NTB>
-__global__ __launch_bounds__(kWgThreads, 1) void k_wgrad_bf16(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_img[];       // [2 stages][A image | B image]
+__global__ __launch_bounds__(kWgThreads, 1) __attribute__((amdgpu_num_vgpr(240))) void k_wgrad_bf16(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_img[];       // [2][A image] [kWgBStages][B image]
+    constexpr int SB = wg_stride_b(NTB), kBImage = kWgRows * SB, kBInstr = kBImage / 1024;      // 2 / 10 / 18 DMA instructions per stage
+    constexpr int kBOff = 2 * kWgImage;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t KB = a.kb1 + a.kb2;
     const uint32_t row0 = blockIdx.x * a.rows_per_slab;
     const uint32_t row1 = row0 + a.rows_per_slab < a.M ? row0 + a.rows_per_slab : a.M;
     const uint32_t n_stage = row1 > row0 ? (row1 - row0 + kWgRows - 1) / kWgRows : 0;
-    // ---- this thread's 16-byte chunks of a stage: chunk q of the A image = (row q / ca, column chunk q % ca), then B's
-    const uint32_t ca = a.KA / 8, cb = KB / 8, cb1 = a.kb1 / 8;
-    const uint32_t n_chunks = kWgRows * (ca + cb);
-    constexpr int kPer = (kWgRows * (32 + 36) + kWgThreads - 1) / kWgThreads;       // 5: at most 256 + 288 columns
-    uint4 stage[kPer];
-    auto fetch = [&](uint32_t st) {
+    const uint32_t ca = a.KA / 8, cb = KB / 8, cb1 = a.kb1 / 8;            // 16-byte chunks per row of A / of B (first block)
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)s_img;
+    // ---- A: this thread's two chunks of a stage (chunk q = row q / ca, column chunk q % ca; a thread without one repeats the last)
+    const uint16_t *acol[2];
+    uint32_t arow[2], alds[2];
 #pragma unroll
-        for (int i = 0; i < kPer; i++) {
-            const uint32_t q = tid + i * kWgThreads;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < n_chunks) {
-                const bool isA = q < kWgRows * ca;
-                const uint32_t qq = isA ? q : q - kWgRows * ca;
-                const uint32_t per = isA ? ca : cb;
-                const uint32_t r = qq / per, c = qq - r * per;
-                const uint32_t m = row0 + st * kWgRows + r;
-                if (m < row1) {
-                    const uint16_t *p = isA ? a.A + (size_t)m * a.lda + 8u * c
-                                            : (c < cb1 ? a.B1 + (size_t)m * a.ldb1 + 8u * c : a.B2 + (size_t)m * a.ldb2 + 8u * (c - cb1));
-                    v = *reinterpret_cast<const uint4 *>(p);
-                }
+    for (int i = 0; i < 2; i++) {
+        uint32_t q = tid + i * kWgThreads;
+        q = q < kWgRows * ca ? q : kWgRows * ca - 1;
+        const uint32_t r = q / ca, c = q - r * ca;
+        arow[i] = r;
+        acol[i] = a.A + 8u * c;
+        alds[i] = r * kWgStride + 16u * c;
+    }
+    // ---- B: this wave's DMA instructions i = wave, wave + 8, ... < kBInstr; lane l of instruction i fills image bytes 1024 i + 16 l
+    constexpr int kBMine = (kBInstr + 7) / 8;                        // most instructions a wave issues per stage
+    const int nb = (kBInstr - wave + 7) / 8;                          // this wave's (uniform): kBMine or kBMine - 1
+    const uint16_t *bcol[kBMine];
+    uint32_t brow[kBMine], bld[kBMine];
+#pragma unroll
+    for (int k = 0; k < kBMine; k++) {
+        const uint32_t pbyte = 1024u * (wave + 8 * k) + 16u * lane;
+        const uint32_t r = (pbyte / SB) & 31u, c = (pbyte % SB) / 16u;
+        const uint32_t cc = c < cb ? c : 0u;                          // pad bytes of the row: its first chunk again
+        brow[k] = r;
+        bcol[k] = cc < cb1 ? a.B1 + 8u * cc : a.B2 + 8u * (cc - cb1);
+        bld[k] = cc < cb1 ? a.ldb1 : a.ldb2;
+    }
+    auto fetch_a = [&](auto setc, uint32_t st) {
+        constexpr int S = decltype(setc)::value;
+        sfor<2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint32_t m = row0 + st * kWgRows + arow[i];
+            wg_load_a<S, i>(acol[i] + (size_t)(m < a.M ? m : a.M - 1) * a.lda);
+        });
+    };
+    auto deposit_a = [&](auto setc, uint32_t st) {           // behind the hand-placed wait
+        constexpr int S = decltype(setc)::value;
+        sfor<2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint32_t l = (st & 1u) * kWgImage + alds[i];
+            wg_store_a<S, i>(lds0 + l);
+            // a row outside the slab (its last stage only): zeros over what was just written (same lane, LDS writes stay in order)
+            if (!(row0 + st * kWgRows + arow[i] < row1)) *reinterpret_cast<uint4 *>(s_img + l) = make_uint4(0, 0, 0, 0);
+        });
+    };
+    auto issue_b = [&](uint32_t st) {
+        const uint32_t img = lds0 + kBOff + (st % kWgBStages) * kBImage;
+#pragma unroll
+        for (int k = 0; k < kBMine; k++) {
+            if (k < nb) {
+                const uint32_t m = row0 + st * kWgRows + brow[k];
+                const uint16_t *g = bcol[k] + (size_t)(m < a.M ? m : a.M - 1) * bld[k];
+                const uint32_t l = img + 1024u * (wave + 8 * k);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(l), "v"(g) : "memory");
             }
-            stage[i] = v;
         }
     };
-    auto deposit = [&](int buf) {
+    // rows of B(st) outside the slab (a slab's last stage only): zeroed by the lane that loaded them, after they have landed
+    auto zero_b = [&](uint32_t st) {
+        const uint32_t valid = row1 - (row0 + st * kWgRows);
+        if (valid >= kWgRows) return;
+        uint8_t *img = s_img + kBOff + (st % kWgBStages) * kBImage;
 #pragma unroll
-        for (int i = 0; i < kPer; i++) {
-            const uint32_t q = tid + i * kWgThreads;
-            if (q < n_chunks) {
-                const bool isA = q < kWgRows * ca;
-                const uint32_t qq = isA ? q : q - kWgRows * ca;
-                const uint32_t per = isA ? ca : cb;
-                const uint32_t r = qq / per, c = qq - r * per;
-                *reinterpret_cast<uint4 *>(s_img + buf * 2 * kWgImage + (isA ? 0 : kWgImage) + r * kWgStride + 16u * c) = stage[i];
-            }
-        }
+        for (int k = 0; k < kBMine; k++)
+            if (k < nb && brow[k] >= valid) *reinterpret_cast<uint4 *>(img + 1024u * (wave + 8 * k) + 16u * lane) = make_uint4(0, 0, 0, 0);
     };
+    // at most (B(st + 2), A(st + 2), B(st + 3)) of this wave outstanding = everything up to A(st + 1) has landed
+    auto wait_stage = [&]() {
+        if (nb == kBMine) wg_wait_vm<2 * kBMine + 2>();
+        else wg_wait_vm<2 * (kBMine - 1) + 2>();
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     f32x16 acc[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; t++) zero_acc(acc[t]);
     const bool active = 32u * wave < a.KA;                          // waves beyond the A columns only help with the loads
     // lane part of the transposed reads: row 8 g + (j & 15) / 4, column chunk (4 (j & 3) + 16 ((j >> 4) & 1)) elements
     const uint32_t j = lane & 31, g = lane >> 5;
-    const uint32_t lane_off = (8u * g + ((j & 15u) >> 2)) * kWgStride + (4u * (j & 3u) + 16u * ((j >> 4) & 1u)) * 2u;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)s_img;
-    if (n_stage) {
-        fetch(0);
-        deposit(0);
-    }
-    __syncthreads();
-    for (uint32_t st = 0; st < n_stage; st++) {
-        const int buf = st & 1;
-        if (st + 1 < n_stage) fetch(st + 1);                         // next stage's global loads fly under this stage's MFMAs
+    const uint32_t lrow = 8u * g + ((j & 15u) >> 2), lcol = (4u * (j & 3u) + 16u * ((j >> 4) & 1u)) * 2u;
+    const uint32_t lane_a = lrow * kWgStride + lcol, lane_b = lrow * SB + lcol;
+    auto compute = [&](uint32_t st) {
         if (active) {
-            const uint32_t abase = lds0 + buf * 2 * kWgImage + lane_off + 64u * wave;       // A columns 32 w ..
-            const uint32_t bbase = lds0 + buf * 2 * kWgImage + kWgImage + lane_off;
+            const uint32_t abase = lds0 + (st & 1u) * kWgImage + lane_a + 64u * wave;       // A columns 32 w ..
+            const uint32_t bbase = lds0 + kBOff + (st % kWgBStages) * kBImage + lane_b;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                const uint32_t ro = ks * 16 * kWgStride;
-                const uint64_t a_lo = tr_read(abase + ro), a_hi = tr_read(abase + ro + 4 * kWgStride);
+                const uint64_t a_lo = tr_read(abase + ks * 16 * kWgStride), a_hi = tr_read(abase + ks * 16 * kWgStride + 4 * kWgStride);
                 uint64_t b_lo[NTB], b_hi[NTB];
 #pragma unroll
                 for (int t = 0; t < NTB; t++) {
-                    b_lo[t] = tr_read(bbase + ro + 64u * t);
-                    b_hi[t] = tr_read(bbase + ro + 64u * t + 4 * kWgStride);
+                    b_lo[t] = tr_read(bbase + ks * 16 * SB + 64u * t);
+                    b_hi[t] = tr_read(bbase + ks * 16 * SB + 64u * t + 4 * SB);
                 }
                 // the reads above are inline asm: the compiler does not count them.  One wait, then every value is passed through
                 // an (ordered) empty asm so that no MFMA can be scheduled in front of the wait.
@@ -135,10 +203,36 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wgrad_bf16(WgradArgs a) {
                 }
             }
         }
-        // buffer buf ^ 1 was last read in the previous iteration, in front of its barrier: it can be refilled right away;
-        // the barrier below publishes it and ends everybody's reads of `buf`
-        if (st + 1 < n_stage) deposit(buf ^ 1);
-        __syncthreads();
+    };
+    // one stage: [issue A(st + 2), B(st + 3)] [MFMAs of st] [A(st + 1) -> LDS, B(st + 1) checked] barrier.  The barrier publishes
+    // stage st + 1 and ends everybody's reads of stage st, whose buffers (A: st & 1, B: st % 4) the next iteration's issues refill.
+    auto step = [&](auto cur, auto nxt, uint32_t st) {
+        fetch_a(cur, st + 2);                   // set `cur` held A(st), deposited one iteration ago
+        issue_b(st + 3);
+        compute(st);                            // (nothing may sit between its operand reads and their wait: the reads' targets are
+        //                                         registers the compiler believes written, and under pressure it would move them)
+        wait_stage();
+        deposit_a(nxt, st + 1);
+        zero_b(st + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    if (n_stage) {
+        issue_b(0);
+        fetch_a(S0{}, 0);
+        issue_b(1);
+        fetch_a(S1{}, 1);
+        issue_b(2);
+        // A(0) and B(0): everything but (B(1), A(1), B(2)) has landed
+        if (nb == kBMine) wg_wait_vm<2 * kBMine + 2>();
+        else wg_wait_vm<2 * (kBMine - 1) + 2>();
+        deposit_a(S0{}, 0);
+        zero_b(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (uint32_t st = 0; st < n_stage; st += 2) {
+            step(S0{}, S1{}, st);
+            if (st + 1 < n_stage) step(S1{}, S0{}, st + 1);
+        }
+        wg_wait_vm<0>();                        // nothing of mine may land in LDS after I am gone
     }
     // ---- partial C of this slab: acc[t] register r of lane (j, g) = C[32 w + (r & 3) + 8 (r >> 2) + 4 g][32 t + j]
     if (active) {
@@ -201,7 +295,7 @@ extern "C" int ucn_wgrad_bf16(const void *A, uint32_t lda, uint32_t KA, const vo
     const uint32_t rows_per_slab = (stages + slabs - 1) / slabs * kWgRows;
     const uint32_t used = (uint32_t)((M + rows_per_slab - 1) / rows_per_slab);
     WgradArgs a{(const uint16_t *)A, (const uint16_t *)B1, (const uint16_t *)B2, lda, ldb1, ldb2, KA, kb1, kb2, (uint32_t)M, rows_per_slab, workspace};
-    const size_t lds = 2 * 2 * kWgImage;
+    const size_t lds = 2 * kWgImage + (size_t)kWgBStages * kWgRows * wg_stride_b((int)(KB / 32));
     switch (KB / 32) {
 #define UCN_WG(N) case N: hipLaunchKernelGGL(k_wgrad_bf16<N>, dim3(used), dim3(kWgThreads), lds, st, a); break;
         UCN_WG(1) UCN_WG(2) UCN_WG(3) UCN_WG(4) UCN_WG(5) UCN_WG(6) UCN_WG(7) UCN_WG(8) UCN_WG(9)
