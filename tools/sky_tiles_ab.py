@@ -3,6 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import raymarch as rm
+from ucnerf_amd import _lib
+if os.environ.get("UCN_TOOL_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["UCN_TOOL_LIB"])
 from ucnerf_amd.internal import train_graph as tg
 from ucnerf_amd.internal.sky import NeRF
 
@@ -17,7 +20,8 @@ rays = rm.synthetic_rays(n, seed=12)
 o, d, cam = (rays[k].cuda() for k in ("origins", "directions", "cam_dirs"))
 far = rays["far"].cuda()
 got = {}
-for tiles in ("1", "2"):
+for tag in ("1a", "2a", "1b", "2b", "1c", "2c"):
+    tiles = tag[0]
     os.environ["UCN_SKY_FWD_TILES"] = tiles
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = tg.sky_forward_fused(net, o, d, cam, far)
@@ -26,8 +30,10 @@ for tiles in ("1", "2"):
     while fn is not None and "SkyFused" not in type(fn).__name__:
         fn = fn.next_functions[0][0] if fn.next_functions else None
     packed, raw, d_, far_, act, mask, mask_v = fn.saved_tensors
-    got[tiles] = dict(out=out.detach().float().clone(), raw=raw.clone(), act=act.float().clone(), mask=mask.clone(), mask_v=mask_v.clone())
-a, b = got["1"], got["2"]
+    got[tag] = dict(out=out.detach().float().clone(), raw=raw.clone(), act=act.float().clone(), mask=mask.clone(), mask_v=mask_v.clone())
+for x, y in (("1a", "1b"), ("1a", "1c"), ("2a", "2b"), ("2a", "2c"), ("1a", "2a")):
+    print(x, y, {k: int((got[x][k][..., :2208] != got[y][k][..., :2208]).sum()) if k == "act" else int((got[x][k] != got[y][k]).sum()) for k in got[x]})
+a, b = got["1a"], got["2a"]
 ld = a["act"].shape[1]
 print("act ld", ld, "M", a["act"].shape[0])
 for k in ("out", "raw"):

@@ -68,21 +68,13 @@ __device__ __forceinline__ void sfor(F &&f) { sfor_impl(std::make_integer_sequen
 // P output tiles (a PAIR, or one) from NT_IN input tiles: acc[o2] += A(frag) . in[it][s], fragments [it][s][o2] from
 // stream position G0.  The two tiles of a pair alternate (two MFMAs into the same accumulator do not issue back to
 // back); only the pair's 32 accumulator registers are live, the caller converts / stores it before the next pair.
-// SC::before(G) = vector-memory STORE instructions the wave has issued (at least; since ring_start) before the MFMA of stream position G:
-// the ring's chunk boundaries then let exactly those that are younger than the awaited chunk stay in flight (Ring::boundary, EXTRA)
-struct NoStoreCount { static constexpr int before(int) { return 0; } };
-template <int P, int NT_IN, int G0, class SC = NoStoreCount, class RING>
+template <int P, int NT_IN, int G0, class RING>
 __device__ __forceinline__ void tile_pair(RING &ring, f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
         constexpr int CH = RING::kChunk, NW = RING::kWaves;     // a wave issues one DMA piece per NW fragments
-        if constexpr (G % CH == 0 && G / CH >= 1) {
-            // the last piece of chunk G / CH was issued in front of the MFMA of position Gp (or by ring_start)
-            constexpr int c = G / CH, Gp = (c - RING::kLeadChunks) * CH + CH - NW;
-            constexpr int extra = SC::before(G) - (c >= RING::kLeadChunks ? SC::before(Gp) : 0);
-            ring.template boundary<c, extra>();
-        }
+        if constexpr (G % CH == 0 && G / CH >= 1) ring.template boundary<G / CH>();
         if constexpr (G % NW == 0) ring.template piece<G / CH + RING::kLeadChunks, (G % CH) / NW>();
         acc[o2] = mfma_bf(__builtin_bit_cast(bf8, ring.template group<G>()), in[it][s], acc[o2]);
         // one operand read per MFMA: left alone, the scheduler hoists a chunk's sixteen reads (64 registers) to its start
@@ -126,17 +118,12 @@ __device__ __forceinline__ bf8 to_agpr(bf8 v) {
     return v;
 }
 constexpr int kWAhead = 3;                  // weight fragments requested ahead of their MFMAs (4 register slots)
-// request fragment GF: the ring's housekeeping rides on the requests (as pipe_fetch of mlp_ring.h).  It executes in front of the
-// MFMAs of position GF - kWAhead, so the activation stores issued before it are SC::before(GF - kWAhead).
-template <int GF, int NG, class SC, class RING>
+// request fragment GF: the ring's housekeeping rides on the requests (as pipe_fetch of mlp_ring.h)
+template <int GF, int NG, class RING>
 __device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[4]) {
     if constexpr (GF < NG) {
         constexpr int CH = RING::kChunk, NW = RING::kWaves;
-        if constexpr (GF % CH == 0 && GF / CH >= 1) {
-            constexpr int c = GF / CH, Gp = (c - RING::kLeadChunks) * CH + CH - NW;
-            constexpr int extra = SC::before(GF - kWAhead) - (c >= RING::kLeadChunks ? SC::before(Gp - kWAhead) : 0);
-            ring.template boundary<c, extra>();
-        }
+        if constexpr (GF % CH == 0 && GF / CH >= 1) ring.template boundary<GF / CH>();
         if constexpr (GF % NW == 0) ring.template piece<GF / CH + RING::kLeadChunks, (GF % CH) / NW>();
         wp[GF % 4] = __builtin_bit_cast(bf8, ring.template group<GF>());
     }
@@ -145,24 +132,24 @@ __device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[4]) {
 // read the SAME four registers -- read, wait for it, MFMA: with one wave per SIMD the LDS latency stands in front of every MFMA (a pair's
 // 32 MFMAs took ~1900 cycles instead of 1024).  Here fragment G + kWAhead is requested in front of the MFMA of G (program order pinned
 // by a scheduling barrier per step), the pipe lives across pairs and layers.
-template <int P, int NT_IN, int G0, int NG, class SC, class RING>
+template <int P, int NT_IN, int G0, int NG, class RING>
 __device__ __forceinline__ void tile_pair_pf(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
-        frag_fetch<G + kWAhead, NG, SC>(ring, wp);
+        frag_fetch<G + kWAhead, NG>(ring, wp);
         acc[o2] = mfma_bf(wp[G % 4], in[it][s], acc[o2]);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 // acc{0,1}[o2] (+)= A(frag) . in{0,1}: tiles 0..7 of the input from in (class INA), tile 8 (NT_IN = 9) = the per-ray tile, always AGPRs
-template <int NT_IN, int G0, int NG, bool INA, bool ZERO, class SC, class RING>
+template <int NT_IN, int G0, int NG, bool INA, bool ZERO, class RING>
 __device__ __forceinline__ void tile_pair2(RING &ring, bf8 (&wp)[4], f32x16 (&acc0)[2], f32x16 (&acc1)[2], const bf8 (&in0)[8][2],
                                            const bf8 (&in1)[8][2], const bf8 (&aux0)[2], const bf8 (&aux1)[2]) {
     sfor<NT_IN * 4>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % 2, s = (I / 2) % 2, it = I / 4;
-        frag_fetch<G + kWAhead, NG, SC>(ring, wp);
+        frag_fetch<G + kWAhead, NG>(ring, wp);
         if constexpr (it < 8) {
             if constexpr (ZERO && I < 2) {
                 mfma_bf_cls_first<INA>(acc0[o2], wp[G % 4], in0[it][s]);

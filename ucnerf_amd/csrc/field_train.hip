@@ -68,7 +68,7 @@ constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;    
 using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
 template <int P, int NT_IN, int G0, int NG, class RING>
 __device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
-    if constexpr (UCN_TRAIN_PIPE != 0) tile_pair_pf<P, NT_IN, G0, NG, NoStoreCount>(ring, wp, acc, in);
+    if constexpr (UCN_TRAIN_PIPE != 0) tile_pair_pf<P, NT_IN, G0, NG>(ring, wp, acc, in);
     else tile_pair<P, NT_IN, G0>(ring, acc, in);
 }
 
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 4 * P2;
     constexpr int NGF = G3 + 4 * (P3 + 4);                 // fragments this kernel consumes
     bf8 wp[4];                                             // fragment pipe
-    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF, NoStoreCount>(ring, wp); });
+    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF>(ring, wp); });
     // ---- density layer 0
     bf8 hin[10 + NA][2];                   // tiles 0..7: h1 (filled below), 8..9: h0, (10: the ray's direction tile)
     bf8 (&h0)[2][2] = reinterpret_cast<bf8(&)[2][2]>(hin[8]);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
     constexpr int H1 = 16, H2 = H1 + 128, H4 = H2 + 4 * 72;
     constexpr int NGF = H4 + 4 * NTF;                      // fragments this kernel consumes
     bf8 wp[4];                                             // fragment pipe
-    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF, NoStoreCount>(ring, wp); });
+    if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF>(ring, wp); });
     bf8 din[16][2];                          // tiles 0..7: d1, 8..15: d0  (the order of [W1x^T | W0x^T])
     // ---- through the rgb layer and the second hidden layer's ReLU
     sfor<4>([&](auto pp) {

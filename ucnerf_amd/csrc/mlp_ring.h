@@ -188,14 +188,12 @@ struct Ring {
         rstatic_for<kPiecesPerChunk>([&](auto i) { piece<C, i.value>(); });
     }
     // first read of chunk C: everything up to and including chunk C has landed for every wave.
-    // EXTRA (r05): vector-memory instructions OTHER than this ring's DMA that the wave is known to have issued AFTER the last piece of
-    // chunk C (activation stores of a training kernel).  vmcnt counts stores too and retires in issue order, so "chunk C has landed"
-    // is "at most (later pieces + EXTRA) operations outstanding".  Without it the wait also drains those stores -- each a ~1 us
-    // round trip to L2 -- at every chunk boundary (every ~0.2 us): the sky training kernels spent their whole duration there.  A LOWER
-    // bound is safe (a smaller count only waits longer); the counter is 6 bits.
-    bool count_stores = true;   // wave-uniform: false for a wave whose tile is ragged or dead -- its conditional stores may not issue,
-    //                             the EXTRA count would then let the wave pass before its DMA pieces have landed
-    template <int C, int EXTRA = 0>
+    // (r05 tried counting the wave's activation STORES that are younger than chunk C into the allowed number -- vmcnt counts stores too --
+    // so that the wait would not drain them.  Once the fragment pipe was in (bf_tiles.h tile_pair_pf) it bought nothing (sky forward 1.31
+    // against 1.29 ms without), and it is NOT safe: it needs stores to retire in issue order with the LDS-DMA loads, and the two-tile sky
+    // kernel -- 8 stores per pair, the last chunks awaited with no later pieces as slack -- read fragments that had not landed
+    // (non-reproducible outputs, profiles/r05/sky_train_variants.txt).  The wait below counts this ring's DMA instructions only.)
+    template <int C>
     __device__ __forceinline__ void boundary() {
         // DMA instructions of this wave that may still be in flight: those of the chunks behind C that have been
         // issued so far, i.e. chunks C+1 .. C+kLead-1 (chunk C+kLead is issued while C is read)
@@ -209,13 +207,7 @@ struct Ring {
             static_assert(STAGE <= (LEAD - 1) * kPiecesPerChunk, "staged pieces would be written after they are needed");
             if constexpr (C == 0) ring_wait_lds<0>();
         } else {
-            constexpr int allowed = later * kPiecesPerChunk + (EXTRA > 0 ? EXTRA : 0);
-            if constexpr (EXTRA > 0) {
-                if (count_stores) ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
-                else ring_wait_vm<later * kPiecesPerChunk>();
-            } else {
-                ring_wait_vm<(allowed > 63 ? 63 : allowed)>();
-            }
+            ring_wait_vm<later * kPiecesPerChunk>();
         }
         // bare barrier: __syncthreads() adds a fence whose lgkmcnt(0) would drain the operand pipe.  LDS is coherent
         // within the CU and every wave has waited for its own DMA; the slot being refilled was last read a chunk ago.

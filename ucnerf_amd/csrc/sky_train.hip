@@ -93,22 +93,6 @@ struct SkyTrainArgs {
 // sky_far = 1.5 * near[0] with near = batch.far (models.py:328-330), read on the device: no host sync in the step
 __device__ __forceinline__ float inv_sky_far_of(const float *far_) { return 1.0f / (1.5f * far_[0]); }
 
-// activation stores of the forward kernel in stream order: every output PAIR of a hidden layer ends with store_pair = 4 global stores
-// (layers 1..7: four pairs each at kFL[li] + (pr + 1) * 4 NT_IN; views layer: two pairs of 36 fragments).  Layer 0's stores and the
-// per-layer mask stores are not counted (a lower bound is safe, see Ring::boundary).
-struct FwdStores {
-    static constexpr int before(int G) {
-        int n = 0;
-        for (int li = 0; li < 7; li++) {
-            const int nt = li == 4 ? 9 : 8;
-            for (int pr = 0; pr < 4; pr++) n += (kFL[li] + (pr + 1) * nt * 4 <= G) ? 4 : 0;
-        }
-        for (int pr = 0; pr < 2; pr++) n += (kFV + (pr + 1) * 36 <= G) ? 4 : 0;
-        return n;
-    }
-};
-
-struct FwdStoresNeg { static constexpr int before(int G) { return G < 0 ? 0 : FwdStores::before(G); } };
 constexpr int kFwdFrags = kFV + 72;              // fragments the forward chain consumes
 // UCN_SKY_FWD_PIPE: fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
 #ifndef UCN_SKY_FWD_PIPE
@@ -121,16 +105,21 @@ __device__ __forceinline__ bf8 (&pick9(bf8 (&a)[9][2], bf8 (&b)[9][2]))[9][2] {
 }
 
 // UCN_SKY_FWD_OCC: workgroups per CU the register budget of the forward kernel is cut for (build knob, tools/build_variant.sh).
-// r05: ONE.  At two per CU (256 registers) the kernel spilled 190 registers to scratch (in + out activation tiles 136, a pair's
-// accumulators 32, the store's lane-swap temporaries 32, ring + geometry ~30), and every scratch reload made the compiler put
+// r05: ONE.  At two per CU (256 registers) the kernel spilled 190 registers to scratch, and every scratch reload made the compiler put
 // `s_waitcnt vmcnt(0)` in front of it (96 inside the chain) -- each draining the weight stream's look-ahead: 2.39 ms.  One workgroup
-// per CU with the whole register file: no scratch, 1.89 ms; + a 6-slot ring requested 4 chunks ahead, the chunk waits counting the
-// activation stores that are younger than the awaited chunk (Ring::boundary EXTRA), and the pairs stored through LDS as whole lines
-// (store_pair_staged): 1.79 ms (profiles/r05/sky_train_variants.txt).  Measured and NOT kept: an 8-slot ring 6 ahead (1.83), a
-// per-layer [M, 256] activation layout (1.79: DRAM page locality is not it), 8-wave workgroups sharing one ring in the backward
-// (2.06 against 1.81), the register-staged weight stream instead of LDS-DMA (2.8).  Without its activation stores the kernel takes
-// 1.29 ms, and its counters (profiles/r05/pmc_sky.txt) show the texture-data path busy 99 % of the duration at 18 % MFMA-busy: the
-// LDS-DMA weight stream (1 MB per 128 samples; ~25 GB/s per CU is what that path lands) shares it with the stores.
+// per CU with the whole register file, a 6-slot ring requested 4 chunks ahead, the pairs stored through LDS as whole lines
+// (store_pair_staged): 1.79 ms.  Then the two changes that mattered (profiles/r05/sky_train_variants.txt):
+//   * with ONE wave per SIMD every instruction is an issue slot nobody else fills, and the chain was "ds_read the fragment, wait for
+//     it, MFMA" with the same four registers for every fragment -- the LDS latency in front of each of the 984 MFMAs.  The fragment
+//     pipe (bf_tiles.h tile_pair_pf: three requests ahead, order pinned per step): 1.56 -> 1.27 ms;
+//   * hipcc's default keeps MFMA accumulators in AGPRs, which only MFMAs can touch: each value the epilogue converts / masks costs a
+//     v_accvgpr_read first -- 1984 of 11317 instructions per wave.  -mllvm -amdgpu-mfma-vgpr-form (build.sh): 1.80 -> 1.60 ms.
+// Measured and NOT kept: an 8-slot ring 6 ahead (1.83 before the pipe), a per-layer [M, 256] activation layout (no change: DRAM page
+// locality is not it), 8-wave workgroups sharing one ring (1.50 against 1.29 with the pipe), two workgroups per CU on a 3-slot ring
+// (1.92), the register-staged weight stream instead of LDS-DMA (2.8), chunk waits that count the younger stores (nothing once the
+// pipe was in, and unsafe: mlp_ring.h boundary), two sample tiles per wave (k_sky_train_fwd2 below: 1.92).  Without its activation
+// stores the kernel takes 1.16 ms: 9.5 k instructions per wave and 32 samples against 984 MFMAs -- on this part VALU / scalar issue
+// adds to MFMA time (DESIGN.md "Execution model of a gfx950 SIMD"), so what is left is instruction count.
 #ifndef UCN_SKY_FWD_OCC
 #define UCN_SKY_FWD_OCC 1
 #endif
@@ -177,7 +166,6 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
     store_tile(row + kActAux, kActLd, b, 0, h, XA[8], live);
 
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
-    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
         const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
         const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
@@ -225,7 +213,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
 
     constexpr bool kPipe = UCN_SKY_FWD_PIPE;
     bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
-    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags, FwdStoresNeg>(ring, wp); });
+    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags>(ring, wp); });
     float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;
     sfor<7>([&](auto lic) {
@@ -243,8 +231,8 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
                 zero_acc(cur[0]);
                 zero_acc(cur[1]);
             }
-            if constexpr (kPipe) tile_pair_pf<2, NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags, FwdStoresNeg>(ring, wp, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
-            else tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4, FwdStores>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            if constexpr (kPipe) tile_pair_pf<2, NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags>(ring, wp, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
+            else tile_pair<2, NT_IN, kFL[li] + pr * NT_IN * 4>(ring, cur, reinterpret_cast<const bf8(&)[NT_IN][2]>(in));
             if constexpr (li == 6) {                              // alpha head on the fp32 ReLU output of layer 7
                 alpha_partial<2 * pr, 0>(cur[0], pa, sig);
                 alpha_partial<2 * pr, 1>(cur[0], pa, sig);
@@ -281,8 +269,8 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
         f32x16 v[2];
         zero_acc(v[0]);
         zero_acc(v[1]);
-        if constexpr (kPipe) tile_pair_pf<2, 9, kFV + pr * 36, kFwdFrags, FwdStoresNeg>(ring, wp, v, h7);
-        else tile_pair<2, 9, kFV + pr * 36, FwdStores>(ring, v, h7);
+        if constexpr (kPipe) tile_pair_pf<2, 9, kFV + pr * 36, kFwdFrags>(ring, wp, v, h7);
+        else tile_pair<2, 9, kFV + pr * 36>(ring, v, h7);
         bf8 hv[2][2];
 #pragma unroll
         for (int o = 0; o < 2; o++) {
@@ -313,7 +301,6 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
 //   AGPRs: activation buffer A of both tiles (128) + the per-ray tiles (16) + a pair's accumulators (64)
 //   VGPRs: activation buffer B of both tiles (128) + the fragment pipe (16) + epilogue temporaries
 // Layer li reads A and writes B (li even) or reads B and writes A (li odd; the VALU's results are moved over, 128 v_accvgpr_write).
-struct FwdStores2 { static constexpr int before(int G) { return G < 0 ? 0 : 2 * FwdStores::before(G); } };
 #ifndef UCN_SKY_FWD_TILES
 #define UCN_SKY_FWD_TILES 1
 #endif
@@ -361,7 +348,6 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
         AUX[st][1] = to_agpr(t[1]);
     }
     STRing ring(reinterpret_cast<const float *>(a.packed), s_w, lane, wave);
-    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows[0]) == 32u && __builtin_amdgcn_readfirstlane(n_rows[1]) == 32u;
     {   // side table: 14 pieces of 1 KiB, DMA'd once, ahead of the ring's chunks (vmcnt completes in order)
         const uint32_t lside = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)s_w + (uint32_t)(kFwdSlots * kTChunk) * 1024u;
         const float *gside = reinterpret_cast<const float *>(a.packed + kPkSide);
@@ -418,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
     }
 
     bf8 wp[4];
-    sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags, FwdStores2>(ring, wp); });
+    sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags>(ring, wp); });
     float sig[2] = {0.0f, 0.0f};                                  // alpha head partials (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;
     sfor<7>([&](auto lic) {
@@ -442,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
             } else {
                 asm volatile("s_nop 7");
             }
-            tile_pair2<NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags, INA, ZERO, FwdStores2>(ring, wp, c0, c1, in0, in1, AUX[0], AUX[1]);
+            tile_pair2<NT_IN, kFL[li] + pr * NT_IN * 4, kFwdFrags, INA, ZERO>(ring, wp, c0, c1, in0, in1, AUX[0], AUX[1]);
             pair_settle(c0, c1);
             sfor<2>([&](auto stc) {
                 constexpr int st = stc.value;
@@ -480,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
         constexpr int pr = pc.value;
         f32x16 v0[2], v1[2];
         asm volatile("s_nop 7");
-        tile_pair2<9, kFV + pr * 36, kFwdFrags, false, true, FwdStores2>(ring, wp, v0, v1, XB[0], XB[1], AUX[0], AUX[1]);
+        tile_pair2<9, kFV + pr * 36, kFwdFrags, false, true>(ring, wp, v0, v1, XB[0], XB[1], AUX[0], AUX[1]);
         pair_settle(v0, v1);
         sfor<2>([&](auto stc) {
             constexpr int st = stc.value;
@@ -537,18 +523,6 @@ struct SkyTrainBwdArgs {
 #ifndef UCN_SKY_BWD_STAGED
 #define UCN_SKY_BWD_STAGED (UCN_SKY_BWD_OCC == 1)
 #endif
-// gradient-tile stores of the backward kernel in stream order: 4 per pair (staged or per lane alike)
-struct BwdStores {
-    static constexpr int before(int G) {
-        if (G < 0) return 0;
-        int n = 0;
-        for (int pr = 0; pr < 2; pr++) n += (kGV + 4 * (pr + 1) <= G) ? 4 : 0;
-        for (int pr = 0; pr < 4; pr++) n += (kG7 + 20 * (pr + 1) <= G) ? 4 : 0;
-        for (int q = 1; q < 8; q++)
-            for (int pr = 0; pr < 4; pr++) n += (kGL + 128 * (q - 1) + 32 * (pr + 1) <= G) ? 4 : 0;
-        return n;
-    }
-};
 __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 : UCN_SKY_BWD_OCC) void k_sky_train_bwd(SkyTrainBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];   // weight ring [+ one staging tile per wave]
     constexpr bool kPipe = UCN_SKY_BWD_PIPE, kStaged = UCN_SKY_BWD_STAGED, kPreMask = UCN_SKY_BWD_OCC == 1;
@@ -574,7 +548,6 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     SBRing ring(reinterpret_cast<const float *>(a.packed + kPkBwd), s_w, lane, wave);
-    ring.count_stores = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
     ring_start(ring);
     // ---- the head gradients as one input tile: columns 0..3 = d logits (r, g, b), d sigma -- registers 0..3 of wave half 0
     //      in accumulator order and in natural order alike
@@ -589,14 +562,14 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
     }
     ring.template boundary<0>();
     bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
-    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kTrFrags, BwdStores>(ring, wp); });
+    if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kTrFrags>(ring, wp); });
     // ---- through the rgb layer and the views layer's ReLU
     sfor<2>([&](auto pc) {
         constexpr int pr = pc.value;
         f32x16 acc[2];
         zero_acc(acc[0]);
         zero_acc(acc[1]);
-        if constexpr (kPipe) tile_pair_pf<2, 1, kGV + 4 * pr, kTrFrags, BwdStores>(ring, wp, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
+        if constexpr (kPipe) tile_pair_pf<2, 1, kGV + 4 * pr, kTrFrags>(ring, wp, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
         else tile_pair<2, 1, kGV + 4 * pr>(ring, acc, reinterpret_cast<const bf8(&)[1][2]>(dv[4]));
         const uint32_t mw = pr == 0 ? mv.x : mv.y;
 #pragma unroll
@@ -624,8 +597,8 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
             zero_acc(acc[0]);
             zero_acc(acc[1]);
             if constexpr (kPipe) {
-                if constexpr (q == 0) tile_pair_pf<2, 5, kG7 + 20 * pr, kTrFrags, BwdStores>(ring, wp, acc, dv);
-                else tile_pair_pf<2, 8, kGL + 128 * (q - 1) + 32 * pr, kTrFrags, BwdStores>(ring, wp, acc, pick8<(q + 1) % 2>(DA, DB));
+                if constexpr (q == 0) tile_pair_pf<2, 5, kG7 + 20 * pr, kTrFrags>(ring, wp, acc, dv);
+                else tile_pair_pf<2, 8, kGL + 128 * (q - 1) + 32 * pr, kTrFrags>(ring, wp, acc, pick8<(q + 1) % 2>(DA, DB));
             } else {
                 if constexpr (q == 0) tile_pair<2, 5, kG7 + 20 * pr>(ring, acc, dv);
                 else tile_pair<2, 8, kGL + 128 * (q - 1) + 32 * pr>(ring, acc, pick8<(q + 1) % 2>(DA, DB));
