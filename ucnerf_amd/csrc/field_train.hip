@@ -45,6 +45,12 @@ struct TrainFwdArgs {
 };
 
 
+// UCN_TRAIN_OCC: workgroups per CU both kernels are cut for (build knob); the ring follows it (two per CU: 4 x 16 KiB, 2 chunks ahead;
+// one per CU: 6 x 16 KiB, 4 ahead)
+#ifndef UCN_TRAIN_OCC
+#define UCN_TRAIN_OCC 2
+#endif
+constexpr int kFtSlots = UCN_TRAIN_OCC == 1 ? 6 : kTSlots, kFtLead = UCN_TRAIN_OCC == 1 ? 4 : kTLead;
 // UCN_TRAIN_PIPE (r05): weight fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
 #ifndef UCN_TRAIN_PIPE
 #define UCN_TRAIN_PIPE 1
@@ -61,11 +67,11 @@ struct TrainFwdArgs {
 // both kernels spent 75 % of their wave-cycles waiting (profiles/r02c/pmc_table_train.txt).
 constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
 constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
-using TRing = Ring<kFragsPadded, kTChunk, 4, kTSlots, kTLead>;                            // the backward's stream
+using TRing = Ring<kFragsPadded, kTChunk, 4, kFtSlots, kFtLead>;                            // the backward's stream
 // the forward's stream (composed colour layers, see k_train_fwd): 2 NTF 2 + 32 + 32 + 4 (40 + 4) = 244 / 248 fragments
 constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 4 * 12 + 4 * 48;     // with the direction tile in the stream (inference): 276 / 280
 constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 288
-using FRing = Ring<kFwdPadded, kTChunk, 4, kTSlots, kTLead>;
+using FRing = Ring<kFwdPadded, kTChunk, 4, kFtSlots, kFtLead>;
 template <int P, int NT_IN, int G0, int NG, class RING>
 __device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     if constexpr (UCN_TRAIN_PIPE != 0) tile_pair_pf<P, NT_IN, G0, NG>(ring, wp, acc, in);
@@ -74,7 +80,7 @@ __device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (
 
 
 #ifndef UCN_TRAIN_FWD_WGS
-#define UCN_TRAIN_FWD_WGS 2
+#define UCN_TRAIN_FWD_WGS UCN_TRAIN_OCC
 #endif
 // AUX (inference with rays-fastest lanes): the per-ray direction term is NOT pre-multiplied by the caller (pr0 / pr1 would
 // be 2 KiB per LANE there, 64 KiB of loads per wave); the ray's 32-column tile [dir_enc (27), 1, 0...] (a.ray_cols) enters
@@ -87,7 +93,7 @@ __device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (
 #endif
 constexpr int kInferWaves = UCN_INFER_WAVES;
 using IRing = Ring<(kFwdFragsMax + 2 * kInferWaves - 1) / (2 * kInferWaves) * (2 * kInferWaves), kInferWaves == 4 ? kTChunk : 2 * kInferWaves,
-                   kInferWaves, kTSlots, kTLead>;
+                   kInferWaves, kFtSlots, kFtLead>;
 static_assert(IRing::kChunks * IRing::kChunk <= kFwdPadded, "the packed forward stream is padded to kFwdPadded fragments");
 template <bool AUX> struct FwdShape { using ring = FRing; static constexpr int waves = 4, wgs = UCN_TRAIN_FWD_WGS; };
 template <> struct FwdShape<true> { using ring = IRing; static constexpr int waves = kInferWaves, wgs = kInferWaves == 4 ? 2 : 1; };
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     ring_start(ring);
     const float *side_b0 = nullptr, *side_b1 = nullptr, *side_p0 = nullptr, *side_p1 = nullptr;
     if constexpr (SIDE) {
-        float4 *side = reinterpret_cast<float4 *>(s_w + kTSlots * kTChunk * 256);
+        float4 *side = reinterpret_cast<float4 *>(s_w + kFtSlots * kTChunk * 256);
         if (threadIdx.x < 16) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d0)[threadIdx.x];
         else if (threadIdx.x < (uint32_t)kSideBias) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d1)[threadIdx.x - 16];
         const uint32_t w0 = (blockIdx.x * 4u + wave) * 32u;                                     // the wave's first sample: its ray is every lane's
@@ -332,7 +338,7 @@ struct TrainBwdArgs {
 
 
 template <int NTF>
-__global__ __launch_bounds__(256, 2) void k_train_bwd(TrainBwdArgs a) {
+__global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -509,7 +515,7 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
     const dim3 grid(ucn_div_up(M, 128));
-    const size_t lds = kTSlots * kTChunk * 1024;
+    const size_t lds = kFtSlots * kTChunk * 1024;
     if (aux) {
         const dim3 igrid(ucn_div_up(M, 32 * kInferWaves)), iblock(64 * kInferWaves);
         const size_t ilds = (size_t)IRing::kSlots * IRing::kChunk * 1024;
@@ -539,8 +545,8 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
                    (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kTSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }
