@@ -248,16 +248,30 @@ __device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, ui
         *reinterpret_cast<uint2 *>(row + 64 * t + 48) = make_uint2(hi.z, hi.w);
     }
     wave_lds_handoff();
+    // a full tile (wave-uniform; all but a launch's last tiles) stores without per-row predicates: each predicate is an exec save, a
+    // branch and a restore around ONE store -- 700 of the sky forward kernel's 10 k instructions per wave, at one wave per SIMD
+    const bool full = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
+    uint4 v[4];
+    uint4 *p[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t r = 8u * i + ((uint32_t)lane >> 3), c = (uint32_t)lane & 7u;
-        const uint4 v = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
-#ifndef UCN_EXP_NOSTORE
-        if (r < n_rows) *reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c) = v;
-#else
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#endif
+        v[i] = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
+        p[i] = reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c);
     }
+#ifndef UCN_EXP_NOSTORE
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *p[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (8u * i + ((uint32_t)lane >> 3) < n_rows) *p[i] = v[i];
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < 4; i++) asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
+#endif
 }
 template <bool PAIR>
 __device__ __forceinline__ void store_two(uint16_t *__restrict__ dst, uint32_t width, uint32_t sample, int tp, int h, const bf8 (&t0)[2],
