@@ -15,7 +15,7 @@ tmp = tempfile.mkdtemp()
 base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-w"]
 procs = []
 for f in files:
-    flags = base + (["-fno-slp-vectorize"] if f in NOSLP else [])
+    flags = base + (["-fno-slp-vectorize"] if f in NOSLP else []) + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if f == "sky_train" else [])   # = build.sh
     procs.append((f, subprocess.Popen(flags + ["-S", "--cuda-device-only", "-o", f"{tmp}/{f}.s", f"{f}.hip", "-Rpass-analysis=kernel-resource-usage"],
                                       cwd=CSRC, stderr=open(f"{tmp}/{f}.rem", "w"))))
 for f, p in procs:
