@@ -954,7 +954,8 @@ def test_sky_forward_two_tile_variant_is_bit_identical(n, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,KA,kb1,kb2", [(5000, 96, 256, 32), (37, 256, 32, 0), (70000, 256, 256, 32), (4096, 160, 128, 0), (0, 32, 32, 0)])
+@pytest.mark.parametrize("M,KA,kb1,kb2", [(5000, 96, 256, 32), (37, 256, 32, 0), (70000, 256, 256, 32), (4096, 160, 128, 0), (0, 32, 32, 0),
+                                           (3001, 64, 64, 32), (1000, 256, 64, 0), (2049, 128, 192, 32), (33, 32, 160, 0)])
 def test_wgrad_kernel_against_a_float_matmul(M, KA, kb1, kb2):
     """ucn_wgrad_bf16 (csrc/wgrad.hip: LDS transpose reads + bf16 MFMA, split-K with a fixed-order reduction) against
     A^T [B1 | B2] in float64 on the same bf16 values: ragged row counts, column blocks out of wider strided buffers, one and
