@@ -237,7 +237,11 @@ __device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, ui
                                                   uint32_t n_rows, int tp, int lane, const bf8 (&t0)[2], const bf8 (&t1)[2]) {
     const int j = lane & 31, h = lane >> 5;
     wave_lds_handoff();                                               // the previous pair's reads are done
-    uint8_t *row = tile + j * kStageRow + 8 * h;
+    // ds_write_b64 is served 16 consecutive lanes at a time on 32 banks; with a 36-dword row stride rows j and j + 8 start on the same
+    // bank (2-way conflicts on every write: 5.0e7 conflict cycles per launch, SQ_LDS_BANK_CONFLICT, where the kernels had none before
+    // the staging).  Rows with bit 3 set keep the two 8-byte halves of each 16-byte unit swapped; the read below (row >> 3 == i) undoes
+    // it for free by naming the dwords in the other order.
+    uint8_t *row = tile + j * kStageRow + 8 * (h ^ ((j >> 3) & 1));
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const uint4 lo = __builtin_bit_cast(uint4, t == 0 ? t0[0] : t1[0]), hi = __builtin_bit_cast(uint4, t == 0 ? t0[1] : t1[1]);
@@ -256,7 +260,8 @@ __device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, ui
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t r = 8u * i + ((uint32_t)lane >> 3), c = (uint32_t)lane & 7u;
-        v[i] = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
+        const uint4 u = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
+        v[i] = (i & 1) ? make_uint4(u.z, u.w, u.x, u.y) : u;
         p[i] = reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c);
     }
 #ifndef UCN_EXP_NOSTORE
