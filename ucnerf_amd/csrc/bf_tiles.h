@@ -117,15 +117,18 @@ __device__ __forceinline__ bf8 to_agpr(bf8 v) {
     asm volatile("" : "+a"(v));
     return v;
 }
-constexpr int kWAhead = 3;                  // weight fragments requested ahead of their MFMAs (4 register slots)
+#ifndef UCN_W_AHEAD
+#define UCN_W_AHEAD 3
+#endif
+constexpr int kWAhead = UCN_W_AHEAD, kWSlots = UCN_W_AHEAD + 1;   // weight fragments requested ahead of their MFMAs; register slots of the pipe
 // request fragment GF: the ring's housekeeping rides on the requests (as pipe_fetch of mlp_ring.h)
 template <int GF, int NG, class RING>
-__device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[4]) {
+__device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[kWSlots]) {
     if constexpr (GF < NG) {
         constexpr int CH = RING::kChunk, NW = RING::kWaves;
         if constexpr (GF % CH == 0 && GF / CH >= 1) ring.template boundary<GF / CH>();
         if constexpr (GF % NW == 0) ring.template piece<GF / CH + RING::kLeadChunks, (GF % CH) / NW>();
-        wp[GF % 4] = __builtin_bit_cast(bf8, ring.template group<GF>());
+        wp[GF % kWSlots] = __builtin_bit_cast(bf8, ring.template group<GF>());
     }
 }
 // tile_pair with the fragment pipe (r05): the plain form above issues "one operand read, one MFMA" and the register allocator gives every
@@ -133,18 +136,18 @@ __device__ __forceinline__ void frag_fetch(RING &ring, bf8 (&wp)[4]) {
 // 32 MFMAs took ~1900 cycles instead of 1024).  Here fragment G + kWAhead is requested in front of the MFMA of G (program order pinned
 // by a scheduling barrier per step), the pipe lives across pairs and layers.
 template <int P, int NT_IN, int G0, int NG, class RING>
-__device__ __forceinline__ void tile_pair_pf(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
+__device__ __forceinline__ void tile_pair_pf(RING &ring, bf8 (&wp)[kWSlots], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     sfor<NT_IN * 2 * P>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
         constexpr int o2 = I % P, s = (I / P) % 2, it = I / (2 * P);
         frag_fetch<G + kWAhead, NG>(ring, wp);
-        acc[o2] = mfma_bf(wp[G % 4], in[it][s], acc[o2]);
+        acc[o2] = mfma_bf(wp[G % kWSlots], in[it][s], acc[o2]);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 // acc{0,1}[o2] (+)= A(frag) . in{0,1}: tiles 0..7 of the input from in (class INA), tile 8 (NT_IN = 9) = the per-ray tile, always AGPRs
 template <int NT_IN, int G0, int NG, bool INA, bool ZERO, class RING>
-__device__ __forceinline__ void tile_pair2(RING &ring, bf8 (&wp)[4], f32x16 (&acc0)[2], f32x16 (&acc1)[2], const bf8 (&in0)[8][2],
+__device__ __forceinline__ void tile_pair2(RING &ring, bf8 (&wp)[kWSlots], f32x16 (&acc0)[2], f32x16 (&acc1)[2], const bf8 (&in0)[8][2],
                                            const bf8 (&in1)[8][2], const bf8 (&aux0)[2], const bf8 (&aux1)[2]) {
     sfor<NT_IN * 4>([&](auto i) {
         constexpr int I = i.value, G = G0 + I;
@@ -152,15 +155,15 @@ __device__ __forceinline__ void tile_pair2(RING &ring, bf8 (&wp)[4], f32x16 (&ac
         frag_fetch<G + kWAhead, NG>(ring, wp);
         if constexpr (it < 8) {
             if constexpr (ZERO && I < 2) {
-                mfma_bf_cls_first<INA>(acc0[o2], wp[G % 4], in0[it][s]);
-                mfma_bf_cls_first<INA>(acc1[o2], wp[G % 4], in1[it][s]);
+                mfma_bf_cls_first<INA>(acc0[o2], wp[G % kWSlots], in0[it][s]);
+                mfma_bf_cls_first<INA>(acc1[o2], wp[G % kWSlots], in1[it][s]);
             } else {
-                mfma_bf_cls<INA>(acc0[o2], wp[G % 4], in0[it][s]);
-                mfma_bf_cls<INA>(acc1[o2], wp[G % 4], in1[it][s]);
+                mfma_bf_cls<INA>(acc0[o2], wp[G % kWSlots], in0[it][s]);
+                mfma_bf_cls<INA>(acc1[o2], wp[G % kWSlots], in1[it][s]);
             }
         } else {
-            mfma_bf_cls<true>(acc0[o2], wp[G % 4], aux0[s]);
-            mfma_bf_cls<true>(acc1[o2], wp[G % 4], aux1[s]);
+            mfma_bf_cls<true>(acc0[o2], wp[G % kWSlots], aux0[s]);
+            mfma_bf_cls<true>(acc1[o2], wp[G % kWSlots], aux1[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
     });

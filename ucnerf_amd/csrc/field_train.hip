@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     constexpr int P2 = (2 + NA) * 4, P3 = (10 + NA) * 4;   // fragments per output pair of L2' / L3'
     constexpr int G1 = 2 * NTF * 2, G2 = G1 + 32, G3 = G2 + 4 * P2;
     constexpr int NGF = G3 + 4 * (P3 + 4);                 // fragments this kernel consumes
-    bf8 wp[4];                                             // fragment pipe
+    bf8 wp[kWSlots];                                             // fragment pipe
     if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF>(ring, wp); });
     // ---- density layer 0
     bf8 hin[10 + NA][2];                   // tiles 0..7: h1 (filled below), 8..9: h0, (10: the ray's direction tile)
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
     // two gx tiles just finished: 8) | Wd0^T
     constexpr int H1 = 16, H2 = H1 + 128, H4 = H2 + 4 * 72;
     constexpr int NGF = H4 + 4 * NTF;                      // fragments this kernel consumes
-    bf8 wp[4];                                             // fragment pipe
+    bf8 wp[kWSlots];                                             // fragment pipe
     if constexpr (UCN_TRAIN_PIPE != 0) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, NGF>(ring, wp); });
     bf8 din[16][2];                          // tiles 0..7: d1, 8..15: d0  (the order of [W1x^T | W0x^T])
     // ---- through the rgb layer and the second hidden layer's ReLU

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_FWD_WAVES, UCN_SKY_FWD_WAVES == 8 ? 1 
     }
 
     constexpr bool kPipe = UCN_SKY_FWD_PIPE;
-    bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
+    bf8 wp[kWSlots];                                                    // fragment pipe (tile_pair_pf)
     if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags>(ring, wp); });
     float sig = 0.0f;                                             // alpha head partial (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_sky_train_fwd2(SkyTrainArgs a) {
             if (live[st]) a.mask[((size_t)0 * M + b[st]) * 2 + h] = make_uint4(mk[st][0], mk[st][1], mk[st][2], mk[st][3]);
     }
 
-    bf8 wp[4];
+    bf8 wp[kWSlots];
     sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kFwdFrags>(ring, wp); });
     float sig[2] = {0.0f, 0.0f};                                  // alpha head partials (this lane's 128 neurons)
     const float *pa = side + kSAlpha + h;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * UCN_SKY_BWD_WAVES, UCN_SKY_BWD_WAVES == 8 ? 1 
         store_tile(a.dl + kDlG, kDlLd, b, 0, h, dv[4], live);
     }
     ring.template boundary<0>();
-    bf8 wp[4];                                                    // fragment pipe (tile_pair_pf)
+    bf8 wp[kWSlots];                                                    // fragment pipe (tile_pair_pf)
     if constexpr (kPipe) sfor<kWAhead>([&](auto g) { frag_fetch<g.value, kTrFrags>(ring, wp); });
     // ---- through the rgb layer and the views layer's ReLU
     sfor<2>([&](auto pc) {
