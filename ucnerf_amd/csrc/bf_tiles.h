@@ -258,27 +258,30 @@ __device__ __forceinline__ void store_pair_staged(uint8_t *__restrict__ tile, ui
     // a full tile (wave-uniform; all but a launch's last tiles) stores without per-row predicates: each predicate is an exec save, a
     // branch and a restore around ONE store -- 700 of the sky forward kernel's 10 k instructions per wave, at one wave per SIMD
     const bool full = __builtin_amdgcn_readfirstlane(n_rows) == 32u;
-    uint4 v[4];
-    uint4 *p[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t r = 8u * i + ((uint32_t)lane >> 3), c = (uint32_t)lane & 7u;
-        const uint4 u = *reinterpret_cast<const uint4 *>(tile + r * kStageRow + 16u * c);
-        v[i] = (i & 1) ? make_uint4(u.z, u.w, u.x, u.y) : u;
-        p[i] = reinterpret_cast<uint4 *>(dst + (size_t)(sample0 + r) * width + 32 * tp + 8u * c);
-    }
+    const uint32_t r0 = (uint32_t)lane >> 3, c = (uint32_t)lane & 7u;
+    const uint8_t *src = tile + r0 * kStageRow + 16u * c;
+    uint16_t *out = dst + (size_t)(sample0 + r0) * width + 32 * tp + 8u * c;
+    const size_t step = (size_t)8 * width;                            // 8 rows further per instruction
 #ifndef UCN_EXP_NOSTORE
     if (full) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) *p[i] = v[i];
+        for (int i = 0; i < 4; i++) {
+            const uint4 u = *reinterpret_cast<const uint4 *>(src + i * 8 * kStageRow);
+            *reinterpret_cast<uint4 *>(out + i * step) = (i & 1) ? make_uint4(u.z, u.w, u.x, u.y) : u;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (8u * i + ((uint32_t)lane >> 3) < n_rows) *p[i] = v[i];
+        for (int i = 0; i < 4; i++) {
+            const uint4 u = *reinterpret_cast<const uint4 *>(src + i * 8 * kStageRow);
+            if (8u * i + r0 < n_rows) *reinterpret_cast<uint4 *>(out + i * step) = (i & 1) ? make_uint4(u.z, u.w, u.x, u.y) : u;
+        }
     }
 #else
 #pragma unroll
-    for (int i = 0; i < 4; i++) asm volatile("" ::"v"(v[i].x), "v"(v[i].y), "v"(v[i].z), "v"(v[i].w));
+    for (int i = 0; i < 4; i++) {
+        const uint4 u = *reinterpret_cast<const uint4 *>(src + i * 8 * kStageRow);
+        asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+    }
 #endif
 }
 template <bool PAIR>

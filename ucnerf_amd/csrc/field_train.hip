@@ -50,7 +50,20 @@ struct TrainFwdArgs {
 #ifndef UCN_TRAIN_OCC
 #define UCN_TRAIN_OCC 2
 #endif
-constexpr int kFtSlots = UCN_TRAIN_OCC == 1 ? 6 : kTSlots, kFtLead = UCN_TRAIN_OCC == 1 ? 4 : kTLead;
+// UCN_TRAIN_STAGED (r05): activation / gradient pairs leave through a per-wave LDS tile as whole 128-byte lines (bf_tiles.h
+// store_pair_staged) instead of one 64-byte sector per lane: the forward kernel ran 0.255 ms without its stores and 0.553 with them.
+// Two workgroups per CU then have room for a 3-slot ring only (3 x 16 + 9.25 side + 18 staging = 75.25 KiB each), which by itself
+// costs 2-4 % (measured: 0.563 / 0.577 against 0.553 / 0.553 ms).
+#ifndef UCN_TRAIN_STAGED
+#define UCN_TRAIN_STAGED 1
+#endif
+#ifndef UCN_TRAIN_SLOTS
+#define UCN_TRAIN_SLOTS (UCN_TRAIN_OCC == 1 ? 6 : (UCN_TRAIN_STAGED ? 3 : kTSlots))
+#endif
+#ifndef UCN_TRAIN_LEAD
+#define UCN_TRAIN_LEAD (UCN_TRAIN_OCC == 1 ? 4 : (UCN_TRAIN_STAGED ? 1 : kTLead))
+#endif
+constexpr int kFtSlots = UCN_TRAIN_SLOTS, kFtLead = UCN_TRAIN_LEAD;
 // UCN_TRAIN_PIPE (r05): weight fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
 #ifndef UCN_TRAIN_PIPE
 #define UCN_TRAIN_PIPE 1
@@ -107,6 +120,7 @@ template <> struct FwdShape<true> { using ring = IRing; static constexpr int wav
 #endif
 constexpr int kSideBias = 16 + 64, kSideWave = 128;                    // float4: [bias_d0 (16) | bias_d1 (64)], then per wave [pr0 (64) | pr1 (64)]
 constexpr size_t kFwdSideBytes = (size_t)(kSideBias + 4 * kSideWave) * 16;
+constexpr size_t kStageBytes = UCN_TRAIN_STAGED ? 4 * kStageTile : 0;           // one staging tile per wave (training forms)
 
 template <int NTF, bool AUX = false, bool SIDE = false>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void k_train_fwd(TrainFwdArgs aa) {
@@ -122,8 +136,16 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
     const uint32_t bq = live ? s0 : a.M - 1;             // position in the feature buffer
     const uint32_t ray = a.level_dim ? bq % a.n_rays : bq / a.S;
     const uint32_t sample = a.level_dim ? ray * a.S + bq / a.n_rays : bq;   // position in the [ray][sample] outputs
-    extern __shared__ __attribute__((aligned(16))) float s_w[];      // the 64 KiB weight ring
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // the weight ring [| side table] [| one staging tile per wave]
+    constexpr bool kStaged = UCN_TRAIN_STAGED != 0 && !AUX;
+    const uint32_t wb0 = (blockIdx.x * (uint32_t)FwdShape<AUX>::waves + wave) * 32u;           // the wave's first sample
+    const uint32_t n_rows = wb0 < a.M ? (a.M - wb0 < 32u ? a.M - wb0 : 32u) : 0u;
+    uint8_t *stage = reinterpret_cast<uint8_t *>(s_w) + kFtSlots * kTChunk * 1024 + (SIDE ? kFwdSideBytes : 0) + wave * kStageTile;
     typename FwdShape<AUX>::ring ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
+    auto store_fwd = [&](uint16_t *dst, uint32_t ld, int tp, const bf8 (&t0)[2], const bf8 (&t1)[2]) {
+        if constexpr (kStaged) store_pair_staged(stage, dst, ld, wb0, n_rows, tp, lane, t0, t1);
+        else store_two<UCN_TRAIN_PAIR_FWD != 0>(dst, ld, sample, tp, h, t0, t1, live);
+    };
     ring_start(ring);
     const float *side_b0 = nullptr, *side_b1 = nullptr, *side_p0 = nullptr, *side_p1 = nullptr;
     if constexpr (SIDE) {
@@ -172,15 +194,19 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                 }
             }
             fin[ft][s] = pack8(v);
+#ifndef UCN_EXP_NOAUXSTORE
             if (a.fb && live && a.F % 8 == 0 && 32u * ft + 16u * s + 8u * h < a.F)
                 *reinterpret_cast<uint4 *>(a.fb + (size_t)sample * a.ld_fb + 32u * ft + 16u * s + 8u * h) = __builtin_bit_cast(uint4, fin[ft][s]);
+#endif
         }
+#ifndef UCN_EXP_NOAUXSTORE
     if (!AUX && a.ray_cols && live) {       // lane (j, h): columns 16 h .. 16 h + 15 of its sample's row
         const uint4 *src = reinterpret_cast<const uint4 *>(a.ray_cols + (size_t)ray * 32 + 16 * h);
         uint4 *dst = reinterpret_cast<uint4 *>(a.ray_dst + (size_t)sample * a.ld_act + 16 * h);
         dst[0] = src[0];
         dst[1] = src[1];
     }
+#endif
     ring.template boundary<0>();            // chunk 0 and the feature loads above land together
     // The bottleneck x = W_d1 h0 + b_d1 has NO activation behind it (models.py:508) and only linear maps consume it: the
     // colour layers take it COMPOSED, (W0x W_d1) h0 and (W1x W_d1) h0 (the host forms the two 256 x 64 products and folds
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
             h0[t][0] = to_b(a0[t], 0, true);
             h0[t][1] = to_b(a0[t], 1, true);
         }
-        if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h0, a.ld_h0, sample, 0, h, h0[0], h0[1], live);
+        if (a.store) store_fwd(a.h0, a.ld_h0, 0, h0[0], h0[1]);
         if (live && a.store) a.m0[(size_t)sample * 2 + h] = mask16(a0[0]) | (mask16(a0[1]) << 16);
     }
     // ---- density layer 1 -> bottleneck x (no activation), raw density = x[0]
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
             xp[o][1] = to_b(acc[o], 1, false);
         }
         if constexpr (p == 0) x0[0] = xp[0][0];
-        if (a.store && a.x) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.x, a.ld_act, sample, 2 * p, h, xp[0], xp[1], live);     // (r04: x = NULL -- its weight gradients are formed from h0, see _FusedHeads)
+        if (a.store && a.x) store_fwd(a.x, a.ld_act, 2 * p, xp[0], xp[1]);     // (r04: x = NULL -- its weight gradients are formed from h0, see _FusedHeads)
     });
     if (live && h == 0) {                   // row 0 = accumulator register 0 of tile 0 in wave-half 0, AFTER its bf16 rounding
         const uint4 q = __builtin_bit_cast(uint4, x0[0]);
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                 hin[2 * p + o][0] = to_b(acc[o], 0, true);
                 hin[2 * p + o][1] = to_b(acc[o], 1, true);
             }
-            if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h1, a.ld_act, sample, 2 * p, h, hin[2 * p], hin[2 * p + 1], live);
+            if (a.store) store_fwd(a.h1, a.ld_act, 2 * p, hin[2 * p], hin[2 * p + 1]);
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
         });
         if (live && a.store) a.m1[(size_t)sample * 2 + h] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
                 hp[o][0] = to_b(acc[o], 0, true);
                 hp[o][1] = to_b(acc[o], 1, true);
             }
-            if (a.store) store_two<UCN_TRAIN_PAIR_FWD != 0>(a.h2, a.ld_act, sample, 2 * p, h, hp[0], hp[1], live);
+            if (a.store) store_fwd(a.h2, a.ld_act, 2 * p, hp[0], hp[1]);
             mk[p] = mask16(acc[0]) | (mask16(acc[1]) << 16);
             f32x16 yo[1];                          // transient: four MFMAs, then only its three real rows are kept
             zero_acc(yo[0]);
@@ -345,7 +371,15 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
     const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
     const bool live = s0 < a.M;
     const uint32_t sample = live ? s0 : a.M - 1;
-    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // the weight ring [| one staging tile per wave]
+    constexpr bool kStaged = UCN_TRAIN_STAGED != 0;
+    const uint32_t wb0 = (blockIdx.x * 4u + wave) * 32u;            // the wave's first sample
+    const uint32_t n_rows = wb0 < a.M ? (a.M - wb0 < 32u ? a.M - wb0 : 32u) : 0u;
+    uint8_t *stage = reinterpret_cast<uint8_t *>(s_w) + kFtSlots * kTChunk * 1024 + wave * kStageTile;
+    auto store_bwd = [&](uint16_t *dst, uint32_t ld, int tp, const bf8 (&t0)[2], const bf8 (&t1)[2]) {
+        if constexpr (kStaged) store_pair_staged(stage, dst, ld, wb0, n_rows, tp, lane, t0, t1);
+        else store_two<UCN_TRAIN_PAIR_BWD != 0>(dst, ld, sample, tp, h, t0, t1, live);
+    };
     TRing ring(reinterpret_cast<const float *>(a.w), s_w, lane, wave);
     ring_start(ring);
     // ---- colour logit gradients: k = 0..2 of k-step 0, wave half 0
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
             din[2 * p + o][0] = to_b_masked(acc[o], 0, bits);
             din[2 * p + o][1] = to_b_masked(acc[o], 1, bits);
         }
-        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.d1, 256, sample, 2 * p, h, din[2 * p], din[2 * p + 1], live);
+        store_bwd(a.d1, 256, 2 * p, din[2 * p], din[2 * p + 1]);
     });
     // ---- through W1h and the first hidden layer's ReLU
     sfor<4>([&](auto pp) {
@@ -420,7 +454,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
             din[8 + 2 * p + o][0] = to_b_masked(acc[o], 0, bits);
             din[8 + 2 * p + o][1] = to_b_masked(acc[o], 1, bits);
         }
-        store_two<UCN_TRAIN_PAIR_BWD != 0>(a.d0, 256, sample, 2 * p, h, din[8 + 2 * p], din[9 + 2 * p], live);
+        store_bwd(a.d0, 256, 2 * p, din[8 + 2 * p], din[9 + 2 * p]);
     });
     // ---- both paths into the bottleneck (plus the density head's column), and density layer 1 backwards on each
     //      finished pair of gx tiles
@@ -448,7 +482,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
             gp[o][0] = to_b(acc[o], 0, false);
             gp[o][1] = to_b(acc[o], 1, false);
         }
-        if (a.gx) store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gx, 256, sample, 2 * p, h, gp[0], gp[1], live);                  // (r04: gx = NULL -- the bottleneck's weight gradient is formed from d0^T h0, d1^T h0)
+        if (a.gx) store_bwd(a.gx, 256, 2 * p, gp[0], gp[1]);                  // (r04: gx = NULL -- the bottleneck's weight gradient is formed from d0^T h0, d1^T h0)
         tile_pair_sel<2, 2, H2 + 72 * p + 64, NGF>(ring, wp, a0, gp);
     });
     // ---- ReLU of h0
@@ -459,7 +493,7 @@ __global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a
         gh0[t][0] = to_b_masked(a0[t], 0, bits);
         gh0[t][1] = to_b_masked(a0[t], 1, bits);
     }
-    store_two<UCN_TRAIN_PAIR_BWD != 0>(a.gh0, 64, sample, 0, h, gh0[0], gh0[1], live);
+    store_bwd(a.gh0, 64, 0, gh0[0], gh0[1]);
     // ---- density layer 0 backwards: the feature gradient, fp32, natural feature order
     f32x16 gf[NTF];
 #pragma unroll
@@ -523,11 +557,11 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
         else hipLaunchKernelGGL((k_train_fwd<2, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
     } else if (UCN_TRAIN_FWD_SIDE && S % 32u == 0u && (((uintptr_t)bias_d0 | (uintptr_t)bias_d1 | (uintptr_t)pr0 | (uintptr_t)pr1) & 15u) == 0u) {
         // a wave's 32 samples are one ray's: biases + the wave's per-ray rows from an LDS side table (see k_train_fwd, SIDE)
-        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false, true>), grid, dim3(256), lds + kFwdSideBytes, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_train_fwd<2, false, true>), grid, dim3(256), lds + kFwdSideBytes, (hipStream_t)stream, a);
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false, true>), grid, dim3(256), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false, true>), grid, dim3(256), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
     } else {
-        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds + kStageBytes, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds + kStageBytes, (hipStream_t)stream, a);
     }
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
@@ -545,8 +579,8 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
                    (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }
