@@ -50,6 +50,12 @@ struct TrainFwdArgs {
 #ifndef UCN_TRAIN_OCC
 #define UCN_TRAIN_OCC 2
 #endif
+// UCN_TRAIN_WAVES: waves per workgroup of the two training kernels (4: two workgroups per CU; 8: ONE workgroup per CU whose eight waves
+// share one ring -- half the LDS-DMA weight stream per sample, a 6-slot ring, still two waves per SIMD)
+#ifndef UCN_TRAIN_WAVES
+#define UCN_TRAIN_WAVES 8
+#endif
+constexpr int kTrainWaves = UCN_TRAIN_WAVES;
 // UCN_TRAIN_STAGED (r05): activation / gradient pairs leave through a per-wave LDS tile as whole 128-byte lines (bf_tiles.h
 // store_pair_staged) instead of one 64-byte sector per lane: the forward kernel ran 0.255 ms without its stores and 0.553 with them.
 // Two workgroups per CU then have room for a 3-slot ring only (3 x 16 + 9.25 side + 18 staging = 75.25 KiB each), which by itself
@@ -58,10 +64,10 @@ struct TrainFwdArgs {
 #define UCN_TRAIN_STAGED 1
 #endif
 #ifndef UCN_TRAIN_SLOTS
-#define UCN_TRAIN_SLOTS (UCN_TRAIN_OCC == 1 ? 6 : (UCN_TRAIN_STAGED ? 3 : kTSlots))
+#define UCN_TRAIN_SLOTS (UCN_TRAIN_OCC == 1 || UCN_TRAIN_WAVES == 8 ? 6 : (UCN_TRAIN_STAGED ? 3 : kTSlots))
 #endif
 #ifndef UCN_TRAIN_LEAD
-#define UCN_TRAIN_LEAD (UCN_TRAIN_OCC == 1 ? 4 : (UCN_TRAIN_STAGED ? 1 : kTLead))
+#define UCN_TRAIN_LEAD (UCN_TRAIN_OCC == 1 || UCN_TRAIN_WAVES == 8 ? 4 : (UCN_TRAIN_STAGED ? 1 : kTLead))
 #endif
 constexpr int kFtSlots = UCN_TRAIN_SLOTS, kFtLead = UCN_TRAIN_LEAD;
 // UCN_TRAIN_PIPE (r05): weight fragments requested kWAhead ahead of their MFMAs through a register pipe (bf_tiles.h tile_pair_pf)
@@ -80,11 +86,11 @@ constexpr int kFtSlots = UCN_TRAIN_SLOTS, kFtLead = UCN_TRAIN_LEAD;
 // both kernels spent 75 % of their wave-cycles waiting (profiles/r02c/pmc_table_train.txt).
 constexpr int kFragsMax = 2 * 2 * 2 + 8 * 2 * 2 + 8 * 8 * 2 + 8 * 16 * 2 + 1 * 8 * 2;   // 440 with two feature tiles, 436 with one
 constexpr int kFragsPadded = (kFragsMax + kTChunk - 1) / kTChunk * kTChunk;               // 448: the stream is zero-padded
-using TRing = Ring<kFragsPadded, kTChunk, 4, kFtSlots, kFtLead>;                            // the backward's stream
+using TRing = Ring<kFragsPadded, kTChunk, kTrainWaves, kFtSlots, kFtLead>;                            // the backward's stream
 // the forward's stream (composed colour layers, see k_train_fwd): 2 NTF 2 + 32 + 32 + 4 (40 + 4) = 244 / 248 fragments
 constexpr int kFwdFragsMax = 2 * 2 * 2 + 32 + 4 * 12 + 4 * 48;     // with the direction tile in the stream (inference): 276 / 280
 constexpr int kFwdPadded = (kFwdFragsMax + kTChunk - 1) / kTChunk * kTChunk;              // 288
-using FRing = Ring<kFwdPadded, kTChunk, 4, kFtSlots, kFtLead>;
+using FRing = Ring<kFwdPadded, kTChunk, kTrainWaves, kFtSlots, kFtLead>;
 template <int P, int NT_IN, int G0, int NG, class RING>
 __device__ __forceinline__ void tile_pair_sel(RING &ring, bf8 (&wp)[4], f32x16 (&acc)[P], const bf8 (&in)[NT_IN][2]) {
     if constexpr (UCN_TRAIN_PIPE != 0) tile_pair_pf<P, NT_IN, G0, NG>(ring, wp, acc, in);
@@ -108,7 +114,7 @@ constexpr int kInferWaves = UCN_INFER_WAVES;
 using IRing = Ring<(kFwdFragsMax + 2 * kInferWaves - 1) / (2 * kInferWaves) * (2 * kInferWaves), kInferWaves == 4 ? kTChunk : 2 * kInferWaves,
                    kInferWaves, kFtSlots, kFtLead>;
 static_assert(IRing::kChunks * IRing::kChunk <= kFwdPadded, "the packed forward stream is padded to kFwdPadded fragments");
-template <bool AUX> struct FwdShape { using ring = FRing; static constexpr int waves = 4, wgs = UCN_TRAIN_FWD_WGS; };
+template <bool AUX> struct FwdShape { using ring = FRing; static constexpr int waves = kTrainWaves, wgs = kTrainWaves == 8 ? 1 : UCN_TRAIN_FWD_WGS; };
 template <> struct FwdShape<true> { using ring = IRing; static constexpr int waves = kInferWaves, wgs = kInferWaves == 4 ? 2 : 1; };
 
 // SIDE (r05, training form): the layer biases and the wave's two per-ray rows (pr0 / pr1: all 32 samples of a wave belong to one ray
@@ -119,8 +125,8 @@ template <> struct FwdShape<true> { using ring = IRing; static constexpr int wav
 #define UCN_TRAIN_FWD_SIDE 1
 #endif
 constexpr int kSideBias = 16 + 64, kSideWave = 128;                    // float4: [bias_d0 (16) | bias_d1 (64)], then per wave [pr0 (64) | pr1 (64)]
-constexpr size_t kFwdSideBytes = (size_t)(kSideBias + 4 * kSideWave) * 16;
-constexpr size_t kStageBytes = UCN_TRAIN_STAGED ? 4 * kStageTile : 0;           // one staging tile per wave (training forms)
+constexpr size_t kFwdSideBytes = (size_t)(kSideBias + kTrainWaves * kSideWave) * 16;
+constexpr size_t kStageBytes = UCN_TRAIN_STAGED ? kTrainWaves * kStageTile : 0;           // one staging tile per wave (training forms)
 
 template <int NTF, bool AUX = false, bool SIDE = false>   // feature tiles: F <= 32 * NTF
 __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void k_train_fwd(TrainFwdArgs aa) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64 * FwdShape<AUX>::waves, FwdShape<AUX>::wgs) void
         float4 *side = reinterpret_cast<float4 *>(s_w + kFtSlots * kTChunk * 256);
         if (threadIdx.x < 16) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d0)[threadIdx.x];
         else if (threadIdx.x < (uint32_t)kSideBias) side[threadIdx.x] = reinterpret_cast<const float4 *>(a.bias_d1)[threadIdx.x - 16];
-        const uint32_t w0 = (blockIdx.x * 4u + wave) * 32u;                                     // the wave's first sample: its ray is every lane's
+        const uint32_t w0 = (blockIdx.x * (uint32_t)kTrainWaves + wave) * 32u;                  // the wave's first sample: its ray is every lane's
         const uint32_t wray = (w0 < a.M ? w0 : a.M - 1) / a.S;
         float4 *wp = side + kSideBias + wave * kSideWave;
         wp[lane] = reinterpret_cast<const float4 *>(a.pr0)[(size_t)wray * 64 + lane];
@@ -364,16 +370,16 @@ struct TrainBwdArgs {
 
 
 template <int NTF>
-__global__ __launch_bounds__(256, UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a) {
+__global__ __launch_bounds__(64 * kTrainWaves, kTrainWaves == 8 ? 1 : UCN_TRAIN_OCC) void k_train_bwd(TrainBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t s0 = (blockIdx.x * 4u + wave) * 32u + j;
+    const uint32_t s0 = (blockIdx.x * (uint32_t)kTrainWaves + wave) * 32u + j;
     const bool live = s0 < a.M;
     const uint32_t sample = live ? s0 : a.M - 1;
     extern __shared__ __attribute__((aligned(16))) float s_w[];      // the weight ring [| one staging tile per wave]
     constexpr bool kStaged = UCN_TRAIN_STAGED != 0;
-    const uint32_t wb0 = (blockIdx.x * 4u + wave) * 32u;            // the wave's first sample
+    const uint32_t wb0 = (blockIdx.x * (uint32_t)kTrainWaves + wave) * 32u;   // the wave's first sample
     const uint32_t n_rows = wb0 < a.M ? (a.M - wb0 < 32u ? a.M - wb0 : 32u) : 0u;
     uint8_t *stage = reinterpret_cast<uint8_t *>(s_w) + kFtSlots * kTChunk * 1024 + wave * kStageTile;
     auto store_bwd = [&](uint16_t *dst, uint32_t ld, int tp, const bf8 (&t0)[2], const bf8 (&t1)[2]) {
@@ -548,7 +554,7 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
                    (uint16_t *)h2, (const uint16_t *)ray_cols, (uint16_t *)ray_dst, (uint16_t *)feat_bf16, raw, y, act_ld ? act_ld : 64u, act_ld ? act_ld : 256u, act_ld ? act_ld : F, store ? 1 : 0, bf16_in ? 1 : 0, N, feat_level_dim, head != nullptr,
                    head ? head[0] : 0.0f, head ? head[1] : 1.0f, head ? head[2] : 0.0f, head ? head[3] : 0.0f,
                    m0, (uint4 *)m1, (uint4 *)m2, (uint32_t)M, S, F};
-    const dim3 grid(ucn_div_up(M, 128));
+    const dim3 grid(ucn_div_up(M, 32 * kTrainWaves));
     const size_t lds = kFtSlots * kTChunk * 1024;
     if (aux) {
         const dim3 igrid(ucn_div_up(M, 32 * kInferWaves)), iblock(64 * kInferWaves);
@@ -557,11 +563,11 @@ extern "C" int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, 
         else hipLaunchKernelGGL((k_train_fwd<2, true>), igrid, iblock, ilds, (hipStream_t)stream, a);
     } else if (UCN_TRAIN_FWD_SIDE && S % 32u == 0u && (((uintptr_t)bias_d0 | (uintptr_t)bias_d1 | (uintptr_t)pr0 | (uintptr_t)pr1) & 15u) == 0u) {
         // a wave's 32 samples are one ray's: biases + the wave's per-ray rows from an LDS side table (see k_train_fwd, SIDE)
-        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false, true>), grid, dim3(256), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_train_fwd<2, false, true>), grid, dim3(256), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false, true>), grid, dim3(64 * kTrainWaves), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false, true>), grid, dim3(64 * kTrainWaves), lds + kFwdSideBytes + kStageBytes, (hipStream_t)stream, a);
     } else {
-        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(256), lds + kStageBytes, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(256), lds + kStageBytes, (hipStream_t)stream, a);
+        if (F <= 32) hipLaunchKernelGGL((k_train_fwd<1, false>), grid, dim3(64 * kTrainWaves), lds + kStageBytes, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_train_fwd<2, false>), grid, dim3(64 * kTrainWaves), lds + kStageBytes, (hipStream_t)stream, a);
     }
     UCN_LAUNCH_CHECK("train_fwd");
     return 0;
@@ -579,8 +585,8 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
                    (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F};
-    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 128)), dim3(256), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
+    if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 32 * kTrainWaves)), dim3(64 * kTrainWaves), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 32 * kTrainWaves)), dim3(64 * kTrainWaves), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");
     return 0;
 }
