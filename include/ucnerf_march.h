@@ -485,6 +485,27 @@ uint64_t ucn_wgrad_f32_ws_floats(uint32_t N, uint32_t K, uint64_t M);
 int ucn_wgrad_f32(const float *GY, uint32_t ldg, const float *X, uint32_t ldx, uint32_t M, uint32_t N, uint32_t K, float *ws, float *GW,
                   float *gb, ucn_stream_t stream);
 
+/* ---- the same dense layers on the split-f16 MFMA engine (r06; csrc/gemm_h3.hip): "fp32-class" products, x w ~ x_hi w_hi + x_hi w_lo +
+ * x_lo w_hi with hi = f16(x), lo = f16(x - hi) (three v_mfma_f32_32x32x16_f16 per 16 k against eight fp32 MFMAs; fp32 accumulation).
+ * Replaces the same reference code as ucn_gemm_f32 / ucn_wgrad_f32 (F.linear forward and its two backward GEMMs: models.py:438-483,
+ * 581-674, 743-820, extrinsic_optimizer.py:4-48 under scripts/train_waymo.sh:3's fp32 launch); the exact-fp32 kernels stay behind
+ * the host-side switch.  Every operand carries a power-of-two scale derived from its absolute maximum, a DEVICE float:
+ *   ucn_amax_f32:  *slot = max(*slot, max |X[M, K]|) (atomic on the bit pattern; zero the slot first) for operands no kernel here made;
+ *   ucn_pack_h3:   W[N, K] (ldw floats per row; transposed != 0: the operand is given as [K, N] and used as its transpose) -> the packed
+ *                  A-operand stream (ucn_pack_h3_bytes(N, K) bytes, 16-byte aligned), *wmax_out = max |W|;  N <= 256;
+ *   ucn_gemm_h3:   ucn_gemm_f32_ex's product and epilogue (flags, mask, rowbias as there) from X, the packed stream and the two maxima;
+ *                  ymax != NULL: *ymax = max(*ymax, max |Y|) (the xmax of the GEMM that consumes Y);  K, ldx multiples of 4, N <= 256;
+ *   ucn_wgrad_h3:  ucn_wgrad_f32's result from GY, X and their maxima (gb: exact fp32 column sums); ws: ucn_wgrad_h3_ws_floats floats. */
+int ucn_amax_f32(const float *X, uint32_t ldx, uint64_t M, uint32_t K, float *slot, ucn_stream_t stream);
+uint64_t ucn_pack_h3_bytes(uint32_t N, uint32_t K);
+int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K, int transposed, void *packed, float *wmax_out, ucn_stream_t stream);
+int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias, uint32_t M,
+                uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias,
+                uint32_t ldr, uint32_t rgroup, float *ymax, ucn_stream_t stream);
+uint64_t ucn_wgrad_h3_ws_floats(uint32_t N, uint32_t K, uint64_t M);
+int ucn_wgrad_h3(const float *GY, uint32_t ldg, const float *X, uint32_t ldx, const float *gmax, const float *xmax, uint32_t M, uint32_t N,
+                 uint32_t K, float *ws, float *GW, float *gb, ucn_stream_t stream);
+
 /* Iso-surface extraction from a dense lattice of values on the device (ref: skimage.measure.marching_cubes as called by
  * extract.py:379-383, :420-460 and tsdf.py:98-102): volume [X][Y][Z] float32 (z fastest), inside = value < level.
  * Two calls around one host read of the two counts (the outputs have to be allocated):

@@ -1,11 +1,25 @@
-"""csrc/gemm_f32.hip (-m gpu): the fp32 training route's dense layers on hand-written fp32 MFMA kernels, against float64 matmuls
-and against torch's own autograd of F.linear.  Bars: exact fp32 products + fp32 accumulation => a dot product of length K differs
-from the float64 result by ~sqrt(K) ulp of its absolute-value sum."""
+"""csrc/gemm_f32.hip + csrc/gemm_h3.hip (-m gpu): the fp32 training route's dense layers on hand-written MFMA kernels, against float64
+matmuls and against torch's own autograd of F.linear, on both engines of internal/dense_f32.py.  Bars: "exact" = exact fp32 products +
+fp32 accumulation => a dot product of length K differs from the float64 result by ~sqrt(K) ulp of its absolute-value sum; "split" =
+three f16-half products per term (each operand to 2^-22 relative, the lo x lo term dropped: <= 3 x 2^-22 = 7.2e-7 of |x| |w| per term,
+random in sign) + the same fp32 accumulation: 1.2e-6 of the absolute-value sum."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["exact", "split"])
+def engine(request):
+    from ucnerf_amd.internal import dense_f32 as D
+    prev = D.set_engine(request.param)
+    yield request.param
+    D.set_engine(prev)
+
+
+def _eps(engine, base):
+    return base if engine == "exact" else max(base, 1.2e-6)
 
 
 def _ref(x, w, b=None, acc=None, relu=False):
@@ -22,31 +36,34 @@ def _ref(x, w, b=None, acc=None, relu=False):
                                    # r05: the weight-resident persistent kernel (N K small, >= 64 row tiles) incl. ragged last tiles,
                                    # fewer tiles than waves, K not a multiple of the 32-wide chunk, N below the column tile
                                    (100003, 64, 256), (70001, 4, 256), (3000, 128, 128), (2049, 256, 64), (40000, 60, 36), (8191, 20, 252)])
-def test_gemm_f32_against_float64(M, N, K):
+def test_gemm_f32_against_float64(M, N, K, engine):
     from ucnerf_amd.internal import dense_f32 as D
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
     scale = (x.double().abs() @ w.double().abs().t()).max().item() + 1.0
+    e = _eps(engine, 4e-7)
     y = D.gemm(x, w, b)
-    assert float((y.double() - _ref(x, w, b)).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((y.double() - _ref(x, w, b)).abs().max()) <= e * scale * max(1.0, K ** 0.5 / 4)
+    if engine == "split" and M >= D.H3_MIN_ROWS:                  # the epilogue recorded the product's absolute maximum on the device
+        assert float(y._ucn_amax[0]) == float(y.abs().max())
     y2 = D.gemm(x, w, None, D.RELU)
-    assert float((y2.double() - _ref(x, w, relu=True)).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((y2.double() - _ref(x, w, relu=True)).abs().max()) <= e * scale * max(1.0, K ** 0.5 / 4)
     base = torch.randn(M, N, device="cuda", generator=g)
     y3 = base.clone()
     D.gemm(x, w, b, D.ACCUMULATE, out=y3)
-    assert float((y3.double() - _ref(x, w, b, base)).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((y3.double() - _ref(x, w, b, base)).abs().max()) <= e * scale * max(1.0, K ** 0.5 / 4)
     # column-slice views of wider buffers in and out (leading dimensions), the reference's concatenated layer inputs
     wide_x = torch.randn(M, K + 8, device="cuda", generator=g)
     wide_y = torch.zeros(M, N + 5, device="cuda")
     D.gemm(wide_x[:, 4:4 + K], w, b, out=wide_y[:, 2:2 + N])
-    assert float((wide_y[:, 2:2 + N].double() - _ref(wide_x[:, 4:4 + K], w, b)).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((wide_y[:, 2:2 + N].double() - _ref(wide_x[:, 4:4 + K], w, b)).abs().max()) <= e * scale * max(1.0, K ** 0.5 / 4)
     assert float(wide_y[:, :2].abs().max()) == 0 and float(wide_y[:, 2 + N:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("M,N,K,ldm_extra", [(8192, 256, 256, 0), (100003, 64, 256, 8), (5000, 256, 64, 0), (333, 7, 256, 1), (70000, 128, 32, 4)])
-def test_gemm_f32_mask_epilogue(M, N, K, ldm_extra):
+def test_gemm_f32_mask_epilogue(M, N, K, ldm_extra, engine):
     """UCN_GEMM_MASK: y = mask > 0 ? (x w^T + bias) : 0 -- the ReLU derivative of the layer below as the epilogue of its d X GEMM;
     exactly the unmasked product where the mask is positive, exactly 0 elsewhere (also with ACCUMULATE: masked after the sum)."""
     from ucnerf_amd.internal import dense_f32 as D
@@ -66,7 +83,7 @@ def test_gemm_f32_mask_epilogue(M, N, K, ldm_extra):
 
 
 @pytest.mark.parametrize("M,N,K,group", [(120 * 700, 128, 256, 120), (4096, 256, 64, 128), (1000, 6, 256, 7)])
-def test_gemm_f32_row_group_bias(M, N, K, group):
+def test_gemm_f32_row_group_bias(M, N, K, group, engine):
     """rowbias: + rowbias[row // group] before the ReLU -- the per-RAY term of the sky NeRF's view layer under a per-sample GEMM."""
     from ucnerf_amd.internal import dense_f32 as D
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -77,11 +94,11 @@ def test_gemm_f32_row_group_bias(M, N, K, group):
     got = D.gemm(x, w, b, D.RELU, rowbias=rb, rgroup=group)
     want = torch.relu(x.double() @ w.double().t() + b.double() + rb.double().repeat_interleave(group, dim=0)[:M])
     scale = (x.double().abs() @ w.double().abs().t()).max().item() + 1.0
-    assert float((got.double() - want).abs().max()) <= 4e-7 * scale * max(1.0, K ** 0.5 / 4)
+    assert float((got.double() - want).abs().max()) <= _eps(engine, 4e-7) * scale * max(1.0, K ** 0.5 / 4)
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 4, 256), (8191, 256, 544), (4096, 64, 32), (100000, 256, 256), (31, 12, 28), (262144, 128, 284)])
-def test_wgrad_f32_against_float64_and_deterministic(M, N, K):
+def test_wgrad_f32_against_float64_and_deterministic(M, N, K, engine):
     from ucnerf_amd.internal import dense_f32 as D
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     gy = torch.randn(M, N, device="cuda", generator=g)
@@ -89,7 +106,7 @@ def test_wgrad_f32_against_float64_and_deterministic(M, N, K):
     gw, gb = D.wgrad(gy, x, True)
     want = gy.double().t() @ x.double()
     scale = float((gy.double().abs().t() @ x.double().abs()).max())
-    assert float((gw.double() - want).abs().max()) <= 2e-7 * scale * max(1.0, M ** 0.5 / 16)
+    assert float((gw.double() - want).abs().max()) <= _eps(engine, 2e-7) * scale * max(1.0, M ** 0.5 / 16 if engine == "exact" else 1.0)
     assert float((gb.double() - gy.double().sum(0)).abs().max()) <= 2e-7 * float(gy.double().abs().sum(0).max()) * max(1.0, M ** 0.5 / 16)
     gw2, gb2 = D.wgrad(gy, x, True)
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)                  # fixed-order partial sums
@@ -97,7 +114,7 @@ def test_wgrad_f32_against_float64_and_deterministic(M, N, K):
 
 @pytest.mark.parametrize("lead,N,K,relu,bias", [((1024, 120), 256, 256, True, True), ((3000,), 3, 256, False, True), ((210,), 256, 4, True, True),
                                                 ((64, 128), 1, 256, False, True), ((8192,), 256, 27, False, False), ((500, 7), 128, 283, True, True)])
-def test_hip_linear_is_f_linear_with_the_same_gradients(lead, N, K, relu, bias):
+def test_hip_linear_is_f_linear_with_the_same_gradients(lead, N, K, relu, bias, engine):
     from ucnerf_amd.internal import dense_f32 as D
     g = torch.Generator(device="cuda").manual_seed(N * 7 + K)
     x = torch.randn(*lead, K, device="cuda", generator=g, requires_grad=True)
@@ -131,3 +148,72 @@ def test_dense_f32_refuses_host_tensors():
     from ucnerf_amd.internal import dense_f32 as D
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         D._HipLinear.apply(torch.randn(4, 4), torch.randn(4, 4), None, False)
+
+
+@pytest.mark.parametrize("lo,hi", [(-40, -40), (30, 30), (-20, 10), (0, 30)])
+def test_split_engine_operand_range(lo, hi):
+    """The split engine's operands are f16 halves: without the per-tensor power-of-two scales 1e-12-sized gradients would flush to zero
+    and 1e9-sized ones overflow.  Rows of d Y span 2^lo .. 2^hi (up to 2^30 within one tensor); reference = float64.  fp32-class is stated
+    as in test_split_f16_range: as close to the float64 product as the exact-fp32 kernel is, up to a factor and a floor -- the floor is
+    relative to the TENSOR's largest row (the scale is per tensor: an element 2^-15 below the maximum still carries a normal lo half,
+    smaller ones an absolute error of 2^-37 of the maximum), which is what the sums over samples that consume these products see."""
+    from ucnerf_amd.internal import dense_f32 as D
+    g = torch.Generator(device="cuda").manual_seed(100 + lo * 7 + hi)
+    M, N, K = 16384, 256, 256
+    gy = torch.randn(M, N, device="cuda", generator=g)
+    expo = torch.linspace(lo, hi, M, device="cuda").round()
+    gy = gy * torch.exp2(expo)[:, None]
+    w = torch.randn(N, K, device="cuda", generator=g) / N ** 0.5
+    x = torch.randn(M, K, device="cuda", generator=g)
+    want = gy.double() @ w.double()                                  # d X = d Y W
+    want_w = gy.double().t() @ x.double()
+    out = {}
+    for eng in ("exact", "split"):
+        prev = D.set_engine(eng)
+        try:
+            out[eng] = (D.gemm(gy, w.t().contiguous()).double(), D.wgrad(gy, x)[0].double())
+        finally:
+            D.set_engine(prev)
+    assert torch.isfinite(out["split"][0]).all() and torch.isfinite(out["split"][1]).all(), "f16 operand overflow"
+    assert float(out["split"][0].abs().max()) > 0
+    row_scale = (gy.double().abs() @ w.double().abs()).amax(dim=1, keepdim=True)            # per-row absolute-value sums
+    top = float(row_scale.max())
+    for eng in ("exact", "split"):
+        err = (out[eng][0] - want).abs()
+        # rows within 2^-15 of the tensor's largest: relative to the row itself; all rows: relative to the largest row
+        big = (row_scale[:, 0] >= top * 2.0 ** -14)
+        rel_rows = float((err[big] / row_scale[big]).max())
+        rel_top = float(err.max()) / top
+        bar = 4e-7 * 4 if eng == "exact" else 1.2e-6 * 4
+        assert rel_rows <= bar and rel_top <= bar, (eng, rel_rows, rel_top)
+    scale_w = float((gy.double().abs().t() @ x.double().abs()).max())
+    e_exact = float((out["exact"][1] - want_w).abs().max()) / scale_w
+    e_split = float((out["split"][1] - want_w).abs().max()) / scale_w
+    assert e_split <= 3 * e_exact + 1.2e-6, (e_split, e_exact)
+
+
+def test_split_engine_amax_travels_and_goes_stale_safely():
+    """the recorded maximum follows reshapes of the same storage, is recomputed when the tensor has been written through torch
+    (version counter) and dropped by forget() after a raw-pointer write"""
+    from ucnerf_amd.internal import dense_f32 as D
+    prev = D.set_engine("split")
+    try:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn(8192, 64, device="cuda", generator=g)
+        w = torch.randn(128, 64, device="cuda", generator=g)
+        y = D.gemm(x, w)
+        slot = y._ucn_amax[0]
+        assert D.amax_of(y) is slot
+        y3 = y.view(64, 128, 128)
+        y3._ucn_amax = y._ucn_amax                                   # (what _HipLinear does for its reshaped output)
+        assert D.amax_of(D._rows(y3)) is slot
+        y.mul_(1000.0)                                               # torch write: version bump -> recomputed
+        s2 = D.amax_of(y)
+        assert s2 is not slot and float(s2) == float(y.abs().max())
+        w2 = torch.randn(32, 128, device="cuda", generator=g)
+        z = D.gemm(y, w2)
+        assert float((z.double() - y.double() @ w2.double().t()).abs().max()) <= 1.2e-6 * float((y.double().abs() @ w2.double().abs().t()).max())
+        D.forget(y)
+        assert not hasattr(y, "_ucn_amax")
+    finally:
+        D.set_engine(prev)

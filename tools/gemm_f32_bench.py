@@ -21,16 +21,29 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for N, K in ((256, 256), (256, 64), (64, 256), (256, 544), (4, 256)):
+def both(fn):
+    out = {}
+    for eng in ("exact", "split"):
+        prev = D.set_engine(eng)
+        out[eng] = timed(fn)
+        D.set_engine(prev)
+    return out
+
+
+for N, K in ((256, 256), (256, 64), (64, 256), (256, 544), (4, 256), (128, 256), (256, 4)):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     y = torch.empty(M, N, device=dev)
-    t = timed(lambda: D.gemm(x, w, b, out=y))
+    D.amax_of(x)                                      # (the producing kernel records it in the training step)
+    t = both(lambda: D.gemm(x, w, b, out=y))
     tl = timed(lambda: torch.addmm(b, x, w.t(), out=y))
-    fl = 2.0 * M * N * K
-    print(f"gemm  M {M} N {N:3d} K {K:3d}: hip {t:6.3f} ms {fl / t / 1e9:6.1f} TF | library {tl:6.3f} ms {fl / tl / 1e9:6.1f} TF | bytes/hip-time {(M * (N + K) * 4) / t / 1e9:6.0f} GB/s")
-for N, K in ((256, 256), (256, 64), (64, 32), (4, 256), (256, 544)):
+    fl, by = 2.0 * M * N * K, M * (N + K) * 4.0
+    print(f"gemm  M {M} N {N:3d} K {K:3d}: exact {t['exact']:6.3f} ms {fl / t['exact'] / 1e9:6.1f} TF | split {t['split']:6.3f} ms {fl / t['split'] / 1e9:6.1f} TF-equivalent "
+          f"{by / t['split'] / 1e9:5.2f} TB/s | library {tl:6.3f} ms {fl / tl / 1e9:6.1f} TF")
+for N, K in ((256, 256), (256, 64), (64, 32), (4, 256), (256, 544), (128, 256)):
     gy = torch.randn(M, N, device=dev); x = torch.randn(M, K, device=dev)
-    t = timed(lambda: D.wgrad(gy, x, True))
+    D.amax_of(gy); D.amax_of(x)
+    t = both(lambda: D.wgrad(gy, x, True))
     tl = timed(lambda: gy.t() @ x)
-    fl = 2.0 * M * N * K
-    print(f"wgrad M {M} N {N:3d} K {K:3d}: hip {t:6.3f} ms {fl / t / 1e9:6.1f} TF | library {tl:6.3f} ms {fl / tl / 1e9:6.1f} TF | bytes/hip-time {(M * (N + K) * 4) / t / 1e9:6.0f} GB/s")
+    fl, by = 2.0 * M * N * K, M * (N + K) * 4.0
+    print(f"wgrad M {M} N {N:3d} K {K:3d}: exact {t['exact']:6.3f} ms {fl / t['exact'] / 1e9:6.1f} TF | split {t['split']:6.3f} ms {fl / t['split'] / 1e9:6.1f} TF-equivalent "
+          f"{by / t['split'] / 1e9:5.2f} TB/s | library {tl:6.3f} ms {fl / tl / 1e9:6.1f} TF")

@@ -1,0 +1,138 @@
+// Epilogue shared by the dense training kernels (gemm_f32.hip: exact fp32 products; gemm_h3.hip: split-f16 products): accumulator
+// tiles of the 32x32 MFMA C/D layout -> Y[M, N] with bias / row-group bias / ReLU / mask, directly or staged through LDS.
+#pragma once
+#include "ucn_common.h"
+#include "wave_dpp.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kGemmAccum = 1u, kGemmRelu = 2u, kGemmMask = 4u, kGemmVec = 16u;
+
+// ---- epilogue of both gemm kernels -------------------------------------------------------------------------------------------------
+// The product is formed TRANSPOSED, D[feature][sample] = W_tile X_tile^T (A operand = weight rows from LDS, B operand = this lane's
+// sample row): accumulator register r of lane (sample i, half kk) is feature 32 t + (r & 3) + 8 (r >> 2) + 4 kk -- four consecutive
+// output columns per register quad, i.e. ONE 16-byte piece per quad instead of four 4-byte pieces spread over four rows.
+struct GemmOut {
+    const float *bias, *mask;      // mask: y = mask[row][col] > 0 ? y : 0 (the ReLU derivative of the layer below, fused into its d X GEMM)
+    const float *rbias;            // row-group bias [M / rgroup, N]: + rbias[row / rgroup][col] (a per-RAY term under a per-sample GEMM)
+    float *Y;
+    uint32_t ldy, ldm, ldr, rgroup, M, N, flags;
+};
+
+__device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
+    if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (o.rbias) { const float4 bv = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(row / o.rgroup) * o.ldr + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (o.flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (o.flags & kGemmMask) {
+        const float4 m = *reinterpret_cast<const float4 *>(o.mask + (size_t)row * o.ldm + col);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    return v;
+}
+
+// Direct form: a lane stores the quads of its own row (any N, any alignment).  TRACK: returns the maximum of |every value this lane stored|
+// (gemm_h3.hip: the absolute maximum of Y, the power-of-two operand scale of the GEMM that consumes it); NaNs do not enter the maximum.
+template <uint32_t NT, bool TRACK = false>
+__device__ __forceinline__ float gemm_store_direct(const f32x16 (&acc)[NT], const GemmOut &o, uint32_t orow, uint32_t n0, uint32_t kk) {
+    float mx = 0.0f;
+    if (orow >= o.M) return mx;
+    const bool vec = (o.flags & kGemmVec) != 0;
+#pragma unroll
+    for (uint32_t t = 0; t < NT; t++) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint32_t col = n0 + 32u * t + 8u * g + 4u * kk;
+            if (col >= o.N) continue;
+            float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
+            float *yo = o.Y + (size_t)orow * o.ldy + col;
+            if (vec) {
+                const float4 f = gemm_finish(v, o, orow, col);
+                if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
+                *reinterpret_cast<float4 *>(yo) = f;
+                continue;
+            }
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                if (col + c >= o.N) break;
+                float y = e[c] + (o.bias ? o.bias[col + c] : 0.f);
+                if (o.rbias) y += o.rbias[(size_t)(orow / o.rgroup) * o.ldr + col + c];
+                if (o.flags & kGemmRelu) y = fmaxf(y, 0.f);
+                if ((o.flags & kGemmMask) && !(o.mask[(size_t)orow * o.ldm + col + c] > 0.f)) y = 0.f;
+                if constexpr (TRACK) mx = fmaxf(mx, fabsf(y));
+                yo[c] = y;
+            }
+        }
+    }
+    return mx;
+}
+
+// Staged form (full tiles, 16-byte-aligned rows): a direct store instruction is 32 rows x two 16-byte pieces = 64 partial-line
+// requests; written to the wave's own LDS tile as [row][column] and read back row-contiguous, a store instruction covers whole
+// 128-byte lines -- the K = 64 layer went from 1.4 to ~3 TB/s of stores.  COLUMN blocks of 64 (two 32-column tiles) per pass (r05): every
+// lane writes its row's 8 quads of the block (8 full-width ds_write_b128), the wave reads 32 rows x 256 B back as 8 float4 per lane and
+// stores 4 rows x two whole lines per instruction.  (r04 / first r05 form: ROW blocks -- only the lanes of the pass's rows wrote, so a
+// tile cost 32 / SR x 4 NT quarter- or half-empty ds_write_b128: 128 per 32 x 256 tile at SR = 8, 40 % of the CU's LDS time.)
+// The tile is 32 x (64 + 4) floats = 8.5 KiB per wave.
+constexpr uint32_t kStageFloats = 32u * 68u;
+template <uint32_t NT, bool TRACK = false>
+__device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], const GemmOut &o, float *tile, uint32_t m0, uint32_t n0,
+                                                   uint32_t lane) {
+    float mx = 0.0f;
+    static_assert(NT % 2u == 0u, "column blocks of two tiles");
+    constexpr uint32_t RS = 68u;                                   // row stride in floats (64 + 4: the rows of a write fall on different bank groups)
+    const uint32_t i = lane & 31u, kk = lane >> 5;
+#pragma unroll
+    for (uint32_t cb = 0; cb < NT / 2u; cb++) {
+#pragma unroll
+        for (uint32_t t2 = 0; t2 < 2; t2++)
+#pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                const f32x16 &a = acc[2u * cb + t2];
+                *reinterpret_cast<float4 *>(tile + i * RS + 32u * t2 + 8u * g + 4u * kk) =
+                    make_float4(a[4u * g], a[4u * g + 1u], a[4u * g + 2u], a[4u * g + 3u]);
+            }
+        wave_lds_handoff();
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t f = lane + 64u * u, r = f >> 4, c4 = f & 15u;
+            const uint32_t ro = m0 + r, col = n0 + 64u * cb + 4u * c4;
+            float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
+            if (ro < o.M) {
+                const float4 f = gemm_finish(v, o, ro, col);
+                if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
+                *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = f;
+            }
+        }
+        wave_lds_handoff();
+    }
+    return mx;
+}
+
+template <uint32_t NT>
+__device__ __forceinline__ void gemm_init_acc(f32x16 (&acc)[NT], const GemmOut &o, uint32_t orow, uint32_t n0, uint32_t kk) {
+    const bool vec = (o.flags & kGemmVec) != 0;
+#pragma unroll
+    for (uint32_t t = 0; t < NT; t++) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint32_t col = n0 + 32u * t + 8u * g + 4u * kk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((o.flags & kGemmAccum) && orow < o.M) {
+                const float *yi = o.Y + (size_t)orow * o.ldy + col;
+                if (vec) { if (col < o.N) v = *reinterpret_cast<const float4 *>(yi); }
+                else {
+                    if (col < o.N) v.x = yi[0];
+                    if (col + 1u < o.N) v.y = yi[1];
+                    if (col + 2u < o.N) v.z = yi[2];
+                    if (col + 3u < o.N) v.w = yi[3];
+                }
+            }
+            acc[t][4u * g] = v.x; acc[t][4u * g + 1u] = v.y; acc[t][4u * g + 2u] = v.z; acc[t][4u * g + 3u] = v.w;
+        }
+    }
+}
+
+}  // namespace

@@ -1,4 +1,4 @@
-"""fp32 dense layers of the NON-autocast training step on hand-written kernels (csrc/gemm_f32.hip; r04).
+"""fp32 dense layers of the NON-autocast training step on hand-written kernels (csrc/gemm_h3.hip, r06; csrc/gemm_f32.hip, r04).
 
 The reference's shipped launch trains in fp32 (scripts/train_waymo.sh:3 has no --mixed_precision, train.py:165's autocast is then
 a no-op): every nn.Linear of the NeRF / proposal fields (internal/models.py:438-483, 507-674), of the sky NeRF (models.py:743-820) and
@@ -11,6 +11,13 @@ The kernels take 16-byte operand loads: reduction lengths and leading dimensions
 model that are not (3 / 27 / 283-wide inputs, 1 / 3-wide outputs) are zero-padded copies made here -- they are per-ray or weight-sized,
 never an activation-sized concatenation.
 
+r06: the default engine is "split" -- the same three functions on csrc/gemm_h3.hip: fp32-class products x w ~ x_hi w_hi + x_hi w_lo +
+x_lo w_hi of f16 halves on v_mfma_f32_32x32x16_f16 (16 / 3 of the fp32 MFMA rate), fp32 accumulation, every operand at a power-of-two
+scale taken from its absolute maximum.  That maximum is a DEVICE float that travels with the tensor (`_ucn_amax`, set by the GEMM whose
+epilogue produced the tensor; computed by one ucn_amax_f32 pass for operands that come from elsewhere) -- no host round trip.  The
+exact fp32-product kernels stay behind `set_engine("exact")` / UCN_F32_EXACT=1; tall operands only (M >= 4096), short ones always run
+exact.
+
 UCN_F32_LIBRARY=1 (experiment switch, read per call) routes the same functions through torch's library GEMMs: the A/B measurement of
 bench.py `train_step_fp32`, not a fallback -- on a host tensor these functions raise like every other entry point.
 """
@@ -22,9 +29,75 @@ from .. import _lib
 
 ACCUMULATE, RELU, MASK = 1, 2, 4
 
+H3_MIN_ROWS = 4096              # below this a GEMM is launch-bound either way: exact products
+_ENGINE = "exact" if os.environ.get("UCN_F32_EXACT", "0") == "1" else "split"
+
+
+def engine():
+    return _ENGINE
+
+
+def set_engine(name):
+    """"split": fp32-class split-f16 products (csrc/gemm_h3.hip; default).  "exact": exact fp32 products (csrc/gemm_f32.hip)."""
+    global _ENGINE
+    assert name in ("split", "exact"), name
+    prev, _ENGINE = _ENGINE, name
+    return prev
+
 
 def library_route():
     return os.environ.get("UCN_F32_LIBRARY", "0") == "1"
+
+
+# ---- absolute maxima of the split engine's operands: device floats that travel with their tensors ------------------------------------
+_POOL = {}
+
+
+def _slot(device):
+    """a zeroed device float (a view into a pool that is zero-filled once per 4096 slots)"""
+    key = str(device)
+    hit = _POOL.get(key)
+    if hit is None or hit[1] >= hit[0].numel():
+        hit = _POOL[key] = [torch.zeros(4096, device=device), 0]
+    s = hit[0][hit[1]:hit[1] + 1]
+    hit[1] += 1
+    return s
+
+
+def _tag(t, slot):
+    t._ucn_amax = (slot, t._version)
+    return t
+
+
+def forget(t):
+    """call after writing into a tensor through its raw pointer (kernels do not bump `_version`): its recorded maximum is stale"""
+    if hasattr(t, "_ucn_amax"):
+        del t._ucn_amax
+
+
+def amax_of(t):
+    """device float holding max |t| (an upper bound is as good) of a [M, K] operand: the one recorded when a kernel of this module
+    produced `t`, else one ucn_amax_f32 pass (then remembered on the tensor object)."""
+    hit = getattr(t, "_ucn_amax", None)
+    if hit is not None and hit[1] == t._version:
+        return hit[0]
+    lib = _lib.load()
+    s = _slot(t.device)
+    M, K = t.shape
+    _lib.check(lib.ucn_amax_f32(t.data_ptr(), t.stride(0), M, K, s.data_ptr(), _lib.stream()))
+    _tag(t, s)
+    return s
+
+
+def stash_amax(ctx, tensors):
+    """autograd: remember the recorded maxima of tensors about to be saved for backward (saved_tensors may hand back new objects)"""
+    ctx._ucn_amax = [getattr(t, "_ucn_amax", None) if t is not None else None for t in tensors]
+
+
+def restore_amax(ctx, tensors):
+    for t, a in zip(tensors, getattr(ctx, "_ucn_amax", ())):
+        if t is not None and a is not None and a[1] == t._version:
+            t._ucn_amax = a
 
 
 def _rows(t):
@@ -32,12 +105,15 @@ def _rows(t):
     to a multiple of 4 with zero columns if it is not (copy).  Views that already conform (column slices at multiples of 4 of a wider
     buffer) are passed as they are."""
     _lib.require_device(t, "dense_f32 operand")
+    src = t
     if t.dtype != torch.float32:
         t = t.float()
     t = t.reshape(-1, t.shape[-1])
     k = t.shape[1]
     ok = (t.stride(1) == 1 or k == 1) and t.stride(0) % 4 == 0 and t.stride(0) >= k and t.data_ptr() % 16 == 0 and k % 4 == 0
     if ok:
+        if t is not src and hasattr(src, "_ucn_amax") and t.data_ptr() == src.data_ptr() and t.numel() == src.numel():
+            t._ucn_amax = src._ucn_amax                                  # the same values under another shape
         return t
     kp = (k + 3) // 4 * 4
     if kp == k:
@@ -58,15 +134,30 @@ def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     assert out.stride(1) == 1 or N == 1
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape[0] == M and mask.shape[1] >= N and (mask.stride(1) == 1 or N == 1)
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rgroup > 0 and rowbias.shape[0] * rgroup >= M and rowbias.shape[1] >= N and rowbias.stride(1) == 1
+    if _ENGINE == "split" and M >= H3_MIN_ROWS and N <= 256:
+        # fp32-class products on the split-f16 engine: pack the weight (its scale from its own maximum), the activations' scale from the
+        # maximum recorded by the kernel that produced them, this product's maximum recorded for the next one
+        packed = torch.empty(lib.ucn_pack_h3_bytes(N, K), device=x.device, dtype=torch.uint8)
+        wmax = _slot(x.device)
+        _lib.check(lib.ucn_pack_h3(w.data_ptr(), w.stride(0), N, K, 0, packed.data_ptr(), wmax.data_ptr(), _lib.stream()))
+        xmax = amax_of(x)
+        ymax = _slot(x.device)          # (ACCUMULATE too: the epilogue sees, and records, the final values of every element of `out`)
+        _lib.check(lib.ucn_gemm_h3(x.data_ptr(), x.stride(0), packed.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), _lib.ptr(bias), M, N, K,
+                                   int(flags) | (MASK if mask is not None else 0), out.data_ptr(), out.stride(0), _lib.ptr(mask),
+                                   0 if mask is None else mask.stride(0), _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0),
+                                   int(rgroup), ymax.data_ptr(), _lib.stream()))
+        return _tag(out, ymax)
+    forget(out)
     if mask is None and rowbias is None:
         _lib.check(lib.ucn_gemm_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
                                     out.data_ptr(), out.stride(0), _lib.stream()))
         return out
     if mask is not None:
-        assert mask.dtype == torch.float32 and mask.shape[0] == M and mask.shape[1] >= N and (mask.stride(1) == 1 or N == 1)
         flags = int(flags) | MASK
-    if rowbias is not None:
-        assert rowbias.dtype == torch.float32 and rgroup > 0 and rowbias.shape[0] * rgroup >= M and rowbias.shape[1] >= N and rowbias.stride(1) == 1
     _lib.check(lib.ucn_gemm_f32_ex(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), M, N, K, int(flags),
                                    out.data_ptr(), out.stride(0), _lib.ptr(mask), 0 if mask is None else mask.stride(0),
                                    _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0), int(rgroup), _lib.stream()))
@@ -85,7 +176,8 @@ def wgrad(gy, x, want_bias=False):
         # a wide gradient against a narrow input ([256, 64]: the composed colour layers): the kernel's blocks are 256 k columns wide,
         # its narrow shapes are narrow in N -- form the transpose (x^T gy: a 64-row block, every k column used) and flip it back
         return wgrad(x, gy, False)[0].t().contiguous(), None
-    n = lib.ucn_wgrad_f32_ws_floats(N, K, M)
+    split = _ENGINE == "split" and M >= H3_MIN_ROWS
+    n = (lib.ucn_wgrad_h3_ws_floats if split else lib.ucn_wgrad_f32_ws_floats)(N, K, M)
     st = torch.cuda.current_stream()
     key = (str(gy.device), st.cuda_stream)
     hit = _WS.get(key)
@@ -95,6 +187,10 @@ def wgrad(gy, x, want_bias=False):
         hit = _WS[key] = (st, torch.empty(max(n, 1), device=gy.device))
     gw = torch.empty(N, K, device=gy.device)
     gb = torch.empty(N, device=gy.device) if want_bias else None
+    if split:
+        _lib.check(lib.ucn_wgrad_h3(gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), amax_of(gy).data_ptr(), amax_of(x).data_ptr(),
+                                    M, N, K, hit[1].data_ptr(), gw.data_ptr(), _lib.ptr(gb), _lib.stream()))
+        return gw, gb
     _lib.check(lib.ucn_wgrad_f32(gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), M, N, K, hit[1].data_ptr(), gw.data_ptr(),
                                  _lib.ptr(gb), _lib.stream()))
     return gw, gb
@@ -109,12 +205,17 @@ class _HipLinear(torch.autograd.Function):
         x2, w2 = _rows(x), _rows(weight)
         y = gemm(x2, w2, None if bias is None else bias.float().contiguous(), RELU if relu else 0)
         ctx.save_for_backward(x2, weight, y if relu else None)
+        stash_amax(ctx, (x2,))
         ctx.meta = (lead, K, N, bias is not None, relu, x.dtype, weight.dtype)
-        return y.reshape(lead + (N,))
+        out = y.reshape(lead + (N,))
+        if hasattr(y, "_ucn_amax"):
+            out._ucn_amax = (y._ucn_amax[0], out._version)
+        return out
 
     @staticmethod
     def backward(ctx, gy):
         x2, weight, y = ctx.saved_tensors
+        restore_amax(ctx, (x2,))
         lead, K, N, has_bias, relu, x_dt, w_dt = ctx.meta
         gy2 = gy.reshape(-1, N)
         if relu:

@@ -236,10 +236,12 @@ class _ColourMLP(torch.autograd.Function):
                 pr0 = G(eb, R(W0e), b0.contiguous())                                     # [N, NW] per ray
                 h1 = G(xb, W0x)
                 _lib.check(lib.ucn_bias_relu(h1.data_ptr(), pr0.data_ptr(), N, S, NW, code, _lib.stream()))
+                dense_f32.forget(h1)                                                     # written through its raw pointer
                 pr1 = G(eb, R(W1e), b1.contiguous())
                 h2 = G(h1, W1h)
                 G(xb, W1x, flags=dense_f32.ACCUMULATE, out=h2)                           # accumulate in place: no copy
                 _lib.check(lib.ucn_bias_relu(h2.data_ptr(), pr1.data_ptr(), N, S, NW, code, _lib.stream()))
+                dense_f32.forget(h2)
             else:
                 pr0 = torch.addmm(b0.to(dt), eb, W0e.t()).contiguous()                   # [N, NW] per ray
                 h1 = xb @ W0x.t()
@@ -271,6 +273,7 @@ class _ColourMLP(torch.autograd.Function):
                 r0 = torch.empty(N, NW, device=g.device, dtype=dt)
                 _lib.check(lib.ucn_relu_backward_reduce(d0.data_ptr(), h1.data_ptr(), d0.data_ptr(), r0.data_ptr(), N, S, NW, code,
                                                         _lib.stream()))
+                dense_f32.forget(d0)                                                      # masked in place through its raw pointer
                 gW0 = torch.cat([WG(d0, xb)[0][:, :NB], WG(r0, eb)[0][:, :E]], dim=1)
                 gW1 = torch.cat([WG(d1, h1)[0], WG(d1, xb)[0][:, :NB], WG(r1, eb)[0][:, :E]], dim=1)
                 gb0, gb1 = r0.sum(0), r1.sum(0)
@@ -318,12 +321,14 @@ class _ColourMLPComposed(torch.autograd.Function):
         G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
         rgbl = G(h2, Wr, br.float().contiguous())
         ctx.save_for_backward(h0, h1, h2, A0, A1, W1h, Wr)
+        dense_f32.stash_amax(ctx, (h0, h1, h2))
         ctx.meta = (N, S, W1h.shape[0])
         return rgbl
 
     @staticmethod
     def backward(ctx, g_rgbl):
         h0, h1, h2, A0, A1, W1h, Wr = ctx.saved_tensors
+        dense_f32.restore_amax(ctx, (h0, h1, h2))
         N, S, NW = ctx.meta
         R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
         n_rgb = Wr.shape[0]
@@ -914,6 +919,7 @@ class _SkyTrunkF32(torch.autograd.Function):
         hv = G(h, Mv.detach().contiguous(), bv.detach(), dense_f32.RELU, rowbias=per_ray.detach().contiguous(), rgroup=group)    # [M, 128]
         rgbl = G(hv, Wr.detach().contiguous(), br.detach())                                    # [M, 3] logits
         ctx.save_for_backward(pts4, Mv, Wa, Wr, hv, *hs, *Ws)
+        dense_f32.stash_amax(ctx, (pts4, hv, *hs))
         ctx.group = group
         return sigma, rgbl
 
@@ -923,6 +929,7 @@ class _SkyTrunkF32(torch.autograd.Function):
         saved = ctx.saved_tensors
         pts4, Mv, Wa, Wr, hv = saved[:5]
         hs, Ws = saved[5:13], saved[13:21]
+        dense_f32.restore_amax(ctx, (pts4, hv, *hs))
         M, dev = pts4.shape[0], pts4.device
         n = M // ctx.group
         g4 = torch.zeros(M, 4, device=dev)
