@@ -459,13 +459,19 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
             times.append((time.perf_counter() - t0) * 1e3)
     model.eval()
     if not autocast:
+        from ucnerf_amd.internal import dense_f32
+        eng = dense_f32.engine()
         return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
-                    precision="fp32 throughout (the reference's shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision): fp32 tables, "
-                              "exact-fp32-add table gradients, every dense layer forward / dgrad / wgrad on csrc/gemm_f32.hip "
-                              "(v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)" +
+                    dtype=("f32-class (dense layers: split-f16 products on v_mfma_f32_32x32x16_f16, every operand to 2^-22 at a per-tensor "
+                           "power-of-two scale, fp32 accumulate; fp32 tables, exact-fp32-add table gradients, fp32 everything else)"
+                           if eng == "split" and os.environ.get("UCN_F32_LIBRARY") != "1" else "f32"),
+                    precision="no autocast (the reference's shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision): fp32 tables, "
+                              "exact-fp32-add table gradients, every dense layer forward / dgrad / wgrad on " +
+                              ("csrc/gemm_h3.hip (r06: the split-f16 engine; rows < 4096 on csrc/gemm_f32.hip)" if eng == "split" else
+                               "csrc/gemm_f32.hip (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)") +
                               ("; UCN_F32_LIBRARY=1: the r03 graph (uncomposed colour MLP) on torch's library GEMMs (A/B)" if os.environ.get("UCN_F32_LIBRARY") == "1" else
                                "; r04: the activation-free bottleneck is composed into the colour layers (K = 64 instead of 256 for two of the three 256-wide GEMMs)"),
-                    heads=bool(heads))
+                    dense_engine=eng, heads=bool(heads))
     return dict(ms=float(np.median(times)), rays=n_rays, rays_per_s=n_rays / (np.median(times) * 1e-3), steps=steps,
                 heads=("sky NeRF (120 samples x 8 x 256 MLP) + per-ray colour-correction affines + sky-segment and identity "
                        "losses (scripts/train_waymo.sh:11-12)" if heads else "none (BASELINE configs[2])"),
@@ -475,6 +481,19 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
                       "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd, two workgroups per CU), proposal field as VALU "
                       "kernels, compositing fwd / bwd, distortion + interlevel + hash-decay losses, Adam (tables and small "
                       "parameters); weight + bias gradients by wgrad.hip (ds_read_b64_tr_b16 operand transposes + bf16 MFMA, split-K)")
+
+
+def fp32_step_both_engines(model, flat, device, **kw):
+    """the non-autocast step on the default ("split": fp32-class) engine, with the exact-fp32-product engine's time beside it"""
+    from ucnerf_amd.internal import dense_f32
+    r = train_step_ms(model, flat, device, autocast=False, **kw)
+    prev = dense_f32.set_engine("exact")
+    try:
+        kw2 = dict(kw, steps=min(kw.get("steps", 4), 3))
+        r["exact_fp32_products_ms"] = train_step_ms(model, flat, device, autocast=False, **kw2)["ms"]
+    finally:
+        dense_f32.set_engine(prev)
+    return r
 
 
 def self_launch(n):
@@ -794,7 +813,7 @@ def main():
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             # the reference's shipped precision: fp32 (no autocast), hand-written fp32 MFMA dense layers; and the same graph on the
             # library GEMMs for comparison
-            res["train_step_fp32"] = train_step_ms(model, flat, device, steps=6, autocast=False)
+            res["train_step_fp32"] = fp32_step_both_engines(model, flat, device, steps=6)
             prev = os.environ.get("UCN_F32_LIBRARY")
             os.environ["UCN_F32_LIBRARY"] = "1"
             try:
@@ -817,7 +836,7 @@ def main():
                 # what the reference's shipped launch trains: sky NeRF + colour-correction head on (train_waymo.sh:11-12)
                 hmodel, _, _ = build_model(device, heads=True)
                 res["train_step_sky"] = train_step_ms(hmodel, flat, device, heads=True)
-                res["train_step_sky_fp32"] = train_step_ms(hmodel, flat, device, steps=4, heads=True, autocast=False)
+                res["train_step_sky_fp32"] = fp32_step_both_engines(hmodel, flat, device, steps=4, heads=True)
                 del hmodel
                 torch.cuda.empty_cache()
                 # the same step on the reference's OWN grid (waymo.gin / class defaults: L = 10, C = 4, T = 2^21 -- 256 row blocks
@@ -834,7 +853,7 @@ def main():
                 # ... and the reference's LITERAL shipped launch: scripts/train_waymo.sh:3 has no --mixed_precision (fp32 throughout),
                 # waymo.gin:7 batch_size = 15000, waymo.gin:10-13 grid, :11-12 model_sky + brightness_correction
                 res["train_step_waymo_gin_launch_fp32"] = dict(
-                    train_step_ms(rmodel, flat, device, n_rays=15000, steps=4, heads=True, autocast=False),
+                    fp32_step_both_engines(rmodel, flat, device, n_rays=15000, steps=4, heads=True),
                     grid="L 10, C 4, T 2^21, 128 + 32 samples; sky NeRF + colour-correction head on",
                     launch="scripts/train_waymo.sh as shipped: fp32 (no --mixed_precision), batch_size = 15000 (waymo.gin:7)")
                 del rmodel, flat

@@ -25,6 +25,7 @@ import torch
 import bench
 import helpers as H
 from oracle import raymarch as rm
+from ucnerf_amd.internal import dense_f32 as D
 
 pytestmark = pytest.mark.gpu
 
@@ -141,11 +142,16 @@ def _table_bar(name, lvl):
 def test_config2_training_step_full_tables_vs_oracle_autograd():
     model, spec, sd, rays, target, noise = _case("B")
     want_l, want_g = oracle_step(spec, sd, rays, target, noise, 0.5)
-    got_l, got_g = hip_step(model, rays, target, noise, 0.5, bf16=False)
-    rep = _check_fp32(spec, want_l, want_g, got_l, got_g, _table_bar)
-    print("fp32 route, per-level table gradients (sum|g| hip, oracle, rel L2 of the difference):")
-    for k, v in rep.items():
-        print(f"  {k}: {v[0]:.6e} {v[1]:.6e} {v[2]:.3e}")
+    for engine in ("split", "exact"):            # r06: the fp32 route's dense layers on both engines, the same bars
+        prev = D.set_engine(engine)
+        try:
+            got_l, got_g = hip_step(model, rays, target, noise, 0.5, bf16=False)
+        finally:
+            D.set_engine(prev)
+        rep = _check_fp32(spec, want_l, want_g, got_l, got_g, _table_bar)
+        print(f"fp32 route ({engine} engine), per-level table gradients (sum|g| hip, oracle, rel L2 of the difference):")
+        for k, v in rep.items():
+            print(f"  {k}: {v[0]:.6e} {v[1]:.6e} {v[2]:.3e}")
     b_l, b_g = hip_step(model, rays, target, noise, 0.5, bf16=True)
     _check_bf16(want_l, want_g, b_l, b_g)
 
@@ -155,7 +161,12 @@ def test_waymo_gin_grid_training_step_full_tables_vs_oracle_autograd():
     blocks per level in the table-gradient kernel."""
     model, spec, sd, rays, target, noise = _case("R")
     want_l, want_g = oracle_step(spec, sd, rays, target, noise, 0.5)
-    got_l, got_g = hip_step(model, rays, target, noise, 0.5, bf16=False)
-    _check_fp32(spec, want_l, want_g, got_l, got_g, _table_bar)
+    for engine in ("split", "exact"):
+        prev = D.set_engine(engine)
+        try:
+            got_l, got_g = hip_step(model, rays, target, noise, 0.5, bf16=False)
+        finally:
+            D.set_engine(prev)
+        _check_fp32(spec, want_l, want_g, got_l, got_g, _table_bar)
     b_l, b_g = hip_step(model, rays, target, noise, 0.5, bf16=True)
     _check_bf16(want_l, want_g, b_l, b_g)

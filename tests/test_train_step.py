@@ -1192,13 +1192,17 @@ def test_fp32_sky_chain_node_matches_the_layer_by_layer_route_and_torch(monkeypa
 
 
 @pytest.mark.gpu
-def test_fp32_training_step_runs_no_library_gemm():
+@pytest.mark.parametrize("engine", ["split", "exact"])
+def test_fp32_training_step_runs_no_library_gemm(engine):
     """VERDICT r03 missing #2: the NON-autocast training step (the reference's shipped precision, scripts/train_waymo.sh:3) -- fields, sky
-    NeRF and colour-correction head -- runs every dense layer on csrc/gemm_f32.hip: a profiler trace of one forward + backward holds
-    no Tensile / rocBLAS / hipBLASLt kernel (their names start with `Cijk_` or contain `gemm`), and does hold k_gemm_f32 / k_wgrad_f32."""
+    NeRF and colour-correction head -- runs every dense layer on csrc/gemm_f32.hip / csrc/gemm_h3.hip (r06: both engines of
+    internal/dense_f32.py): a profiler trace of one forward + backward holds no Tensile / rocBLAS / hipBLASLt kernel (their names start
+    with `Cijk_` or contain `gemm`), and does hold the engine's own kernels."""
     import types
     import bench
     from ucnerf_amd.internal import train_utils as tu
+    from ucnerf_amd.internal import dense_f32 as D
+    prev_engine = D.set_engine(engine)
     dev = torch.device("cuda", 0)
     model, _, _ = bench.build_model(dev, heads=True)
     model.train()
@@ -1221,15 +1225,22 @@ def test_fp32_training_step_runs_no_library_gemm():
                 + tu.hash_decay_loss(hist, cfg) + 0.002 * tu.sky_loss(batch, rend) + 0.002 * tu.transformIdentityLoss(rend))
         loss.backward()
         return loss
-    step()
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
-        loss = step()
-        torch.cuda.synchronize()
+    try:
+        step()
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
+            loss = step()
+            torch.cuda.synchronize()
+    finally:
+        D.set_engine(prev_engine)
     names = {e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA}
-    # (this repo's own kernels: k_gemm_f32<...>, k_gemm_f32_res<...>, both taking a `GemmOut` argument)
-    lib = sorted(x for x in names if x.startswith("Cijk_") or "gemm" in x.lower().replace("k_gemm_f32", "").replace("gemmout", ""))
+    # (this repo's own kernels: k_gemm_f32<...>, k_gemm_f32_res<...>, k_gemm_h3<...>, all taking a `GemmOut` argument)
+    lib = sorted(x for x in names if x.startswith("Cijk_") or "gemm" in x.lower().replace("k_gemm_f32", "").replace("k_gemm_h3", "").replace("gemmout", ""))
     assert not lib, lib
-    assert any("k_gemm_f32" in x for x in names) and any("k_wgrad_f32" in x for x in names), sorted(names)[:40]
+    if engine == "split":       # the tall layers on the split-f16 engine (the short ones -- per-ray terms, the colour head's 210 codes -- stay exact)
+        assert any("k_gemm_h3" in x for x in names) and any("k_wgrad_h3" in x for x in names), sorted(names)[:40]
+    else:
+        assert any("k_gemm_f32" in x for x in names) and any("k_wgrad_f32" in x for x in names), sorted(names)[:40]
+        assert not any("_h3" in x for x in names), sorted(x for x in names if "_h3" in x)
     assert np.isfinite(float(loss.detach()))
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k

@@ -19,10 +19,11 @@
 //   ucn_wgrad_h3   GW[N, K] = GY[M, N]^T X[M, K], gb[N] = column sums of GY (exact fp32 sums), fixed-order split-K partials
 //   ucn_amax_f32   max |X| of a strided [M, K] operand no kernel of this file produced (atomic max on the bit pattern)
 //
-// k_gemm_h3: a workgroup = 8 waves x 32 rows against all NT x 32 output columns (one workgroup per CU, two waves per SIMD); the weight
-// stream passes through LDS one k-step (16 k: NT x 2 KiB) at a time, double buffered, requested two steps ahead into registers and
-// written one step ahead; a lane's activations are two float4 of its own row per k-step, requested four steps ahead, scaled and split
-// in registers (8 v_ldexp + 12 VALU per 3 NT MFMAs).  HBM-bound by construction at N = K = 256: 2 KiB per row against 96 MFMA cycles.
+// k_gemm_h3: a workgroup = 4 waves x 32 rows against all NT x 32 output columns, two workgroups per CU; the weight stream passes
+// through LDS one k-step (16 k: NT x 2 KiB) at a time, double buffered, requested two steps ahead into registers and written one step
+// ahead; a wave's activations arrive in chunks of 64 k (coalesced 256-byte row pieces), parked in its private LDS tile, read back as
+// operands, scaled and split in registers (8 v_ldexp + 20 VALU per 3 NT MFMAs).  2 KiB of HBM traffic per row against 96 MFMA cycles
+// at N = K = 256.
 // k_wgrad_h3: 32-row slabs of GY and X are scaled and split as they arrive (coalesced float4 loads), stored as [hi | lo] f16 images in
 // the row-major order they have in memory and read back as MFMA fragments with ds_read_b64_tr_b16 (the transposing LDS read of gfx950).
 #include <utility>
@@ -97,11 +98,11 @@ __device__ __forceinline__ float wave_max(float m) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return m;
 }
-// *slot = max(*slot, max over the workgroup of m) on the bit pattern (non-negative floats order like uints): ONE atomic per workgroup, and
-// only when the value read first is smaller.  (first r06 build: one atomicMax per wave -- 30 720 read-modify-writes of one address per
-// GEMM, serialised at ~8 ns each: 0.25 ms of every call, more than the narrow shapes' whole data movement.)  The read may be stale but the
-// slot only grows: a stale value can cause a needless atomic, never a missed one.  `red`: >= blockDim.x / 64 floats of LDS nobody else
-// touches any more; every thread of the workgroup calls.
+// *slot = max(*slot, max over the workgroup of m) on the bit pattern (non-negative floats order like uints): ONE atomic per workgroup,
+// its result unused (the wave does not wait for it).  (first r06 build: one atomicMax per wave -- 30 720 read-modify-writes of one
+// address per GEMM, serialised at ~8 ns each: 0.25 ms of every call, more than the narrow shapes' whole data movement; a read of the
+// slot in front, to skip the atomic, cost the workgroup's tail a memory round trip instead: 7 % of its time.)  `red`: >= blockDim.x / 64
+// floats of LDS nobody else touches any more; every thread of the workgroup calls.
 __device__ __forceinline__ void block_amax_to_slot(float m, float *red, uint32_t *slot) {
     m = wave_max(m);
     const uint32_t nw = blockDim.x >> 6;
@@ -109,8 +110,7 @@ __device__ __forceinline__ void block_amax_to_slot(float m, float *red, uint32_t
     __syncthreads();
     if (threadIdx.x == 0u) {
         for (uint32_t w = 1; w < nw; w++) m = fmaxf(m, red[w]);
-        const uint32_t bits = __float_as_uint(m);
-        if (m > 0.0f && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+        if (m > 0.0f) atomicMax(slot, __float_as_uint(m));          // no return value used: the wave does not wait for it
     }
 }
 
@@ -147,9 +147,17 @@ __global__ __launch_bounds__(256) void k_pack_h3(const float *__restrict__ W, ui
     __shared__ float s_m[4];
     const uint32_t rows = transposed ? K : N, cols = transposed ? N : K;
     float m = 0.0f;
-    for (uint32_t idx = threadIdx.x; idx < rows * cols; idx += 256u) {
-        const uint32_t r = idx / cols;
-        m = fmaxf(m, fabsf(W[(size_t)r * ldw + (idx - r * cols)]));
+    if (ldw == cols && (rows * cols) % 4u == 0u && ((uintptr_t)W & 15u) == 0u) {     // one contiguous block (the usual case): no index arithmetic
+        const uint32_t n4 = rows * cols / 4u;
+        for (uint32_t idx = threadIdx.x; idx < n4; idx += 256u) {
+            const float4 v = reinterpret_cast<const float4 *>(W)[idx];
+            m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+        }
+    } else {
+        for (uint32_t idx = threadIdx.x; idx < rows * cols; idx += 256u) {
+            const uint32_t r = idx / cols;
+            m = fmaxf(m, fabsf(W[(size_t)r * ldw + (idx - r * cols)]));
+        }
     }
     m = wave_max(m);
     if ((threadIdx.x & 63u) == 0u) s_m[threadIdx.x >> 6] = m;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256) void k_pack_h3(const float *__restrict__ W, ui
 }
 
 // ---- k_gemm_h3 -----------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kH3Threads = 512u;
+constexpr uint32_t kH3Waves = 4u, kH3Threads = 64u * kH3Waves;     // 4 waves x 32 rows per workgroup, TWO workgroups per CU (see below)
 // The thread's share of the weight stream is requested PX k-steps ahead, one register set per step in flight.  A wave's activations
 // arrive in CHUNKS of PX k-steps (64 k): eight coalesced loads of 4 rows x 256 bytes each, requested one chunk ahead, parked in the
 // wave's private LDS tile as they lie in memory ([32 rows][64 + 4 floats]: the tile the epilogue stages through later) and read back
@@ -186,9 +194,28 @@ constexpr uint32_t kH3Threads = 512u;
 // scattered 64-byte visits, where the coalesced slab loads of k_wgrad_h3 reach 3.9 and a plain copy 4.9.)
 // vmcnt retires in issue order, so both streams have the same depth on purpose: a wait for a weight piece requested d steps ago also
 // waits for every activation piece requested before it.
-constexpr uint32_t kH3PX = 4u;
+// Workgroup shape (r06, second build): 4 waves, two workgroups per CU (<= 256 registers each), instead of one 8-wave workgroup.  Per
+// workgroup of the 8-wave form, s_memtime (tools/h3_clock.py, N = K = 256): prologue 16 %, k loop 60 %, epilogue 17 %, maximum 7 % -- with
+// one workgroup per CU nothing ran beside the 40 % that is not the loop.  Two independent workgroups put one's first-touch latency, its
+// 128 KiB of stores and its tail behind the other's MFMAs; the weight stream is fetched per 128 rows instead of per 256 (L2 -> LDS,
+// 13 B per clock and CU: nothing), its registers are the same (4 pieces per thread and step, two steps in flight).
+// Where the 256 x 256 shape stands (profiles/r06/gemm_h3_notes.txt): 0.67 ms per 2^20 rows = 3.2 TB/s of X + Y; the same kernel without its
+// MFMAs (and their fragment reads) 0.46 ms, without its stores 0.48 ms: the memory time and the matrix time ADD.  A start-up stagger of the
+// first dispatch round (to rule out chip-wide lockstep of the load / multiply / store phases) changed nothing; neither did the prefetch
+// depth, the activation access pattern (per-lane 16-byte pieces, coalesced 256-byte row pieces) or pairing the output tiles.  Counters:
+// MFMA busy 34 % at the 1.7 GHz the kernel runs at, LDS 27 %, 28 % of the wave-cycles in s_waitcnt -- with one activation chunk (8 KiB)
+// per wave in flight the chip holds 16 MB of requests, one loaded-latency's worth; a second chunk has no registers (256 of 256).
+constexpr uint32_t kH3PX = 4u;                                    // k-steps per activation chunk
+constexpr uint32_t kH3PW = 2u;                                    // the weight stream's depth in k-steps (register sets per thread)
 constexpr uint32_t h3_slot_units(uint32_t nt) { return nt * 128u < kH3Threads ? kH3Threads : nt * 128u; }     // 16-byte units per LDS slot
-constexpr size_t h3_lds_bytes(uint32_t nt) { return 2u * h3_slot_units(nt) * 16u + 8u * kStageFloats * 4u; }   // weight ring + 8 wave tiles
+constexpr size_t h3_lds_bytes(uint32_t nt) { return 2u * h3_slot_units(nt) * 16u + kH3Waves * kStageFloats * 4u; }   // weight ring + wave tiles
+
+#ifdef UCN_H3_CLOCK
+__device__ unsigned long long g_h3_clk[8];        // experiment build: summed s_memtime cycles per phase over the workgroups (thread 0)
+#define H3_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_h3_clk[k], now_ - clk_last_); clk_last_ = now_; } } while (0)
+#else
+#define H3_STAMP(k) do { } while (0)
+#endif
 
 struct H3Scales {
     const float *xmax, *wmax;      // max |X|, max |W| (device): the operand scales
@@ -200,19 +227,22 @@ struct H3Scales {
 // waited for as if every load of that trip had to land first (vmcnt(6) where 14 were allowed: the requests' real depth fell from four
 // steps to one and a half).  In straight-line code its counts are exact.  KS = 0: the loop, any K.
 template <uint32_t NT, uint32_t KS>
-__global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restrict__ X, uint32_t ldx, const u4v *__restrict__ Wp, uint32_t K_rt,
+__global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restrict__ X, uint32_t ldx, const u4v *__restrict__ Wp, uint32_t K_rt,
                                                           uint32_t ksteps_rt, H3Scales sc, GemmOut o) {
-    constexpr uint32_t PX = kH3PX;
+    constexpr uint32_t PX = kH3PX, PW = kH3PW;
+    static_assert(PX % PW == 0u, "the weight sets rotate inside a chunk");
     const uint32_t K = KS ? 16u * KS : K_rt, ksteps = KS ? KS : ksteps_rt;
     constexpr uint32_t CH = NT * 128u, SLOT = h3_slot_units(NT);   // 16-byte units per k-step of the stream / per LDS slot
     constexpr uint32_t WPT = (CH + kH3Threads - 1u) / kH3Threads;   // units per thread and k-step
-    constexpr uint32_t TP = (NT >= 2u && NT < 8u) ? 2u : 1u, NP = NT / TP;   // narrow shapes: output tiles in pairs (two independent MFMA
-    //                                                                          chains); NT = 8 has no registers for a second pair of fragments
+    constexpr uint32_t TP = NT >= 2u ? 2u : 1u, NP = NT / TP;      // output tiles go in pairs
     constexpr uint32_t RS = 68u;                                   // row stride of the wave tile in floats (= gemm_store_staged's)
     static_assert(kStageFloats == 32u * RS, "the activation tile is the epilogue's staging tile");
     extern __shared__ u4v s_ring[];                                // [2][SLOT] weight ring, then 8 wave tiles of kStageFloats floats
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, g = lane >> 5;
-    const uint32_t m0 = blockIdx.x * 256u + wave * 32u;
+    const uint32_t m0 = blockIdx.x * (32u * kH3Waves) + wave * 32u;
+#ifdef UCN_H3_CLOCK
+    unsigned long long clk_last_ = __builtin_amdgcn_s_memtime();
+#endif
     float *tile = reinterpret_cast<float *>(s_ring + 2u * SLOT) + wave * kStageFloats;
     const int ex = h3_exponent(*sc.xmax), ew = h3_exponent(*sc.wmax);
     const float neg1 = h3_neg1();
@@ -225,7 +255,7 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
             for (uint32_t r = 0; r < 16; r++) acc[t][r] = ldexpf(acc[t][r], ex + ew);
     }
     f4v xs[8];                                                     // one chunk in flight: 32 rows x 64 k, 8 pieces of 4 rows x 256 bytes
-    u4v wreg[PX][WPT];
+    u4v wreg[PW][WPT];
     // a chunk piece u: row 4 u + lane / 16, columns 4 (lane % 16) .. + 3 of the chunk.  Every load of the loop is UNCONDITIONAL (clamped
     // address, value zeroed where it is consumed): see k_gemm_f32 -- behind a predicated load's branch the wait-count pass drains
     // everything in flight.
@@ -260,11 +290,11 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
         // 1. requests: at a chunk's first step the NEXT chunk of activations (its registers were parked in LDS at the end of the
         //    previous step), then the weight piece PX steps ahead into the set stored one step ago.  Past the end: the loop form
         //    re-reads the first chunk / step (unused), the unrolled form drops the requests.
+#ifndef UCN_H3_EXP_NOW
+        if (KS == 0u || s + PW < KS) load_w(s + PW, wreg[P % PW]);       // (before the chunk: the wait for it at the end of step s + 1
+#endif                                                               //  must not also wait for the chunk)
 #ifndef UCN_H3_EXP_NOX
         if (P == 0u && (KS == 0u || s + PX < KS)) load_chunk(s / PX + 1u);
-#endif
-#ifndef UCN_H3_EXP_NOW
-        if (KS == 0u || s + PX < KS) load_w(s + PX, wreg[P]);
 #endif
         // 2. this step's activations from the wave tile: zero past K, scale, split
         const float *xr = tile + i * RS + 16u * P + 8u * g;
@@ -279,35 +309,36 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
         for (uint32_t q = 0; q < 8; q++) v[q] = ldexpf(v[q], ex);
         h8 bhi, blo;
         h3_split8(v, neg1, bhi, blo);
-        // 3. products from slot s & 1
+        // 3. products from slot s & 1.  Output tiles in PAIRS (two independent accumulation chains interleaved: three dependent MFMAs in a
+        //    row on one accumulator leave the matrix core waiting on itself); a pair's four fragments are refilled IN PLACE, each right
+        //    behind the last MFMA that reads it (the lo halves after the second product, the hi halves after the third), so the next
+        //    pair's LDS latency sits behind the rest of this pair and no second set of fragment registers exists.
         const u4v *slot = s_ring + (s & 1u) * SLOT + lane;
-        u4v a[TP][2], an[TP][2];
+        u4v ah[TP], al[TP];
 #pragma unroll
-        for (uint32_t q = 0; q < TP; q++) { a[q][0] = slot[(q * 2u) * 64u]; a[q][1] = slot[(q * 2u + 1u) * 64u]; }
+        for (uint32_t q = 0; q < TP; q++) { ah[q] = slot[(q * 2u) * 64u]; al[q] = slot[(q * 2u + 1u) * 64u]; }
 #pragma unroll
         for (uint32_t p = 0; p < NP; p++) {
+#pragma unroll
+            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, ah[q]), bhi, acc[TP * p + q]);
+#pragma unroll
+            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, al[q]), bhi, acc[TP * p + q]);
             if (p + 1u < NP) {
 #pragma unroll
-                for (uint32_t q = 0; q < TP; q++) {
-                    an[q][0] = slot[((TP * (p + 1u) + q) * 2u) * 64u];
-                    an[q][1] = slot[((TP * (p + 1u) + q) * 2u + 1u) * 64u];
-                }
+                for (uint32_t q = 0; q < TP; q++) al[q] = slot[((TP * (p + 1u) + q) * 2u + 1u) * 64u];
             }
-#pragma unroll
-            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, a[q][0]), bhi, acc[TP * p + q]);
-#pragma unroll
-            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, a[q][1]), bhi, acc[TP * p + q]);
-#pragma unroll
-            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, a[q][0]), blo, acc[TP * p + q]);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t q = 0; q < TP; q++) acc[TP * p + q] = mfma_h3(__builtin_bit_cast(h8, ah[q]), blo, acc[TP * p + q]);
             if (p + 1u < NP) {
 #pragma unroll
-                for (uint32_t q = 0; q < TP; q++) { a[q][0] = an[q][0]; a[q][1] = an[q][1]; }
+                for (uint32_t q = 0; q < TP; q++) ah[q] = slot[((TP * (p + 1u) + q) * 2u) * 64u];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // 4. the next step's weights (requested PX - 1 steps ago) into the other slot, whose readers passed the barrier of step s - 1;
         //    at a chunk's last step the next chunk of activations over this one (wave-private: the wave's LDS operations stay in order)
-        if (KS == 0u || s + 1u < KS) store_w(s + 1u, wreg[(P + 1u) % PX]);
+        if (KS == 0u || s + 1u < KS) store_w(s + 1u, wreg[(P + 1u) % PW]);
         if (P == PX - 1u && (KS == 0u || s + 1u < KS)) store_chunk();
 #ifndef UCN_H3_EXP_NOBAR
         __syncthreads();
@@ -317,10 +348,11 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
     load_w(0u, wreg[0]);
     load_chunk(0u);
 #pragma unroll
-    for (uint32_t p = 1; p < PX; p++) load_w(p, wreg[p]);
+    for (uint32_t p = 1; p < PW; p++) load_w(p, wreg[p]);
     store_w(0u, wreg[0]);
     store_chunk();
     __syncthreads();
+    H3_STAMP(0);
     if constexpr (KS > 0u) {
         static_assert(KS % PX == 0u, "whole chunks");
         h3_static_for<KS>([&](auto sc_) { step(std::integral_constant<uint32_t, decltype(sc_)::value % PX>{}, decltype(sc_)::value); });
@@ -329,6 +361,7 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
             h3_static_for<PX>([&](auto pc) { step(pc, s + decltype(pc)::value); });
         }
     }
+    H3_STAMP(1);
     // undo the operand scales (exact), then the shared epilogue through the wave tile
 #pragma unroll
     for (uint32_t t = 0; t < NT; t++)
@@ -348,10 +381,12 @@ __global__ __launch_bounds__(kH3Threads, 1) void k_gemm_h3(const float *__restri
         }
     }
     if (!done) mx = gemm_store_direct<NT, true>(acc, oe, m0 + i, 0u, g);
+    H3_STAMP(2);
     if (sc.ymax) {                                                  // uniform
         __syncthreads();                                            // every wave is done with its tile: the weight ring is scratch now
         block_amax_to_slot(mx, reinterpret_cast<float *>(s_ring), sc.ymax);
     }
+    H3_STAMP(3);
 }
 
 // ---- k_wgrad_h3 ----------------------------------------------------------------------------------------------------------------------
@@ -528,6 +563,14 @@ extern "C" int ucn_amax_f32(const float *X, uint32_t ldx, uint64_t M, uint32_t K
     return 0;
 }
 
+#ifdef UCN_H3_CLOCK
+extern "C" int ucn_h3_clock_read(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_h3_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_h3_clk), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 extern "C" uint64_t ucn_pack_h3_bytes(uint32_t N, uint32_t K) { return (uint64_t)h3_ksteps(K) * h3_tiles(N) * 2048u; }
 
 extern "C" int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K, int transposed, void *packed, float *wmax_out,
@@ -559,9 +602,9 @@ extern "C" int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, con
                      (!(flags & (int)kGemmMask) || (ldm % 4u == 0u && ((uintptr_t)mask & 15u) == 0u)) &&
                      (!rowbias || (ldr % 4u == 0u && ((uintptr_t)rowbias & 15u) == 0u));
     GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
-    H3Scales sc{xmax, wmax, reinterpret_cast<uint32_t *>(ymax)};
     const uint32_t ks = h3_ksteps(K);
-    const dim3 grid(ucn_div_up(M, 256));
+    H3Scales sc{xmax, wmax, reinterpret_cast<uint32_t *>(ymax)};
+    const dim3 grid(ucn_div_up(M, 32u * kH3Waves));
     hipStream_t st = (hipStream_t)stream;
     static const bool no_unroll = getenv("UCN_H3_NO_UNROLL") != nullptr;              // A/B switch: every shape through the loop form
     const uint32_t ku = (K % 16u == 0u && !no_unroll) ? K / 16u : 0u;                 // unrolled forms: K = 64 (wide outputs only), 128, 256
