@@ -202,7 +202,12 @@ def hbm_probe(device, n_floats=1 << 28, steps=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return dict(bytes_read_plus_written=8 * n_floats, ms=ms, GBps=8 * n_floats / (ms * 1e-3) / 1e9, spec_peak_GBps=PEAK_HBM_GBS)
+    return dict(bytes_read_plus_written=8 * n_floats, ms=ms, GBps=8 * n_floats / (ms * 1e-3) / 1e9, spec_peak_GBps=PEAK_HBM_GBS,
+                guide_float4_copy_GBps=6290.0,
+                shape=("k_copy4: a grid-stride float4 copy, 2048 workgroups x 256 threads, 1 GiB read + 1 GiB written, one load in flight per "
+                       "thread (no unrolling, no non-temporal hints); /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for its float4 "
+                       "copy -- this probe is the repo's OWN plain-kernel yardstick and is the pessimistic one of the two; neither enters "
+                       "`roofline.frac`, which is taken against the 8 TB/s spec peak"))
 
 
 class Ranks:
@@ -437,6 +442,11 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
     n_total = batch_flat['origins'].shape[0]
     for it in range(steps + 2):
         idx = torch.randint(0, n_total, (n_rays,), device=device, generator=g)
+        if os.environ.get("UCN_BENCH_SORT_RAYS") == "1" and n_total == H_IMG * W_IMG:
+            # experiment (profiles/r06/sort_rays_ab.txt): the same random rays, visited in 8 x 8-pixel-tile order (the per-ray math and the
+            # mean losses do not depend on the order inside the batch; the synthetic target is drawn after, so nothing is un-permuted)
+            yy, xx = idx // W_IMG, idx % W_IMG
+            idx = idx[torch.argsort(((yy // 8) * (W_IMG // 8) + xx // 8) * 64 + (yy % 8) * 8 + xx % 8)]
         batch = {k: v[idx][:, None, None, :] for k, v in batch_flat.items()}
         batch['rgb'] = torch.rand(n_rays, 1, 1, 3, device=device, generator=g)
         if heads:
@@ -481,6 +491,56 @@ def train_step_ms(model, batch_flat, device, n_rays=8192, steps=12, heads=False,
                       "dgrad as bf16 MFMA kernels (ucn_train_fwd / ucn_train_bwd, two workgroups per CU), proposal field as VALU "
                       "kernels, compositing fwd / bwd, distortion + interlevel + hash-decay losses, Adam (tables and small "
                       "parameters); weight + bias gradients by wgrad.hip (ds_read_b64_tr_b16 operand transposes + bf16 MFMA, split-K)")
+
+
+def fitted_field_frames(device, cfg_template, steps=300, thr=4e-8):
+    """north_star's early-termination sample compaction on a field that is NOT random: the config-B model from the reference's own
+    initialisation (tables +-1e-4, grid.py:151-153), fitted `steps` steps to tools/fit_scene.py's analytic opaque-surface scene with
+    this repo's training graph, then the headline frame timed with Model.compact_min_weight = 0 and = thr; the alive fraction is the
+    share of NeRF-level samples whose compositing weight reaches thr.  (tests/test_full_size.py::test_fitted_field_march_and_
+    compaction_vs_oracle holds the same field to the CPU oracle.)"""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import fit_scene
+    from ucnerf_amd.internal import models
+    torch.manual_seed(20)
+    model, cfg, _ = build_model(device)
+    for mlp in (model.nerf_mlp, model.prop_mlp_0):
+        mlp.encoder.embeddings.data.uniform_(-1e-4, 1e-4)
+    t0 = time.perf_counter()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()) as log:
+        fit_scene.fit(model, device, steps)
+    fit_s = time.perf_counter() - t0
+    last = [l for l in log.getvalue().splitlines() if "psnr" in l][-1].strip()
+    cfg.render_ray_tile = cfg_template.render_ray_tile
+    cfg.render_gather_weights = False
+    batch = frame_rays(device)
+    n_rays = H_IMG * W_IMG
+    batch["rand_vec"] = torch.randn(n_rays, 6, generator=torch.Generator().manual_seed(1)).reshape(H_IMG, W_IMG, 6).to(device)
+    acc = Ranks(1, 0)
+
+    def frame():
+        models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1, out
+    d0, out0 = frame()
+    model.compact_min_weight = thr
+    model._alive_stats = []
+    models.render_image(model, acc, batch, False, 1.0, cfg, verbose=False, eval_camidx=0)          # the statistics frame (host reads: not timed)
+    alive = sum(a for a, _ in model._alive_stats) / max(1, sum(b for _, b in model._alive_stats))
+    model._alive_stats = None
+    d1, out1 = frame()
+    model.compact_min_weight = 0.0
+    return dict(value_fitted=n_rays / d0, value_fitted_compacted=n_rays / d1, ms_fitted=d0 * 1e3, ms_fitted_compacted=d1 * 1e3,
+                compact_min_weight=thr, alive_fraction=alive, rgb_linf_compacted_vs_plain=float((out0["rgb"] - out1["rgb"]).abs().max()),
+                fit=dict(steps=steps, seconds=fit_s, last_logged=last, scene="tools/fit_scene.py: ground plane + six spheres, 24 poses, bf16 autocast steps of 8192 rays"),
+                note=("after a fit of this length the proposal resampling has moved the 128 NeRF-level samples onto the surfaces: (nearly) every sample "
+                      "still carries weight >= the threshold, so the compacted route -- density head, compositing weights, ballot / prefix-sum alive list, "
+                      "colour layers of the alive samples -- is exercised end to end but removes (next to) nothing and pays its fixed cost; it stays off "
+                      "by default (break-even alive fraction 0.73, profiles/r04/compaction_fit8000*.txt)"))
 
 
 def fp32_step_both_engines(model, flat, device, **kw):
@@ -748,6 +808,7 @@ def main():
                        "field": (f"fitted for {args.fit_steps} steps to the analytic scene of tools/fit_scene.py" if args.fit_steps
                                  else "random-init weights, tables U(-1,1) (BASELINE configs)"),
                        "compact_min_weight": args.compact, "ray_tile": args.ray_tile,
+                       "render_gather_weights": bool(cfg.render_gather_weights),
                        "compact_evidence": ("sample compaction stays OFF by default: on a field fitted for 8000 steps to an opaque-surface analytic scene "
                                             "(tools/fit_scene.py: acc 0.995-0.999 on surface-hit rays) 88-92 % of the NeRF-level samples carry weight >= 4e-8 "
                                             "and 85-90 % >= 1e-6 (the proposal resampling has already moved the samples to the surface), while the compacted "
@@ -810,6 +871,21 @@ def main():
                     del out0
                 finally:
                     model.nerf_mlp.mlp_mode = keep
+            # the reference's returned key set (models.py:965-971 also hands back the [H, W, 128] per-sample `weights` of the last level,
+            # which extract.py:355 reads): the same frame with Config.render_gather_weights = True -- at one GPU a 1.26 GB permute more,
+            # at N GPUs 27 x the exchange payload; the headline `value` returns every other key
+            cfg.render_gather_weights = True
+            try:
+                step(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                outw = step(); torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                res["value_with_weights"] = dict(rays_per_s=n_rays / d1, ms_per_frame=d1 * 1e3, steps=1, warmup=1,
+                                                 returned_keys=sorted(k for k in outw if torch.is_tensor(outw[k]) or isinstance(outw[k], list)),
+                                                 weights_shape=list(outw["weights"].shape) if "weights" in outw else None)
+                del outw
+            finally:
+                cfg.render_gather_weights = False
             res["train_step"] = train_step_ms(model, flat, device)       # outside the timed region
             # the reference's shipped precision: fp32 (no autocast), hand-written fp32 MFMA dense layers; and the same graph on the
             # library GEMMs for comparison
@@ -858,6 +934,11 @@ def main():
                     launch="scripts/train_waymo.sh as shipped: fp32 (no --mixed_precision), batch_size = 15000 (waymo.gin:7)")
                 del rmodel, flat
                 torch.cuda.empty_cache()
+                # north_star's compaction beside the headline, on a fitted (non-random) field
+                try:
+                    res["fitted_field"] = fitted_field_frames(device, cfg)
+                except Exception as e:                                    # noqa: BLE001 -- reported, never fatal to the line
+                    res["fitted_field"] = dict(error=f"{type(e).__name__}: {e}"[:300])
                 # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
                 res["configs"] = {
                     "configs[3] 5-camera frame, fp32-class": render_config(device, 5, heads=False, autocast=False),
@@ -879,6 +960,9 @@ def main():
             "rays_per_s": res["value"], "ms_per_frame": res["ms_per_step"], "n_gpus": world,
             "roofline_frac_gather": res["roofline"].get("frac") if res["roofline"].get("bound") == "hbm" else res["roofline_secondary"].get("frac"),
             "rays_per_s_exact_fp32": pick("value_exact_fp32", "rays_per_s"),
+            "rays_per_s_with_weights": pick("value_with_weights", "rays_per_s"),
+            "rays_per_s_fitted": pick("fitted_field", "value_fitted"), "rays_per_s_fitted_compacted": pick("fitted_field", "value_fitted_compacted"),
+            "fitted_alive_fraction": pick("fitted_field", "alive_fraction"),
             "cpu_rays_per_s": pick("cpu_baseline", "value"), "cpu_cores": pick("cpu_baseline", "cores"),
             "rgb_linf_gpu_vs_cpu": pick("cpu_baseline", "rgb_linf_gpu_vs_cpu"),
             "train_step_ms": {k: pick(k) for k in ("train_step", "train_step_fp32", "train_step_sky", "train_step_sky_fp32", "train_step_waymo_gin_grid",

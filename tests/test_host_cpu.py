@@ -240,12 +240,54 @@ for i in ref["state"]:
     for k in ("exp_avg", "exp_avg_sq"):
         assert torch.equal(full["state"][i][k].reshape(-1), ref["state"][i][k].reshape(-1)), (i, k)
 assert b_opt.exchange_bytes["reduce_scatter_in"] == 4096 * 2 * 4
+# ---- checkpoint round trip (ADVICE r05): state_dict() is the gathered, torch.optim.Adam-compatible state (collective); a fresh sharded
+# optimiser loads it (every rank slices ITS rows), one more step on both routes -> still bit-identical.  The rank-local state is refused.
+saved = b_opt.state_dict()
+for i in ref["state"]:
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(saved["state"][i][k].reshape(-1), ref["state"][i][k].reshape(-1)), (i, k)
+import io
+buf = io.BytesIO(); torch.save(saved, buf); buf.seek(0)
+saved = torch.load(buf, weights_only=False)                          # through a file image, like accelerator.save_state / load_state
+c_model = Field()
+c_model.load_state_dict(b_model.state_dict())
+c_ddp = ud.wrap_ddp(c_model, grad_exchange="reduce_scatter", shard_min_numel=1024, process_group=dist.new_group([0, 1]))
+cfg = type("C", (), dict(lr_init=0.01, lr_final=0.001, max_steps=10, lr_delay_steps=0, lr_delay_mult=1.0, adam_beta1=0.9,
+                         adam_beta2=0.99, adam_eps=1e-8))
+c_opt, _ = tu.create_optimizer(cfg, c_model)
+c_opt.load_state_dict(saved)
+try:
+    c_opt.load_state_dict(b_opt.local_state_dict())
+    raise SystemExit("a rank-local optimiser state was accepted")
+except ValueError:
+    pass
+c_opt.load_state_dict(saved)
+a_ddp = ud.wrap_ddp(a_model, grad_exchange="all_reduce")
+g = torch.Generator().manual_seed(300 + rank)
+idx = torch.randint(0, 4096, (512,), generator=g)
+for ddp_, opt_, mdl in ((a_ddp, a_opt, a_model), (c_ddp, c_opt, c_model)):
+    opt_.zero_grad(set_to_none=True)
+    ddp_(idx).backward()
+    tu.clip_gradients(mdl, None, type("C", (), dict(grad_max_norm=0.0, grad_max_val=0.0)))
+    opt_.step()
+for (n, a), (_, c) in zip(a_model.named_parameters(), c_model.named_parameters()):
+    assert torch.equal(a, c), ("after the checkpoint round trip", n, float((a.detach() - c.detach()).abs().max()))
+# a rank without a table gradient still enters the collectives (zero contribution)
+c_opt.zero_grad(set_to_none=True)
+c_ddp(idx).backward()
+if rank == 1:
+    c_model.table.grad = None                                        # (what a batch that never touched the field leaves behind)
+c_opt.step()
 # gradient clipping needs the reduced gradient: refused with the tables sharded
 try:
     tu.clip_gradients(b_model, type("A", (), dict(sync_gradients=True))(), type("C", (), dict(grad_max_norm=1.0, grad_max_val=0.0)))
     raise SystemExit("clip_gradients accepted norm clipping on un-reduced table gradients")
 except NotImplementedError:
     pass
+# re-wrapping for the all-reduce exchange drops the marks of the sharded wrap
+d_ddp = ud.wrap_ddp(b_model, grad_exchange="all_reduce")
+assert not any(getattr(p, "_ucn_sharded", False) for p in b_model.parameters())
+assert type(tu.create_optimizer(cfg, b_model)[0]).__name__ == "FusedAdam"
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
 '''
@@ -255,7 +297,8 @@ def test_reduce_scatter_gradient_exchange_equals_all_reduce_world_size_2_gloo(tm
     """reduce-scatter -> sharded Adam (each rank steps 1 / N of the table rows) -> all-gather of the
     parameters, against DDP's all-reduce + the full Adam pass: identical parameters after 3 steps on 2 ranks (bit for bit),
     a rank-local NaN gradient handled like the reference handles it (nan_to_num on the REDUCED gradient), optimiser state
-    interchangeable through gathered_state_dict()."""
+    interchangeable through state_dict() / load_state_dict() (r06: save -> a new process group -> load -> one more step, bit-identical
+    to the all-reduce route; a rank without a table gradient does not hang the exchange; re-wrapping drops the shard marks)."""
     script = tmp_path / "worker.py"
     script.write_text(EXCHANGE_WORKER)
     port = str(H_free_port())

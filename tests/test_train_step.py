@@ -1244,3 +1244,45 @@ def test_fp32_training_step_runs_no_library_gemm(engine):
     assert np.isfinite(float(loss.detach()))
     for k, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+@pytest.mark.gpu
+def test_render_between_training_steps_sees_the_stepped_weights():
+    """FusedAdam writes parameters through raw pointers, which does not move autograd's version counters -- and the
+    inference caches (packed MLP weights, the fp16 table copies of the mixed route; models.py `field()`, sky.py) are keyed on
+    (data_ptr, _version).  The reference renders between training steps (train.py:330's periodic test render): render, step, render ->
+    the second render must be the STEPPED model's, i.e. equal to a fresh model loaded with the updated state_dict."""
+    import types
+    from ucnerf_amd.internal import train_utils as tu
+    spec = rm.make_spec("tiny")
+    sd = rm.init_state(spec, seed=77)
+    model, _ = H.hip_model(spec, sd)
+    n = 256
+    rays = {k: v.cuda() for k, v in rm.synthetic_rays(n, seed=78).items()}
+    batch = dict(rays, rand_vec=torch.randn(n, 6, generator=torch.Generator().manual_seed(79)).cuda())
+
+    def render(m, mixed):
+        m.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mixed):
+            r, _ = m(False, batch, 1.0, True)
+        return r[-1]["rgb"].float().clone()
+    cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                                anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                                hash_decay_mults=0.1, disable_multiscale_loss=False)
+    opt = tu.FusedAdam(model.parameters(), lr=0.05, betas=(0.9, 0.99), eps=1e-8)
+    for mixed in (False, True):
+        before = render(model, mixed)
+        model.train()
+        tb = {k: v[:, None, None, :] for k, v in rays.items()}
+        tb['rgb'] = torch.rand(n, 1, 1, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(80))
+        tb['lossmult'] = torch.ones(n, 1, 1, 1, device="cuda")
+        rend, hist = model(True, tb, 0.5, False, zero_glo=False)
+        loss = tu.compute_data_loss(tb, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg) + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        after = render(model, mixed)
+        fresh, _ = H.hip_model(spec, {k: v.detach().cpu() for k, v in model.state_dict().items()})
+        want = render(fresh, mixed)
+        assert float((after - before).abs().max()) > 1e-4, "the step did not change the rendering: stale packed operands"
+        assert torch.equal(after, want), float((after - want).abs().max())

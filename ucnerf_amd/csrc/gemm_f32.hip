@@ -371,14 +371,19 @@ uint32_t wgrad_chunk_rows(uint32_t M) {
 
 }  // namespace
 
-static int gemm_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
+// CU count and LDS per workgroup of the CURRENT device (cached per device id: a process may drive several GPUs)
+static void gemm_device_limits(int &cus, size_t &lds) {
+    static int s_cus[16] = {0};
+    static size_t s_lds[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { cus = 256; lds = 64u * 1024u; return; }
+    if (s_cus[dev] == 0) {
+        int v = 0, l = 0;
+        s_cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        s_lds[dev] = (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && l > 0) ? (size_t)l : 64u * 1024u;
     }
-    return n;
+    cus = s_cus[dev];
+    lds = s_lds[dev];
 }
 
 extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uint32_t ldw, const float *bias, uint32_t M, uint32_t N,
@@ -404,8 +409,12 @@ extern "C" int ucn_gemm_f32_ex(const float *X, uint32_t ldx, const float *W, uin
     const size_t res_lds = (size_t)kq * (nc + 1u) * 16u + (nt >= 2u ? 8u * kStageFloats * 4u : 0u);
     const uint32_t ntiles = ucn_div_up(M, 32);
     static const bool no_res = getenv("UCN_GEMM_NO_RESIDENT") != nullptr;            // A/B switch (tools/gemm_f32_bench.py)
-    if (N <= nc && res_lds <= 150u * 1024u && ntiles >= 64u && !no_res) {
-        const uint32_t wgs = ucn_div_up(ntiles, 8) < (uint32_t)gemm_num_cus() ? ucn_div_up(ntiles, 8) : (uint32_t)gemm_num_cus();
+    int num_cus = 256;
+    size_t max_lds = 0;
+    gemm_device_limits(num_cus, max_lds);
+    // (a device whose workgroups cannot hold the resident weight takes the weight-streaming kernel below)
+    if (N <= nc && res_lds <= 150u * 1024u && res_lds <= max_lds && ntiles >= 64u && !no_res) {
+        const uint32_t wgs = ucn_div_up(ntiles, 8) < (uint32_t)num_cus ? ucn_div_up(ntiles, 8) : (uint32_t)num_cus;
 #define UCN_GR(NT) hipLaunchKernelGGL((k_gemm_f32_res<NT, 2u>), dim3(wgs), dim3(512), res_lds, st, X, ldx, W, ldw, K, o)
         switch (nt) {
             case 1: UCN_GR(1); break;

@@ -96,6 +96,14 @@ def wrap_ddp(model, device_ids=None, grad_exchange="all_reduce", shard_min_numel
             dist.broadcast(p.data, src=dist.get_global_rank(opts["process_group"], 0) if opts.get("process_group") is not None else 0,
                            group=opts.get("process_group"))
         DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [n for n, _ in sharded])
+    else:
+        # a model wrapped before with grad_exchange="reduce_scatter": the marks and the ignore list must not outlive that wrap, or this
+        # all-reduce wrap would leave the tables out of the reducer while create_optimizer still selects ShardedFusedAdam
+        for p in model.parameters():
+            if getattr(p, "_ucn_sharded", False):
+                del p._ucn_sharded
+        if getattr(model, "_ddp_params_and_buffers_to_ignore", None):
+            DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [])
     ddp = DistributedDataParallel(model, device_ids=device_ids, **opts)
     ddp.grad_exchange = grad_exchange
     return ddp

@@ -925,6 +925,9 @@ class _SkyTrunkF32(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sigma, g_rgbl):
+        # (no gradient into the sample points: the reference's rays are data.  A caller that makes them differentiable -- pose refinement --
+        #  must take the layer-by-layer route, UCN_SKY_F32_CHAIN=0, which propagates it)
+        assert not ctx.needs_input_grad[0], "_SkyTrunkF32 does not propagate a gradient into the sample points (use UCN_SKY_F32_CHAIN=0)"
         G, WG = dense_f32.gemm, dense_f32.wgrad
         saved = ctx.saved_tensors
         pts4, Mv, Wa, Wr, hv = saved[:5]

@@ -404,6 +404,11 @@ class FusedAdam(torch.optim.Adam):
                                               arr([s['exp_avg'] for _, _, s in items]), arr([s['exp_avg_sq'] for _, _, s in items]),
                                               (ctypes.c_uint64 * n)(*[p.numel() for p, _, _ in items]), n, float(group['lr']),
                                               float(beta1), float(beta2), float(group['eps']), step, 1, _lib.stream()))
+        # the kernels wrote through raw pointers: tell autograd's version counters, which key the inference caches of the packed MLP
+        # weights and of the half-precision table copies (models.py `field()`, sky.py) -- a render between two training steps
+        # (train.py:330's periodic test render) must not reuse the operands packed before the step
+        for _, p, _ in held:
+            torch.autograd.graph.increment_version(p)
         return loss
 
 
@@ -419,8 +424,10 @@ class ShardedFusedAdam(FusedAdam):
     Every rank ends the step with identical tables (the same bits: each element is computed on exactly one rank).  With two
     ranks the result is bit-identical to the all-reduce route (a + b is commutative); with more, equal up to the
     summation order of the collective.  zero_grad() also clears the full-size table gradients, which are not in
-    param_groups.  `gathered_state_dict()` returns a torch.optim.Adam-compatible state (moments all-gathered) for
-    checkpoints that must load into the unsharded optimiser."""
+    param_groups.  `state_dict()` (= `gathered_state_dict()`, collective) is torch.optim.Adam-compatible over the FULL parameters
+    (moments all-gathered) and `load_state_dict()` slices such a state back to this rank's rows: checkpoints move between the
+    sharded and the unsharded optimiser and between world sizes (r06, ADVICE r05: the inherited rank-local state_dict loaded
+    rank 0's rows into every rank without an error)."""
 
     def __init__(self, params, process_group=None, **kw):
         import torch.distributed as dist
@@ -461,10 +468,9 @@ class ShardedFusedAdam(FusedAdam):
             raise NotImplementedError("ShardedFusedAdam.step(closure): re-evaluating the model between the exchange steps is not supported")
         live = []
         for p, shard in self._tables:
-            if p.grad is None:
-                shard.grad = None
-                continue
-            g = p.grad.contiguous().view(-1)
+            # a table without a gradient on THIS rank (none of its rays touched the field) still takes part in the collectives -- the
+            # other ranks enter them -- with a zero contribution (skipping would hang the job)
+            g = torch.zeros(p.numel(), device=p.device, dtype=p.dtype) if p.grad is None else p.grad.contiguous().view(-1)
             out = torch.empty(shard.numel(), device=g.device, dtype=g.dtype)
             dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.AVG, group=self._group)
             if not (out.is_cuda and out.numel() >= self.MIN_NUMEL):
@@ -475,23 +481,57 @@ class ShardedFusedAdam(FusedAdam):
         for p, shard in live:
             # out-of-place send buffer: the shard is a slice of the receive buffer (see _exchange in dist.py for the in-place form)
             dist.all_gather_into_tensor(p.data.view(-1), shard.data.clone(), group=self._group)
+            torch.autograd.graph.increment_version(p)           # (p.data is a detached alias: its writes do not count for p)
             shard.grad = None
         return loss
+
+    def state_dict(self):
+        """torch.optim.Adam's layout over the FULL parameters: the moments of the sharded tables all-gathered.  COLLECTIVE -- every
+        rank must call it, which is what the reference's checkpoint flow does (checkpoints.py:24 -> accelerator.save_state calls
+        optimizer.state_dict() on every process and writes on the main one).  The rank-local form (1 / N of each table's moments:
+        shapes that load without an error into the wrong rows of another rank) is `local_state_dict()`."""
+        return self.gathered_state_dict()
+
+    def local_state_dict(self):
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Accepts the full-size state `state_dict()` returns (or one saved by FusedAdam / torch.optim.Adam over model.parameters()):
+        every rank keeps rows [rank n, (rank + 1) n) of each sharded table's moments, whatever world size wrote the checkpoint."""
+        import copy
+        sd = {"state": dict(state_dict["state"]), "param_groups": copy.deepcopy(state_dict["param_groups"])}
+        order = [p for g in self.param_groups for p in g['params']]
+        shard_ids = {id(shard): p for p, shard in self._tables}
+        for i, q in enumerate(order):
+            if id(q) in shard_ids and i in sd["state"]:
+                full, n = shard_ids[id(q)].numel(), q.numel()
+                st = dict(sd["state"][i])
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    v = st[k]
+                    if v.numel() != full:
+                        raise ValueError(f"ShardedFusedAdam.load_state_dict: parameter {i} carries {v.numel()} moment elements, expected the "
+                                         f"full table's {full} (a rank-local state of another run? save with state_dict(), not local_state_dict())")
+                    st[k] = v.reshape(-1)[self._rank * n:(self._rank + 1) * n].clone().view_as(q)
+                sd["state"][i] = st
+        super().load_state_dict(sd)
 
     def gathered_state_dict(self):
         """The optimiser state in torch.optim.Adam's layout over the FULL parameters (moments all-gathered): loads into
         FusedAdam / torch.optim.Adam built on model.parameters().  Collective: every rank must call it."""
         import torch.distributed as dist
-        sd = self.state_dict()
+        sd = super().state_dict()
         order = [p for g in self.param_groups for p in g['params']]
         full_of = {id(shard): p for p, shard in self._tables}
+        sd = dict(sd, state=dict(sd['state']))                 # (torch hands out the optimiser's OWN per-parameter dicts: copy before editing)
         for i, q in enumerate(order):
             if id(q) in full_of and i in sd['state']:
                 p = full_of[id(q)]
+                st = dict(sd['state'][i])
                 for k in ('exp_avg', 'exp_avg_sq'):
                     full = torch.empty(p.numel(), device=p.device, dtype=p.dtype)
-                    dist.all_gather_into_tensor(full, sd['state'][i][k].contiguous().view(-1), group=self._group)
-                    sd['state'][i][k] = full.view_as(p)
+                    dist.all_gather_into_tensor(full, st[k].contiguous().view(-1), group=self._group)
+                    st[k] = full.view_as(p)
+                sd['state'][i] = st
         return sd
 
 
