@@ -200,3 +200,23 @@ def test_live_sky_layer_overflows_by_the_references_own_formula():
     # well before the overflow the layer's "colour" has left [0, 1]: at sigma = 2 it is already in the thousands, of either sign
     # (119 negative weights alpha_i T_i against the one positive weight of the last sample, whose spacing is +1e10)
     assert bool(torch.isfinite(out["live"]).all()) and float(out["live"].abs().max()) > 100.0
+
+
+@pytest.mark.parametrize("name", ["train_step.npz", "train_step_sky.npz"])
+def test_oracle_losses_match_reference_values(name):
+    """oracle/losses.py (the oracle side's own restatement of train_utils.py:149-305 / stepfun.py:297-307, 395-403 / math.py:110-133)
+    on the reference's own per-level outputs stored in the G10 fixtures, against the loss values the imported reference produced for
+    them (tests/golden/make_golden.py).  The product's O(S) forms are held to the same values by tests/test_train_step.py."""
+    from oracle import losses as ol
+    fx = H.load(name)
+    hist = [dict(sdist=fx[f"L{l}_sdist"], weights=fx[f"L{l}_weights"]) for l in range(2)]
+    rend = [dict(rgb=fx[f"L{l}_rgb"], weights=fx[f"L{l}_weights"]) for l in range(2)]
+    batch = {k[4:]: v for k, v in fx.items() if k.startswith("ray_")}
+    batch = {k: (v[:, None, None, :] if v.dim() == 2 else v[:, None, None]) for k, v in batch.items()}
+    assert abs(float(ol.data_loss(batch, rend)) - float(fx["loss_data"])) <= 1e-6
+    a = float(ol.anti_interlevel_loss(hist))
+    assert abs(a - float(fx["loss_anti_interlevel"])) <= 2e-6 * max(1.0, float(fx["loss_anti_interlevel"])), (a, float(fx["loss_anti_interlevel"]))
+    d = float(ol.distortion_loss(hist))
+    assert abs(d - float(fx["loss_distortion"])) <= 1e-6 * max(1.0, float(fx["loss_distortion"])), (d, float(fx["loss_distortion"]))
+    if "loss_sky" in fx:
+        assert abs(0.002 * float(ol.sky_loss(batch, rend)) - float(fx["loss_sky"])) <= 1e-7

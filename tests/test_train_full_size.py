@@ -40,9 +40,19 @@ def _losses(tu, batch, rend, hist):
                 distortion=tu.distortion_loss(hist, CFG), hash_decay=tu.hash_decay_loss(hist, CFG))
 
 
+def _oracle_losses(batch, rend, hist):
+    """the oracle side's OWN restatement of the reference's losses (oracle/losses.py, pinned to reference-generated values by
+    tests/test_oracle_golden.py) -- not the product's train_utils, which the HIP side uses (VERDICT r05 weak #1)"""
+    from oracle import losses as ol
+    return dict(data=ol.data_loss(batch, rend, charb_padding=CFG.charb_padding, data_loss_mult=CFG.data_loss_mult,
+                                  data_coarse_loss_mult=CFG.data_coarse_loss_mult),
+                anti_interlevel=ol.anti_interlevel_loss(hist, pulse_width=CFG.pulse_width, anti_interlevel_loss_mult=CFG.anti_interlevel_loss_mult),
+                distortion=ol.distortion_loss(hist, distortion_loss_mult=CFG.distortion_loss_mult),
+                hash_decay=ol.hash_decay_loss(hist, hash_decay_mults=CFG.hash_decay_mults))
+
+
 def oracle_step(spec, sd, rays, target, noise, train_frac):
     """The reference's step on the host: forward (training branches), losses, backward.  Returns losses and gradients."""
-    from ucnerf_amd.internal import train_utils as tu
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.is_floating_point() and not k.endswith("grid_sizes")}
     state = dict(sd)
@@ -50,21 +60,27 @@ def oracle_step(spec, sd, rays, target, noise, train_frac):
     rend, hist = rm.model_forward(spec, state, rays, noise, train_frac=train_frac, compute_extras=False, training=True)
     batch = {k: v[:, None, None, :] for k, v in rays.items()}
     batch['rgb'] = target[:, None, None, :]
+    if 'lossmult' not in batch:
+        batch['lossmult'] = torch.ones(N_RAYS, 1, 1, 1)
     rend = [{k: (v[:, None, None] if torch.is_tensor(v) else v) for k, v in r.items()} for r in rend]
     hist = [{k: (v[:, None, None] if torch.is_tensor(v) and v.dim() >= 1 and k != 'loss_hash_decay' else v)
              for k, v in h.items()} for h in hist]
-    losses = _losses(tu, batch, rend, hist)
+    losses = _oracle_losses(batch, rend, hist)
     sum(losses.values()).backward()
+    oracle_step.sdist = [h['sdist'].detach().reshape(N_RAYS, -1).clone() for h in hist]      # for the pinned-position run
     return {k: float(v.detach()) for k, v in losses.items()}, {k: p.grad for k, p in params.items() if p.grad is not None}
 
 
-def hip_step(model, rays, target, noise, train_frac, bf16):
+def hip_step(model, rays, target, noise, train_frac, bf16, sdist=None):
     from ucnerf_amd.internal import train_utils as tu
     model.train()
     model.zero_grad(set_to_none=True)
     batch = {k: v[:, None, None, :].cuda() for k, v in rays.items()}
     batch['rgb'] = target[:, None, None, :].cuda()
     batch = H.pin_noise(batch, noise)
+    if sdist is not None:                        # the oracle's own sample fenceposts (see test_..._pinned_sample_positions)
+        for lvl, s in enumerate(sdist):
+            batch['march_noise'][lvl]['sdist'] = s.cuda()
     batch['rand_vec'] = batch['rand_vec'][:, None, None, :]
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16):
         rend, hist = model(True, batch, train_frac, False, zero_glo=False)
@@ -154,6 +170,97 @@ def test_config2_training_step_full_tables_vs_oracle_autograd():
             print(f"  {k}: {v[0]:.6e} {v[1]:.6e} {v[2]:.3e}")
     b_l, b_g = hip_step(model, rays, target, noise, 0.5, bf16=True)
     _check_bf16(want_l, want_g, b_l, b_g)
+
+
+def _nerf_level_features(model, spec, sd, rays, noise, sdist):
+    """The NeRF level's damped, multisample-averaged grid features [N, S, L, C] at the SAME fenceposts, cone draws and tables: (a) the
+    oracle's torch formulation (render.py:94-152 cone cast -> coord.py contraction -> grid lookup -> erf damping -> mean of six), (b) the
+    fused HIP gather, called through the C ABI."""
+    import ctypes
+    from ucnerf_amd import _lib
+    lib = _lib.load()
+    fs = spec.nerf
+    nz = noise[-1]
+    tdist = sdist * rays['far'] + (1 - sdist) * rays['near']
+    with torch.no_grad():
+        means, stds, _ = rm.cone_multisamples(tdist, rays['origins'], rays['directions'], rays['cam_dirs'], rays['radii'], nz.rand_vec,
+                                              spec.std_scale, nz.flip, nz.spin)
+        _, _, _, feat = rm.field_density_features(fs, sd, means, stds)
+    n, S = sdist.shape[0], sdist.shape[1] - 1
+    L, C = fs.num_grid_levels, fs.grid_level_dim
+    want = feat.reshape(n, S, L, C)
+    dev = "cuda"
+    g = {k: v.to(dev).contiguous() for k, v in rays.items()}
+    basis = torch.empty(n, 6, device=dev)
+    rv = nz.rand_vec.to(dev).contiguous()
+    _lib.check(lib.ucn_cone_basis(g['cam_dirs'].data_ptr(), rv.data_ptr(), n, basis.data_ptr(), _lib.stream()))
+    geom = (sdist.to(dev).contiguous(), g['near'].reshape(-1).contiguous(), g['far'].reshape(-1).contiguous(), g['origins'], g['directions'], basis,
+            g['radii'].reshape(-1).contiguous(), nz.flip.to(dev).contiguous(), nz.spin.to(dev).contiguous())
+    desc = _lib.UcnField.from_buffer_copy(model.nerf_mlp.field())
+    out = torch.empty(L, n * S, C, device=dev)
+    _lib.check(lib.ucn_march_features(ctypes.byref(desc), *[t.data_ptr() for t in geom], float(model.std_scale), n, S, 0, 0, out.data_ptr(),
+                                      None, None, _lib.stream()))
+    got = out.reshape(L, n, S, C).permute(1, 2, 0, 3).float().cpu()
+    return got, want
+
+
+def test_config2_table_gradient_with_pinned_sample_positions():
+    """the hashed levels of the NeRF grid are held to the oracle at 1e-1 (measured 1.4 - 3.4 %) where the proposal
+    grid agrees to 1e-7, and the stated reason -- positions that differ by an ulp, turned into other cells by levels up to 2^19 wide --
+    was an argument.  Three measurements replace it:
+
+    1. The same step with BOTH levels' sample fenceposts handed to the HIP graph from the oracle's own forward
+       (batch['march_noise'][l]['sdist'], a test hook beside the pinned random draws): the per-level differences fall by about a third
+       (0.23 - 2.4 % instead of 0.36 - 3.4 %), the losses agree to 2e-5.  So the resampling is part of it, NOT all of it.
+    2. The dense layers between the loss and the grid: rgb layer 4e-5, colour layers 2-4e-4, density_layer.2 2e-4, density_layer.0 (the one
+       whose weight gradient is d h0^T FEATURES) 4e-3 -- the distance grows towards the features.
+    3. The features themselves, at the oracle's fenceposts, oracle formulation against the fused gather (both pinned elsewhere: the
+       gather's table arithmetic bit for bit against grid_oracle.c, its geometry against the G3 / G4 fixtures): their relative
+       difference DOUBLES from level to level -- 1.9e-7 at a grid side of 17, 1.6e-2 at 524 289 -- i.e. it is proportional to the
+       resolution, at a constant 3e-8 of the unit cube: half an ulp of a coordinate near 0.5.  The six points of the cone cast are
+       computed in-kernel in another operation order than torch's; an ulp of position is 3 % of a cell at the finest level, and the
+       trilinear weights move by that much.  A sample sees a 1 % different top-level feature, hence a slightly different hidden
+       state, hence a different gradient on EVERY level, the dense ones included: that is the 0.2 - 0.9 % of levels 0 - 3.
+    The table-gradient kernel itself is the exact adjoint of the gather at the gather's own positions
+    (tests/test_full_size.py::test_featurisation_is_linear_with_closed_form_on_ones_and_exact_adjoint, 1e-5 of the absolute sum) and equals
+    the global-atomic kernel row for row; the proposal grid (resolution <= 512) agrees with the oracle to 1e-7 in this very run."""
+    model, spec, sd, rays, target, noise = _case("B")
+    want_l, want_g = oracle_step(spec, sd, rays, target, noise, 0.5)
+    got_l, got_g = hip_step(model, rays, target, noise, 0.5, bf16=False, sdist=oracle_step.sdist)
+    for k, v in want_l.items():
+        assert abs(got_l[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got_l[k], v)
+    rep = _check_fp32(spec, want_l, want_g, got_l, got_g, lambda name, lvl: 1.0)
+    print("fp32 route with the oracle's sample positions, per-level table gradients (sum|g| hip, oracle, rel L2 of the difference):")
+    for k, v in rep.items():
+        print(f"  {k}: {v[0]:.6e} {v[1]:.6e} {v[2]:.3e}")
+    dense = {}
+    for name, w in want_g.items():
+        if not name.endswith("encoder.embeddings"):
+            dense[name] = float((got_g[name].double() - w.double()).norm() / (w.double().norm() + 1e-30))
+            print(f"  dense {name}: rel L2 {dense[name]:.3e}")
+    for k, v in rep.items():
+        assert v[2] <= (2.5e-3 if k.startswith("prop") else 1.2e-2 if int(k.split("[")[1][:-1]) < 4 else 3e-2), (k, v)
+    assert dense["nerf_mlp.rgb_layer.weight"] <= 2e-4 and dense["nerf_mlp.lin_second_stage_1.weight"] <= 1.5e-3
+    assert dense["nerf_mlp.density_layer.0.weight"] >= 3 * dense["nerf_mlp.rgb_layer.weight"]          # grows towards the features
+    assert all(v <= 2e-4 for k, v in dense.items() if k.startswith("prop_mlp_0"))
+    # 3. the features at the oracle's fenceposts
+    got, want = _nerf_level_features(model, spec, sd, rays, noise, oracle_step.sdist[-1])
+    _, offsets, grid_sizes, _ = spec.nerf.layout()
+    print("NeRF-level features at the oracle's fenceposts, oracle formulation vs fused gather, per level:")
+    print("  level  grid side   rel L2     share of (sample, level) entries off by > 1e-4")
+    off_any = torch.zeros(got.shape[:2], dtype=torch.bool)
+    rel, share = [], []
+    for l in range(got.shape[2]):
+        d = (got[:, :, l] - want[:, :, l]).abs().amax(dim=-1)
+        rel.append(float((got[:, :, l] - want[:, :, l]).norm() / (want[:, :, l].norm() + 1e-30)))
+        share.append(float((d > 1e-4).float().mean()))
+        off_any |= d > 1e-4
+        print(f"  {l:5d}  {int(grid_sizes[l]):9d}  {rel[-1]:.3e}  {share[-1]:.5f}")
+    print(f"  samples with at least one such level: {float(off_any.float().mean()):.4f}")
+    # every level: no further from the oracle than a position difference of 1e-7 of the unit cube (1.7 ulp at 0.5) explains
+    for l in range(got.shape[2]):
+        assert rel[l] <= 1e-7 * float(grid_sizes[l]) + 2e-7, (l, rel[l], int(grid_sizes[l]))
+    assert rel[-1] >= 30 * rel[5]                              # ... and proportional to the resolution, not a constant floor
 
 
 def test_waymo_gin_grid_training_step_full_tables_vs_oracle_autograd():

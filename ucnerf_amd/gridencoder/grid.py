@@ -107,12 +107,11 @@ class GridEncoder(nn.Module):
     def reset_parameters(self):
         self.embeddings.data.uniform_(-self.init_std, self.init_std)
 
-    def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> "
-                f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
-                f"gridtype={self.gridtype} align_corners={self.align_corners} interpolation={self.interpolation}")
+    def extra_repr(self):
+        # (nn.Module's own hook: `print(model)` lists the table's geometry; nothing reads this string)
+        finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
+        return (f"{self.input_dim}-d points, {self.num_levels} levels x {self.level_dim} features, side {self.base_resolution} .. {finest}, "
+                f"{self.embeddings.shape[0]:,} rows, {self.gridtype} / {self.interpolation}" + (", align_corners" if self.align_corners else ""))
 
     def forward(self, inputs, bound=1):
         inputs = (inputs + bound) / (2 * bound)

@@ -1272,6 +1272,13 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         _lib.check(lib.ucn_resample(_lib.ptr(sdist_prev), _lib.ptr(wp), n_prev, dilation, anneal,
                                     float(model.resample_padding), u_tab.data_ptr(), _lib.ptr(jitter),
                                     0 if jitter is None else jitter.shape[1], max_jitter, N, S, sdist.data_ptr(), st))
+        pn_s = (pinned[i_level] if pinned is not None else {}).get('sdist') if rand else None
+        if pn_s is not None:
+            # test hook, like the pinned random draws: this level's sample fenceposts handed in (the oracle's own) instead of the
+            # resampling kernel's -- tests/test_train_full_size.py uses it to separate "1-ulp sample positions amplified by 2^19-wide
+            # levels" from anything the backward could be doing wrong.  No gradient flows through the fenceposts in the reference
+            # either (stepfun.py:251-294 works on detached weights).
+            sdist = _f32(pn_s, N, S + 1).clone()
         _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
         geom = (sdist, near, far, o, d, basis, rad, flip, spin)
         half_table = torch.is_autocast_enabled() and mlp.encoder.level_dim % 2 == 0 and getattr(model, 'autocast_half_tables', True)
