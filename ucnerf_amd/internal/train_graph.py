@@ -1274,7 +1274,7 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
                                     0 if jitter is None else jitter.shape[1], max_jitter, N, S, sdist.data_ptr(), st))
         pn_s = (pinned[i_level] if pinned is not None else {}).get('sdist') if rand else None
         if pn_s is not None:
-            # test hook, like the pinned random draws: this level's sample fenceposts handed in (the oracle's own) instead of the
+            # test hook, like the pinned random draws: this level's sample fenceposts handed in by the caller instead of the
             # resampling kernel's -- tests/test_train_full_size.py uses it to separate "1-ulp sample positions amplified by 2^19-wide
             # levels" from anything the backward could be doing wrong.  No gradient flows through the fenceposts in the reference
             # either (stepfun.py:251-294 works on detached weights).
