@@ -531,12 +531,12 @@ def test_fitted_field_march_and_compaction_vs_oracle():
 
     1. The fitted field as it is, with compact_min_weight = 0 and with 4e-8 (north_star's early-termination sample compaction: ballot /
        prefix-sum alive list, the colour layers only for the samples whose compositing weight reaches the threshold): acc <= 1e-4,
-       depth <= 1e-3 away from the 0.6 switch, rgb: 99 % of the rays <= 5e-5 and the worst ray <= 3e-4 (+ num_nerf_samples x threshold).
+       depth <= 1e-3 away from the 0.6 switch, rgb: 99 % of the rays <= 1e-4 (north_star's bar) and the worst ray <= 3e-4 (+ num_nerf_samples x threshold).
        The worst-ray bar is NOT north_star's 1e-4, and the numbers say why: over fits of 100-300 steps and two seeds the worst of 1 024
        rays measured 0.8e-4 ... 1.6e-4 (median ray 8e-6; the fit itself is not bit-reproducible: its table gradients meet in float
        atomics) -- on a fitted field a few rays graze a surface, where one ulp in a resampled position moves weight between
        differently coloured samples.  That is fp32 itself, not the split-f16 engine: the exact-fp32-product mode is asserted to
-       be as far from the oracle (mode 1 <= 1.5 x mode 0 + 2e-5), and both engines agree with each other to 2e-5.  (The benchmark's
+       be as far from the oracle (mode 1 <= 1.5 x mode 0 + 2e-5), and both engines agree with each other to 5e-5 (measured 1.9e-5).  (The benchmark's
        random-init field holds 1e-4 with a factor 3 to spare: test_config_B_full_tables_vs_oracle.)
        MEASURED alive fraction: 1.0 -- after such a fit the proposal resampling has moved all 128 samples onto the surfaces, every
        sample weighs >= 1e-5 -- so on this field the compacted route is exercised end to end but removes nothing (the reason it is
@@ -605,8 +605,8 @@ def test_fitted_field_march_and_compaction_vs_oracle():
         d_modes = float((got["rgb"].reshape(n, 3).float() - exact["rgb"].reshape(n, 3).float()).abs().max())
         print(f"  compact_min_weight {thr:g}: rgb vs oracle: worst ray {e:.3e}, 99 % of the rays <= {q99:.3e}, median {float(per_ray(got).median()):.2e}; "
               f"exact-fp32 mode: worst ray {e_exact:.3e}; split vs exact mode {d_modes:.2e}" + ("" if alive is None else f"; alive fraction {alive:.4f}"))
-        assert e <= 3e-4 + S * thr and q99 <= 5e-5 + S * thr, (thr, e, q99)
-        assert e <= 1.5 * e_exact + 2e-5 + S * thr and d_modes <= 2e-5 + S * thr, (e, e_exact, d_modes)
+        assert e <= 3e-4 + S * thr and q99 <= 1e-4 + S * thr, (thr, e, q99)
+        assert e <= 1.5 * e_exact + 2e-5 + S * thr and d_modes <= 5e-5 + S * thr, (e, e_exact, d_modes)
         _check_other_keys(got, want, n)
     # ---- 2. the sharpened field
     with torch.no_grad():

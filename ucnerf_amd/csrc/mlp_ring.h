@@ -65,6 +65,35 @@ __device__ __forceinline__ f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 
 // hi = f16(v), lo = f16(v - hi): |v - hi - lo| <= 2^-22 |v| while lo is a normal f16 (|v| >= 2^-3); the packers'
 // power-of-two scaling (field_mlp_h.hip) keeps the operands in that window and below the f16 maximum.
+#ifndef UCN_SPLIT_ASM
+// r06: the operand split with COMPILER-VISIBLE instructions (gemm_h3.hip's form: -1.0f made opaque so that the fma is not folded into a
+// subtraction and hipcc itself selects v_fma_mix{lo,hi}_f16): 5 instructions per pair instead of 3 (measured on the NeRF-level MLP alone:
+// 4.899 against 4.878 ms per 8.4 M samples, profiles/r06/mlp_waves_ab.txt), but the hazard recogniser sees them.
+// The inline-asm form below (-DUCN_SPLIT_ASM: the r02-r05 form, kept for the A/B) can be handed, as its output, the register an MFMA issued just before still reads as its A operand -- for an
+// asm statement no wait states are inserted (tools/isa_asm_hazard.py lists the places; r06 found it the hard way in k_gemm_h3<4, 16>).
+__device__ __forceinline__ float rsplit_neg1() {
+    float v = -1.0f;
+    asm("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ void rsplit8(const float (&v)[8], h8 &hi, h8 &lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float neg1 = rsplit_neg1();
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        h2 hp, lp;
+        hp[0] = (_Float16)v[2 * p];
+        hp[1] = (_Float16)v[2 * p + 1];
+        lp[0] = (_Float16)__builtin_fmaf((float)hp[0], neg1, v[2 * p]);
+        lp[1] = (_Float16)__builtin_fmaf((float)hp[1], neg1, v[2 * p + 1]);
+        hw[p] = __builtin_bit_cast(uint32_t, hp);
+        lw[p] = __builtin_bit_cast(uint32_t, lp);
+    }
+    hi = __builtin_bit_cast(h8, hw);
+    lo = __builtin_bit_cast(h8, lw);
+}
+#else
 __device__ __forceinline__ void rsplit8(const float (&v)[8], h8 &hi, h8 &lo) {
     // three VALU instructions per PAIR of values instead of six: hi pair = v_cvt_pk_f16_f32; each lo = f16(v - hi) is
     // ONE v_fma_mix{lo,hi}_f16 (f16 source hi, f32 constant -1, f32 source v: the exact difference rounded once, into its
@@ -83,6 +112,7 @@ __device__ __forceinline__ void rsplit8(const float (&v)[8], h8 &hi, h8 &lo) {
     hi = __builtin_bit_cast(h8, hw);
     lo = __builtin_bit_cast(h8, lw);
 }
+#endif
 // ReLU as ONE v_max_i32 on the bit pattern: negative floats (and -0) are negative integers.  fmaxf costs two VALU
 // instructions here (IEEE mode canonicalises the MFMA result first).  A negative NaN becomes 0, a positive one stays.
 __device__ __forceinline__ float relu_bits(float x) {
