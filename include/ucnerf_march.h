@@ -502,6 +502,13 @@ int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K, int transp
 int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias, uint32_t M,
                 uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias,
                 uint32_t ldr, uint32_t rgroup, float *ymax, ucn_stream_t stream);
+/* ucn_gemm_h3_x2: the same with a second, 4-wide operand pair added in the epilogue (exact fp32 FMAs) before the ReLU / mask:
+ *   Y = ... + X2[M, 4] W2[N, 4]^T -- the [hidden | 3-d point] input of the sky NeRF's skip layer (models.py:790-795) and the
+ *   [view branch | density row] gradient into its last trunk layer (models.py:800-806) as ONE pass over the [M, 256] output. */
+int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias, uint32_t M,
+                   uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias,
+                   uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2, float *ymax,
+                   ucn_stream_t stream);
 uint64_t ucn_wgrad_h3_ws_floats(uint32_t N, uint32_t K, uint64_t M);
 int ucn_wgrad_h3(const float *GY, uint32_t ldg, const float *X, uint32_t ldx, const float *gmax, const float *xmax, uint32_t M, uint32_t N,
                  uint32_t K, float *ws, float *GW, float *gb, ucn_stream_t stream);

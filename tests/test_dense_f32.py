@@ -217,3 +217,28 @@ def test_split_engine_amax_travels_and_goes_stale_safely():
         assert not hasattr(y, "_ucn_amax")
     finally:
         D.set_engine(prev)
+
+
+@pytest.mark.parametrize("M,N,K,relu,masked", [(120 * 300, 256, 256, True, False), (8192, 256, 128, False, True), (5000, 128, 64, True, True), (1000, 256, 256, True, False)])
+def test_gemm_second_narrow_operand_in_the_epilogue(M, N, K, relu, masked, engine):
+    """x2 / w2 (r06): out = x w^T + bias + x2[M, 4] w2[N, 4]^T, then ReLU / mask -- the sky NeRF's [hidden | 3-d point] skip layer and its
+    [view branch | density row] gradient as ONE pass over the output (split engine: inside ucn_gemm_h3_x2's epilogue, exact fp32 FMAs;
+    exact engine and short operands: two accumulating calls).  Against float64."""
+    from ucnerf_amd.internal import dense_f32 as D
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    x2 = torch.zeros(M, 4, device="cuda"); x2[:, :3] = torch.randn(M, 3, device="cuda", generator=g)
+    w2 = torch.zeros(N, 4, device="cuda"); w2[:, :3] = torch.randn(N, 3, device="cuda", generator=g)
+    mask = torch.relu(torch.randn(M, N, device="cuda", generator=g)) if masked else None
+    got = D.gemm(x, w, b, D.RELU if relu else 0, mask=mask, x2=x2, w2=w2)
+    want = x.double() @ w.double().t() + b.double() + x2.double() @ w2.double().t()
+    if relu:
+        want = torch.relu(want)
+    if masked:
+        want = torch.where(mask > 0, want, torch.zeros_like(want))
+    scale = (x.double().abs() @ w.double().abs().t() + x2.double().abs() @ w2.double().abs().t()).max().item() + 1.0
+    assert float((got.double() - want).abs().max()) <= _eps(engine, 4e-7) * scale * max(1.0, K ** 0.5 / 4)
+    if engine == "split" and M >= D.H3_MIN_ROWS and hasattr(got, "_ucn_amax"):
+        assert float(got._ucn_amax[0]) == float(got.abs().max())

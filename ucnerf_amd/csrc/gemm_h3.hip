@@ -376,7 +376,12 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
 #endif
     if constexpr (NT >= 2u) {
         if ((oe.flags & kGemmVec) && NT * 32u <= oe.N) {
-            mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, 0u, lane);
+            if constexpr (NT == 8u) {                                   // the second operand pair: 256-wide outputs only (the host checks)
+                if (oe.x2) mx = gemm_store_staged<NT, true, true>(acc, oe, tile, m0, 0u, lane);
+                else mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, 0u, lane);
+            } else {
+                mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, 0u, lane);
+            }
             done = true;
         }
     }
@@ -589,6 +594,16 @@ extern "C" int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K,
 extern "C" int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias,
                            uint32_t M, uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm,
                            const float *rowbias, uint32_t ldr, uint32_t rgroup, float *ymax, ucn_stream_t stream) {
+    return ucn_gemm_h3_x2(X, ldx, packed, xmax, wmax, bias, M, N, K, flags, Y, ldy, mask, ldm, rowbias, ldr, rgroup, nullptr, 0, nullptr, 0, ymax, stream);
+}
+
+extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias,
+                              uint32_t M, uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm,
+                              const float *rowbias, uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2,
+                              float *ymax, ucn_stream_t stream) {
+    UCN_REQUIRE(!X2 == !W2, "gemm_h3: the 4-wide second operand pair needs both X2 [M, 4] and W2 [N, 4]");
+    UCN_REQUIRE(!X2 || (ldx2 >= 4 && ldw2 >= 4 && ldx2 % 4u == 0u && ldw2 % 4u == 0u && (((uintptr_t)X2 | (uintptr_t)W2) & 15u) == 0u),
+                "gemm_h3: X2 / W2 rows are 4 floats, 16-byte aligned (ldx2 %u ldw2 %u)", ldx2, ldw2);
     UCN_REQUIRE(X && packed && Y && xmax && wmax, "gemm_h3: null pointer argument");
     UCN_REQUIRE(N >= 1 && N <= 256, "gemm_h3: N = %u (1 .. 256: one column block)", N);
     UCN_REQUIRE(K % 4u == 0u && ldx % 4u == 0u && ldx >= K && ldy >= N,
@@ -601,7 +616,9 @@ extern "C" int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, con
     const bool vec = N % 4u == 0u && ldy % 4u == 0u && ((uintptr_t)Y & 15u) == 0u && (!bias || ((uintptr_t)bias & 15u) == 0u) &&
                      (!(flags & (int)kGemmMask) || (ldm % 4u == 0u && ((uintptr_t)mask & 15u) == 0u)) &&
                      (!rowbias || (ldr % 4u == 0u && ((uintptr_t)rowbias & 15u) == 0u));
+    UCN_REQUIRE(!X2 || (vec && N == 256u), "gemm_h3: the second operand pair is built for 256-wide outputs with the vector epilogue (N %u)", N);
     GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
+    o.x2 = X2; o.w2 = W2; o.ldx2 = ldx2; o.ldw2 = ldw2;
     const uint32_t ks = h3_ksteps(K);
     H3Scales sc{xmax, wmax, reinterpret_cast<uint32_t *>(ymax)};
     const dim3 grid(ucn_div_up(M, 32u * kH3Waves));

@@ -123,12 +123,19 @@ def _rows(t):
     return out
 
 
-def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None, rgroup=0):
-    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (+ rowbias[row // rgroup]) (ReLU); x / w as returned by _rows (equal padded K).
-    `out` may be a column view.  mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below): out = mask > 0 ? out : 0
-    as the last step of the epilogue."""
+def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None, rgroup=0, x2=None, w2=None):
+    """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (+ rowbias[row // rgroup]) (+ x2[M, 4] w2[N, 4]^T) (ReLU); x / w as returned by _rows
+    (equal padded K).  `out` may be a column view.  mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below):
+    out = mask > 0 ? out : 0 as the last step of the epilogue.  x2 / w2 (r06): a second, 4-wide operand pair (zero-padded 3-d points
+    against their weight columns, a density-row gradient against its weight row) added inside the split engine's epilogue; on the exact
+    engine and for short operands the same sum as a second accumulating call."""
     lib = _lib.load()
     M, K = x.shape
+    if x2 is not None and not (_ENGINE == "split" and M >= H3_MIN_ROWS and (w.shape[0] if n_out is None else n_out) == 256):
+        # two passes: the wide product (bias / row bias), then the narrow one accumulating, with the ReLU / mask behind the sum
+        first = int(flags) & ACCUMULATE
+        out = gemm(x, w, bias, first, out, n_out, None, rowbias, rgroup)
+        return gemm(x2, w2, None, (int(flags) & ~ACCUMULATE) | ACCUMULATE, out, n_out, mask)
     N = w.shape[0] if n_out is None else n_out
     assert w.shape[1] == K, (x.shape, w.shape)
     if out is None:
@@ -146,10 +153,14 @@ def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None
         _lib.check(lib.ucn_pack_h3(w.data_ptr(), w.stride(0), N, K, 0, packed.data_ptr(), wmax.data_ptr(), _lib.stream()))
         xmax = amax_of(x)
         ymax = _slot(x.device)          # (ACCUMULATE too: the epilogue sees, and records, the final values of every element of `out`)
-        _lib.check(lib.ucn_gemm_h3(x.data_ptr(), x.stride(0), packed.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), _lib.ptr(bias), M, N, K,
-                                   int(flags) | (MASK if mask is not None else 0), out.data_ptr(), out.stride(0), _lib.ptr(mask),
-                                   0 if mask is None else mask.stride(0), _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0),
-                                   int(rgroup), ymax.data_ptr(), _lib.stream()))
+        if x2 is not None:
+            assert x2.shape == (M, 4) and w2.shape[1] == 4 and w2.shape[0] >= N and x2.dtype == w2.dtype == torch.float32
+            assert x2.stride(1) == 1 and w2.stride(1) == 1
+        _lib.check(lib.ucn_gemm_h3_x2(x.data_ptr(), x.stride(0), packed.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), _lib.ptr(bias), M, N, K,
+                                      int(flags) | (MASK if mask is not None else 0), out.data_ptr(), out.stride(0), _lib.ptr(mask),
+                                      0 if mask is None else mask.stride(0), _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0),
+                                      int(rgroup), _lib.ptr(x2), 0 if x2 is None else x2.stride(0), _lib.ptr(w2),
+                                      0 if w2 is None else w2.stride(0), ymax.data_ptr(), _lib.stream()))
         return _tag(out, ymax)
     forget(out)
     if mask is None and rowbias is None:

@@ -909,9 +909,9 @@ class _SkyTrunkF32(torch.autograd.Function):
         hs.append(h)
         for i in range(1, 8):
             W = Ws[i].detach()
-            if i == 5:                                                      # [pts | h] -> two column blocks of the weight
-                y = G(h, W[:, 3:].contiguous(), bs[i].detach())
-                h = G(pts4, pad4(W[:, :3]).contiguous(), None, dense_f32.ACCUMULATE | dense_f32.RELU, out=y)
+            if i == 5:                                                      # [pts | h] -> two column blocks of the weight: the 3-d block
+                h = G(h, W[:, 3:].contiguous(), bs[i].detach(), dense_f32.RELU,       # rides in the wide product's epilogue (r06)
+                      x2=pts4, w2=pad4(W[:, :3]).contiguous())
             else:
                 h = G(h, W.contiguous(), bs[i].detach(), dense_f32.RELU)
             hs.append(h)
@@ -947,10 +947,9 @@ class _SkyTrunkF32(torch.autograd.Function):
         gMv, gbv = WG(dv, hs[7], True)
         g_per_ray = dv.reshape(n, ctx.group, -1).sum(dim=1)
         # into h7: view layer + density row, masked by h7 > 0 after the sum
-        d = G(dv, Mv.detach().t().contiguous())
         gWa4, gba4 = WG(gs4, hs[7], True)
         gWa, gba = gWa4[:1], gba4[:1]
-        d = G(gs4, padT(Wa), None, dense_f32.ACCUMULATE, out=d, mask=hs[7])
+        d = G(dv, Mv.detach().t().contiguous(), mask=hs[7], x2=gs4, w2=padT(Wa))    # (the density row's rank-1 term in the epilogue, r06)
         del dv
         gW, gb = [None] * 8, [None] * 8
         for i in range(7, 0, -1):
