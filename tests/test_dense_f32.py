@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["exact", "split"])
 def engine(request):
     from ucnerf_amd.internal import dense_f32 as D
-    prev = D.set_engine(request.param)
+    prev, prev_rows = D.set_engine(request.param), D.H3_MIN_ROWS
+    D.H3_MIN_ROWS = 4096                # (the product keeps operands below 32768 rows on the exact kernels: launch-bound; here the split kernels take them too)
     yield request.param
     D.set_engine(prev)
+    D.H3_MIN_ROWS = prev_rows
 
 
 def _eps(engine, base):
@@ -168,12 +170,14 @@ def test_split_engine_operand_range(lo, hi):
     want = gy.double() @ w.double()                                  # d X = d Y W
     want_w = gy.double().t() @ x.double()
     out = {}
+    prev_rows, D.H3_MIN_ROWS = D.H3_MIN_ROWS, 4096
     for eng in ("exact", "split"):
         prev = D.set_engine(eng)
         try:
             out[eng] = (D.gemm(gy, w.t().contiguous()).double(), D.wgrad(gy, x)[0].double())
         finally:
             D.set_engine(prev)
+    D.H3_MIN_ROWS = prev_rows
     assert torch.isfinite(out["split"][0]).all() and torch.isfinite(out["split"][1]).all(), "f16 operand overflow"
     assert float(out["split"][0].abs().max()) > 0
     row_scale = (gy.double().abs() @ w.double().abs()).amax(dim=1, keepdim=True)            # per-row absolute-value sums
@@ -197,6 +201,7 @@ def test_split_engine_amax_travels_and_goes_stale_safely():
     (version counter) and dropped by forget() after a raw-pointer write"""
     from ucnerf_amd.internal import dense_f32 as D
     prev = D.set_engine("split")
+    prev_rows, D.H3_MIN_ROWS = D.H3_MIN_ROWS, 4096
     try:
         g = torch.Generator(device="cuda").manual_seed(5)
         x = torch.randn(8192, 64, device="cuda", generator=g)
@@ -217,6 +222,7 @@ def test_split_engine_amax_travels_and_goes_stale_safely():
         assert not hasattr(y, "_ucn_amax")
     finally:
         D.set_engine(prev)
+        D.H3_MIN_ROWS = prev_rows
 
 
 @pytest.mark.parametrize("M,N,K,relu,masked", [(120 * 300, 256, 256, True, False), (8192, 256, 128, False, True), (5000, 128, 64, True, True), (1000, 256, 256, True, False)])

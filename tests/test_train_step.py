@@ -1286,3 +1286,53 @@ def test_render_between_training_steps_sees_the_stepped_weights():
         want = render(fresh, mixed)
         assert float((after - before).abs().max()) > 1e-4, "the step did not change the rendering: stale packed operands"
         assert torch.equal(after, want), float((after - want).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads", [False, True])
+def test_autocast_training_step_runs_no_library_gemm(heads):
+    """the bf16-autocast training step -- BASELINE configs[2], and with the sky NeRF + colour-correction head on --
+    holds no Tensile / rocBLAS / hipBLASLt kernel either: the fields and the sky run on the hand-written bf16 MFMA kernels, their weight
+    gradients on ucn_wgrad_bf16, and (r06) the small products left on the library -- the composed-weight products of prepare_heads, the
+    per-ray direction terms, feature_linear composed into the views layer, the colour head's four 210-row layers -- on csrc/gemm_f32.hip."""
+    import types
+    import bench
+    from ucnerf_amd.internal import train_utils as tu
+    dev = torch.device("cuda", 0)
+    model, _, _ = bench.build_model(dev, heads=heads)
+    model.train()
+    n = 1024
+    rays = {k: v.to(dev) for k, v in rm.synthetic_rays(n, seed=31).items()}
+    g = torch.Generator(device=dev).manual_seed(32)
+    batch = {k: v[:, None, None, :] for k, v in rays.items()}
+    batch['rgb'] = torch.rand(n, 1, 1, 3, device=dev, generator=g)
+    batch['lossmult'] = torch.ones(n, 1, 1, 1, device=dev)
+    if heads:
+        batch['cam_idx'] = torch.randint(0, 210, (n, 1, 1, 1), device=dev, generator=g)
+        batch['sky_segs'] = (torch.rand(n, 1, 1, device=dev, generator=g) > 0.7).float()
+    cfg = types.SimpleNamespace(data_loss_type='charb', charb_padding=0.001, data_loss_mult=1.0, data_coarse_loss_mult=0.,
+                                anti_interlevel_loss_mult=0.01, pulse_width=[0.03, 0.003], distortion_loss_mult=0.005,
+                                hash_decay_mults=0.1, disable_multiscale_loss=False)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            rend, hist = model(True, batch, 0.5, False, zero_glo=False)
+        loss = tu.compute_data_loss(batch, rend, cfg)[0] + tu.anti_interlevel_loss(hist, cfg) + tu.distortion_loss(hist, cfg) + tu.hash_decay_loss(hist, cfg)
+        if heads:
+            loss = loss + 0.002 * tu.sky_loss(batch, rend) + 0.002 * tu.transformIdentityLoss(rend)
+        loss.backward()
+        return loss
+    step()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
+        loss = step()
+        torch.cuda.synchronize()
+    names = {e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA}
+    lib = sorted(x for x in names if x.startswith("Cijk_") or "gemm" in x.lower().replace("k_gemm_f32", "").replace("k_gemm_h3", "").replace("gemmout", ""))
+    assert not lib, lib
+    assert any("k_train_fwd" in x for x in names) and any("k_wgrad_bf16" in x for x in names), sorted(names)[:40]
+    if heads:
+        assert any("k_sky_train_fwd" in x for x in names), sorted(names)[:40]
+    assert np.isfinite(float(loss.detach()))
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k

@@ -22,24 +22,14 @@ struct GemmOut {
     // r06: a second, 4-wide operand pair added in the epilogue -- Y += X2[M, 4] W2[N, 4]^T (exact fp32 FMAs) before the ReLU / mask.  The
     // sky NeRF has two layers whose input is [256-wide hidden | 3-d point] or whose gradient is [128-wide | 1 density row]
     // (models.py:790-795, :800-806): as a second accumulating GEMM the narrow block cost a full read-modify-write of the [M, 256] output.
-    // (vector form only: the host requires N % 4 == 0 and aligned rows with it -- the scalar tail path is at hipcc's full-unroll limit.)
+    // (staged vector form only: the host requires N = 256 with it -- the scalar tail path is at hipcc's full-unroll limit.)
     const float *x2 = nullptr, *w2 = nullptr;
     uint32_t ldx2 = 0, ldw2 = 0;
 };
 
-template <bool X2 = false>
 __device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
     if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
     if (o.rbias) { const float4 bv = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(row / o.rgroup) * o.ldr + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-    if constexpr (X2) {      // (a template flag, not a run-time test: the exact engine's resident kernels have no registers to spare for it)
-        const float4 xv = *reinterpret_cast<const float4 *>(o.x2 + (size_t)row * o.ldx2);
-        const float4 w0 = *reinterpret_cast<const float4 *>(o.w2 + (size_t)col * o.ldw2), w1 = *reinterpret_cast<const float4 *>(o.w2 + (size_t)(col + 1u) * o.ldw2);
-        const float4 w2 = *reinterpret_cast<const float4 *>(o.w2 + (size_t)(col + 2u) * o.ldw2), w3 = *reinterpret_cast<const float4 *>(o.w2 + (size_t)(col + 3u) * o.ldw2);
-        v.x += xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
-        v.y += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
-        v.z += xv.x * w2.x + xv.y * w2.y + xv.z * w2.z + xv.w * w2.w;
-        v.w += xv.x * w3.x + xv.y * w3.y + xv.z * w3.z + xv.w * w3.w;
-    }
     if (o.flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (o.flags & kGemmMask) {
         const float4 m = *reinterpret_cast<const float4 *>(o.mask + (size_t)row * o.ldm + col);
@@ -50,7 +40,7 @@ __device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32
 
 // Direct form: a lane stores the quads of its own row (any N, any alignment).  TRACK: returns the maximum of |every value this lane stored|
 // (gemm_h3.hip: the absolute maximum of Y, the power-of-two operand scale of the GEMM that consumes it); NaNs do not enter the maximum.
-template <uint32_t NT, bool TRACK = false, bool X2 = false>
+template <uint32_t NT, bool TRACK = false>
 __device__ __forceinline__ float gemm_store_direct(const f32x16 (&acc)[NT], const GemmOut &o, uint32_t orow, uint32_t n0, uint32_t kk) {
     float mx = 0.0f;
     if (orow >= o.M) return mx;
@@ -64,7 +54,7 @@ __device__ __forceinline__ float gemm_store_direct(const f32x16 (&acc)[NT], cons
             float4 v = make_float4(acc[t][4u * g], acc[t][4u * g + 1u], acc[t][4u * g + 2u], acc[t][4u * g + 3u]);
             float *yo = o.Y + (size_t)orow * o.ldy + col;
             if (vec) {
-                const float4 f = gemm_finish<X2>(v, o, orow, col);
+                const float4 f = gemm_finish(v, o, orow, col);
                 if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
                 *reinterpret_cast<float4 *>(yo) = f;
                 continue;
@@ -111,13 +101,29 @@ __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], cons
                     make_float4(a[4u * g], a[4u * g + 1u], a[4u * g + 2u], a[4u * g + 3u]);
             }
         wave_lds_handoff();
+        // (X2, a template flag and not a run-time test -- the exact engine's resident kernels have no registers to spare for it: the four
+        //  W2 rows of this lane's four columns are the same for every row of the block -- lane & 15 picks the columns -- and are fetched
+        //  once per block; per row one 16-byte X2 load and 16 FMAs.  First form: inside the per-row finish, 5 loads per row: the
+        //  K = 128 gradient GEMM that carries the density row went from 0.36 + 0.38 ms as two passes to 0.97 as one.)
+        float4 w2r[4];
+        if constexpr (X2) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) w2r[j] = *reinterpret_cast<const float4 *>(o.w2 + (size_t)(n0 + 64u * cb + 4u * (lane & 15u) + j) * o.ldw2);
+        }
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) {
             const uint32_t f = lane + 64u * u, r = f >> 4, c4 = f & 15u;
             const uint32_t ro = m0 + r, col = n0 + 64u * cb + 4u * c4;
             float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
             if (ro < o.M) {
-                const float4 f = gemm_finish<X2>(v, o, ro, col);
+                if constexpr (X2) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(o.x2 + (size_t)ro * o.ldx2);
+                    v.x += xv.x * w2r[0].x + xv.y * w2r[0].y + xv.z * w2r[0].z + xv.w * w2r[0].w;
+                    v.y += xv.x * w2r[1].x + xv.y * w2r[1].y + xv.z * w2r[1].z + xv.w * w2r[1].w;
+                    v.z += xv.x * w2r[2].x + xv.y * w2r[2].y + xv.z * w2r[2].z + xv.w * w2r[2].w;
+                    v.w += xv.x * w2r[3].x + xv.y * w2r[3].y + xv.z * w2r[3].z + xv.w * w2r[3].w;
+                }
+                const float4 f = gemm_finish(v, o, ro, col);
                 if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
                 *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = f;
             }

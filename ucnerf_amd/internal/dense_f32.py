@@ -15,7 +15,7 @@ r06: the default engine is "split" -- the same three functions on csrc/gemm_h3.h
 x_lo w_hi of f16 halves on v_mfma_f32_32x32x16_f16 (16 / 3 of the fp32 MFMA rate), fp32 accumulation, every operand at a power-of-two
 scale taken from its absolute maximum.  That maximum is a DEVICE float that travels with the tensor (`_ucn_amax`, set by the GEMM whose
 epilogue produced the tensor; computed by one ucn_amax_f32 pass for operands that come from elsewhere) -- no host round trip.  The
-exact fp32-product kernels stay behind `set_engine("exact")` / UCN_F32_EXACT=1; tall operands only (M >= 4096), short ones always run
+exact fp32-product kernels stay behind `set_engine("exact")` / UCN_F32_EXACT=1; tall operands only (M >= 32768), short ones always run
 exact.
 
 UCN_F32_LIBRARY=1 (experiment switch, read per call) routes the same functions through torch's library GEMMs: the A/B measurement of
@@ -29,7 +29,7 @@ from .. import _lib
 
 ACCUMULATE, RELU, MASK = 1, 2, 4
 
-H3_MIN_ROWS = 4096              # below this a GEMM is launch-bound either way: exact products
+H3_MIN_ROWS = 32768             # below this a GEMM is launch-bound either way (per-ray terms, the colour head): exact products, no pack
 _ENGINE = "exact" if os.environ.get("UCN_F32_EXACT", "0") == "1" else "split"
 
 

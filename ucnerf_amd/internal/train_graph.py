@@ -545,7 +545,8 @@ def prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, dir_in_stream=Fals
     if zero is None:
         zero = _FRAG_CACHE[("zero1", str(dev))] = torch.zeros(1, device=dev)
     W0x32, W1x32, Wd132, bd132 = W0.detach()[:, :NB].float(), W1.detach()[:, NW:NW + NB].float(), Wd1.detach().float(), bd1.detach().float()
-    Wc0, Wc1 = W0x32 @ Wd132, W1x32 @ Wd132
+    Wd1t = Wd132.t().contiguous()                                    # (csrc/gemm_f32.hip: no library GEMM in the autocast step, r06)
+    Wc0, Wc1 = dense_f32.gemm(W0x32.contiguous(), Wd1t), dense_f32.gemm(W1x32.contiguous(), Wd1t)
     b0c, b1c = torch.addmv(b0.detach().float(), W0x32, bd132), torch.addmv(b1.detach().float(), W1x32, bd132)
     src = torch.cat([t.detach().reshape(-1).float() for t in (Wd0, Wd1, W0, W1, Wr, bd0, bd1, b0c, b1c, br, Wc0, Wc1)] + [zero]).to(dt)
     assert src.numel() == n_src
@@ -577,8 +578,11 @@ class _FusedHeads(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             packed, packed_t, We, be, bias0, bias1, biasr = prepare_heads(Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br)
             eb = enc.to(dt)
-            pr0 = torch.addmm(be[:NW], eb, We[:NW].t()).float()          # what the bf16 GEMM + bias would hold, acc order
-            pr1 = torch.addmm(be[NW:], eb, We[NW:].t()).float()
+            # what the bf16 GEMM + bias would hold (operands rounded to bf16, fp32 accumulation, the sum rounded to bf16), acc order --
+            # on csrc/gemm_f32.hip instead of the library's bf16 kernel (r06)
+            eb4, We4 = dense_f32._rows(eb.float()), dense_f32._rows(We.float())
+            pr = dense_f32.gemm(eb4, We4, be.float().contiguous()).to(dt).float()
+            pr0, pr1 = pr[:, :NW].contiguous(), pr[:, NW:].contiguous()
             M = N * S
             f = feat.float().contiguous()
             act = torch.empty(M, ACT_LD, device=dev, dtype=dt)
@@ -1118,7 +1122,8 @@ def sky_forward_fused(net, origins, directions, cam_dirs, far):
         z = W5.new_zeros
         M5 = torch.cat([W5[:, 3:], W5[:, :3], b5[:, None], z(256, 28)], dim=1)
         Wvf = Wv[:, :256]
-        Mv = torch.cat([Wvf @ Wf, z(128, 3), (bv + Wvf @ bf)[:, None], Wv[:, 256:], z(128, 1)], dim=1)
+        lin = dense_f32.hip_linear                                    # (differentiable, csrc/gemm_f32.hip: no library GEMM, r06)
+        Mv = torch.cat([lin(Wvf.contiguous(), Wf.t()), z(128, 3), (bv + lin(bf[None, :], Wvf)[0])[:, None], Wv[:, 256:], z(128, 1)], dim=1)
         args = [origins, directions, cam_dirs, far, P[0].weight, P[0].bias]
         for l in (1, 2, 3, 4, 6, 7):
             args += [P[l].weight, P[l].bias]
@@ -1194,11 +1199,17 @@ def brightness_forward(bc, idx, which="latent_code"):
     codes = getattr(bc, which)
     idx = idx.reshape(-1).long()
     mlp = bc.brightness_MLP
-    if dense_f32.usable(codes, mlp.output_linear.weight) and not dense_f32.library_route():      # the fp32 step: csrc/gemm_f32.hip
+    if codes.is_cuda and codes.dtype == torch.float32 and mlp.output_linear.weight.dtype == torch.float32 and not dense_f32.library_route():
+        # csrc/gemm_f32.hip, with or without autocast (r06: under autocast the reference runs these four 210-row layers in bf16 on the
+        # library; fp32 products here are the higher precision, and the step holds no library GEMM)
+        out_dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+
         def run(x):
-            for lin in mlp.pts_linears:
-                x = dense_f32.hip_linear(x, lin.weight, lin.bias, relu=True)
-            return dense_f32.hip_linear(x, mlp.output_linear.weight, mlp.output_linear.bias).view(-1, 3, 4)
+            with torch.autocast("cuda", enabled=False):
+                for lin in mlp.pts_linears:
+                    x = dense_f32.hip_linear(x, lin.weight, lin.bias, relu=True)
+                y = dense_f32.hip_linear(x, mlp.output_linear.weight, mlp.output_linear.bias).view(-1, 3, 4)
+            return y if out_dt is None else y.to(out_dt)          # the dtype the reference's nn.Linear returns under autocast
     else:
         def run(x):
             for lin in mlp.pts_linears:
