@@ -220,6 +220,10 @@ __device__ unsigned long long g_h3_clk[8];        // experiment build: summed s_
 struct H3Scales {
     const float *xmax, *wmax;      // max |X|, max |W| (device): the operand scales
     uint32_t *ymax;                // atomic max of |Y| on the bit pattern (may be null)
+    uint32_t halves;               // 1: a workgroup owns all NT tiles of the packed stream.  2: the stream holds 2 NT tiles and workgroup
+    //                                b owns column half (b >> 3) & 1 of row tile (b >> 4) * 8 + (b & 7) -- the two halves of a row tile
+    //                                are 8 blocks apart: the same XCD (blocks go round robin over the 8 XCDs), dispatched back to back,
+    //                                so the second read of the activation rows is an L2 hit, not HBM traffic
 };
 
 // KS > 0: the k loop fully unrolled for K = 16 KS exactly (the layer widths of this model: 64, 128, 256).  Not a nicety: across a loop's
@@ -239,7 +243,10 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
     static_assert(kStageFloats == 32u * RS, "the activation tile is the epilogue's staging tile");
     extern __shared__ u4v s_ring[];                                // [2][SLOT] weight ring, then 8 wave tiles of kStageFloats floats
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & 31u, g = lane >> 5;
-    const uint32_t m0 = blockIdx.x * (32u * kH3Waves) + wave * 32u;
+    const uint32_t half = sc.halves == 2u ? (blockIdx.x >> 3) & 1u : 0u;
+    const uint32_t rtile = sc.halves == 2u ? (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u) : blockIdx.x;
+    const uint32_t m0 = rtile * (32u * kH3Waves) + wave * 32u, n0 = half * (NT * 32u);
+    if (rtile * (32u * kH3Waves) >= o.M) return;                   // (halves == 2: the grid is rounded up to whole groups of 16 blocks)
 #ifdef UCN_H3_CLOCK
     unsigned long long clk_last_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
     const int ex = h3_exponent(*sc.xmax), ew = h3_exponent(*sc.wmax);
     const float neg1 = h3_neg1();
     f32x16 acc[NT];
-    gemm_init_acc<NT>(acc, o, m0 + i, 0u, g);
+    gemm_init_acc<NT>(acc, o, m0 + i, n0, g);
     if (o.flags & kGemmAccum) {
 #pragma unroll
         for (uint32_t t = 0; t < NT; t++)
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
         for (uint32_t u = 0; u < 8; u++) *reinterpret_cast<f4v *>(tile + (4u * u + prow) * RS + pcol) = xs[u];
     };
     auto load_w = [&](uint32_t s, u4v (&d)[WPT]) {
-        const u4v *src = Wp + (size_t)(s < ksteps ? s : 0u) * CH;
+        const u4v *src = Wp + ((size_t)(s < ksteps ? s : 0u) * sc.halves + half) * CH;
 #pragma unroll
         for (uint32_t u = 0; u < WPT; u++) {
             const uint32_t idx = threadIdx.x + u * kH3Threads;
@@ -375,17 +382,17 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
     if (acc[0][0] != 123.456f) return;
 #endif
     if constexpr (NT >= 2u) {
-        if ((oe.flags & kGemmVec) && NT * 32u <= oe.N) {
-            if constexpr (NT == 8u) {                                   // the second operand pair: 256-wide outputs only (the host checks)
-                if (oe.x2) mx = gemm_store_staged<NT, true, true>(acc, oe, tile, m0, 0u, lane);
-                else mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, 0u, lane);
+        if ((oe.flags & kGemmVec) && n0 + NT * 32u <= oe.N) {
+            if constexpr (NT >= 4u) {                                   // the second operand pair: 256-wide outputs only (the host checks)
+                if (oe.x2) mx = gemm_store_staged<NT, true, true>(acc, oe, tile, m0, n0, lane);
+                else mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, n0, lane);
             } else {
-                mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, 0u, lane);
+                mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, n0, lane);
             }
             done = true;
         }
     }
-    if (!done) mx = gemm_store_direct<NT, true>(acc, oe, m0 + i, 0u, g);
+    if (!done) mx = gemm_store_direct<NT, true>(acc, oe, m0 + i, n0, g);
     H3_STAMP(2);
     if (sc.ymax) {                                                  // uniform
         __syncthreads();                                            // every wave is done with its tile: the weight ring is scratch now
@@ -620,8 +627,14 @@ extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, 
     GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
     o.x2 = X2; o.w2 = W2; o.ldx2 = ldx2; o.ldw2 = ldw2;
     const uint32_t ks = h3_ksteps(K);
-    H3Scales sc{xmax, wmax, reinterpret_cast<uint32_t *>(ymax)};
-    const dim3 grid(ucn_div_up(M, 32u * kH3Waves));
+    // UCN_H3_HALVES=2 (experiment, measured SLOWER: 0.755 against 0.656 ms at N = K = 256, profiles/r06/gemm_h3_notes.txt): 256-wide outputs as
+    // two workgroups of 4 tiles per row tile instead of one of 8 -- the 4-tile kernel moves 4.3 TB/s on its own 128-wide shape, but here the
+    // activation rows are fetched twice and the second fetch is not the L2 hit the block pairing was meant to make it
+    static const bool two_wg = getenv("UCN_H3_HALVES") != nullptr && atoi(getenv("UCN_H3_HALVES")) == 2;
+    const uint32_t halves = (h3_tiles(N) == 8u && two_wg) ? 2u : 1u;
+    H3Scales sc{xmax, wmax, reinterpret_cast<uint32_t *>(ymax), halves};
+    const uint32_t rtiles = ucn_div_up(M, 32u * kH3Waves);
+    const dim3 grid(halves == 2u ? ucn_div_up(rtiles, 8) * 16u : rtiles);
     hipStream_t st = (hipStream_t)stream;
     static const bool no_unroll = getenv("UCN_H3_NO_UNROLL") != nullptr;              // A/B switch: every shape through the loop form
     const uint32_t ku = (K % 16u == 0u && !no_unroll) ? K / 16u : 0u;                 // unrolled forms: K = 64 (wide outputs only), 128, 256
@@ -633,7 +646,7 @@ extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, 
         else if (ku == 4u) UCN_H3K(NT, 4);                 \
         else UCN_H3K(NT, 0);                               \
     } while (0)
-    switch (h3_tiles(N)) {
+    switch (h3_tiles(N) / halves) {
         case 1: UCN_H3(1); break;
         case 2: UCN_H3(2); break;
         case 4: UCN_H3(4); break;
