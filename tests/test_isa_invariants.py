@@ -41,3 +41,17 @@ def test_wgrad_reserved_staging_registers_are_only_named_by_the_asm_statements()
         assert named >= 8, (m.group(2), named)          # the loads and the ds_writes are there
         # the kernel descriptor reserves the whole 256 (the asm statements' clobbers count)
     assert len(re.findall(r"\.amdhsa_next_free_vgpr 256", text)) >= 9
+
+
+def test_no_inline_asm_valu_write_lands_on_a_live_mfma_operand():
+    """r06: hipcc pads no hazards around an `asm` statement, and its register allocator may hand an asm VALU instruction the registers
+    that the MFMA issued just before still reads as its A / B operand.  It happened (k_gemm_h3<4, 16>: the inline-asm operand split wrote
+    into the A operand of the preceding MFMA; one output tile lost its lo x hi term on 5 % of the rows).  The split-f16 kernels now use
+    compiler-visible instructions; this scan (tools/isa_asm_hazard.py) keeps it that way for the three files that split operands:
+    no inline-asm VALU write overlaps the A / B sources of an MFMA within the 12 instructions before it."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "isa_asm_hazard.py"), "gemm_h3", "field_mlp_h", "sky"],
+                       capture_output=True, text=True, timeout=1500, cwd=repo)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.strip().endswith("TOTAL 0"), p.stdout[-3000:]
