@@ -507,8 +507,13 @@ int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, const float *x
  *   [view branch | density row] gradient into its last trunk layer (models.py:800-806) as ONE pass over the [M, 256] output. */
 int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias, uint32_t M,
                    uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm, const float *rowbias,
-                   uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2, float *ymax,
-                   ucn_stream_t stream);
+                   uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2,
+                   uint64_t *relu_bits_out, const uint64_t *mask_bits, float *ymax, ucn_stream_t stream);
+/* ReLU derivatives as bit masks (128- / 256-wide outputs): relu_bits_out != NULL: the call leaves "Y > 0" of every output as one bit
+ * (ucn_relu_bits_words(M, N) 64-bit words, in the epilogue's own store order); mask_bits != NULL: Y = bit ? Y : 0 as the last step, from
+ * the bits a forward call of the same [M, N] shape left -- the d X GEMM of a Linear + ReLU layer without reading the layer's stored
+ * fp32 output (UCN_GEMM_MASK's 4 bytes per element become 1 bit). */
+uint64_t ucn_relu_bits_words(uint64_t M, uint32_t N);
 uint64_t ucn_wgrad_h3_ws_floats(uint32_t N, uint32_t K, uint64_t M);
 int ucn_wgrad_h3(const float *GY, uint32_t ldg, const float *X, uint32_t ldx, const float *gmax, const float *xmax, uint32_t M, uint32_t N,
                  uint32_t K, float *ws, float *GW, float *gb, ucn_stream_t stream);

@@ -248,3 +248,71 @@ def test_gemm_second_narrow_operand_in_the_epilogue(M, N, K, relu, masked, engin
     assert float((got.double() - want).abs().max()) <= _eps(engine, 4e-7) * scale * max(1.0, K ** 0.5 / 4)
     if engine == "split" and M >= D.H3_MIN_ROWS and hasattr(got, "_ucn_amax"):
         assert float(got._ucn_amax[0]) == float(got.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,x2", [(120 * 300, 256, 256, False), (8192 + 17, 256, 128, True), (5000, 128, 64, False), (70001, 128, 4, False),
+                                      (32 * 1000 + 31, 256, 64, False)])
+def test_relu_derivative_as_bit_mask_is_the_float_mask(M, N, K, x2):
+    """r06: a ReLU product on the split engine leaves "out > 0" as one bit per element; a masked product whose mask is that output reads
+    the bits (ucn_gemm_h3_x2 relu_bits_out / mask_bits) -- EXACTLY the result of reading the fp32 mask, on ragged row counts, with the
+    second operand pair in the epilogue, and after the mask went through save_for_backward; a mask rewritten since falls back."""
+    from ucnerf_amd.internal import dense_f32 as D
+    prev, prev_rows = D.set_engine("split"), D.H3_MIN_ROWS
+    D.H3_MIN_ROWS = 4096
+    try:
+        g = torch.Generator(device="cuda").manual_seed(M + N + K)
+        x = torch.randn(M, K, device="cuda", generator=g)
+        w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        b = torch.randn(N, device="cuda", generator=g)
+        h = D.gemm(x, w, b, D.RELU)
+        bits = h._ucn_relu_bits[0]
+        assert bits.numel() == (M + 31) // 32 * (N // 64) * 32
+        # every bit: word (((row tile) * (N/64) + column block) * 8 + u) * 4 + j, bit lane <-> row 32 tile + 4 u + lane // 16, column
+        # 64 block + 4 (lane % 16) + j
+        words = bits.view(-1, N // 64, 8, 4).cpu().numpy().astype(np.uint64)
+        lane = np.arange(64, dtype=np.uint64)
+        got = ((words[..., None] >> lane) & np.uint64(1)).astype(bool)                     # [tile, cb, u, j, lane]
+        hp = torch.zeros((M + 31) // 32 * 32, N, device="cuda")
+        hp[:M] = h
+        want = (hp > 0).cpu().numpy().reshape(-1, 8, 4, N // 64, 16, 4)                     # [tile, u, lane // 16, cb, lane % 16, j]
+        want = want.transpose(0, 3, 1, 5, 2, 4).reshape(got.shape)
+        assert np.array_equal(got, want)
+        gy = torch.randn(M, 64, device="cuda", generator=g)
+        wt = torch.randn(N, 64, device="cuda", generator=g)
+        kw = {}
+        if x2:
+            kw = dict(x2=torch.randn(M, 4, device="cuda", generator=g), w2=torch.randn(N, 4, device="cuda", generator=g))
+        with_bits = D.gemm(gy, wt, mask=h, **kw)
+        saved = h.detach().clone()                      # no recorded bits: the fp32 mask
+        assert not hasattr(saved, "_ucn_relu_bits")
+        with_floats = D.gemm(gy, wt, mask=saved, **kw)
+        assert torch.equal(with_bits, with_floats)
+        assert float(with_bits._ucn_amax[0]) == float(with_floats._ucn_amax[0])
+        # through autograd's saved tensors
+
+        class Node(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a):
+                ctx.save_for_backward(h)
+                D.stash_amax(ctx, (h,))
+                return a * 1.0
+
+            @staticmethod
+            def backward(ctx, ga):
+                (hh,) = ctx.saved_tensors
+                D.restore_amax(ctx, (hh,))
+                assert D._bits_of(hh, M, N) is not None
+                Node.out = D.gemm(gy, wt, mask=hh, **kw)
+                return ga
+
+        a = torch.ones(1, device="cuda", requires_grad=True)
+        Node.apply(a).sum().backward()
+        assert torch.equal(Node.out, with_floats)
+        # a mask rewritten in place (version bump) no longer matches its bits: the float path, with the NEW values
+        h.mul_(-1.0).add_(0.01)
+        assert D._bits_of(h, M, N) is None
+        again = D.gemm(gy, wt, mask=h, **kw)
+        assert torch.equal(again, D.gemm(gy, wt, mask=h.clone(), **kw)) and not torch.equal(again, with_floats)
+    finally:
+        D.set_engine(prev)
+        D.H3_MIN_ROWS = prev_rows

@@ -1192,6 +1192,47 @@ def test_fp32_sky_chain_node_matches_the_layer_by_layer_route_and_torch(monkeypa
 
 
 @pytest.mark.gpu
+def test_fp32_sky_chain_backward_reads_relu_bits_and_changes_nothing(monkeypatch):
+    """r06: on the split engine every ReLU layer of _SkyTrunkF32 leaves its derivative as one bit per element and the d X GEMM above
+    reads the bits instead of the stored fp32 activations (ucn_gemm_h3_x2 relu_bits_out / mask_bits): all nine masked products of the
+    backward take the bit form, and outputs and parameter gradients are IDENTICAL to the float-mask run."""
+    from ucnerf_amd.internal import sky, train_graph as tg, dense_f32 as D
+    prev = D.set_engine("split")
+    try:
+        torch.manual_seed(11)
+        net = sky.NeRF(D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True).cuda()
+        net.alpha_linear.bias.data.fill_(0.05)
+        n = 700                                                     # x 120 samples = 84 000 rows: above dense_f32.H3_MIN_ROWS
+        g = torch.Generator(device="cuda").manual_seed(12)
+        o = torch.randn(n, 3, device="cuda", generator=g) * 0.1
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda", generator=g), dim=-1)
+        cam = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda", generator=g), dim=-1)
+        far = torch.full((n, 1), 8.0, device="cuda")
+        up = torch.randn(n, 3, device="cuda", generator=g)
+        monkeypatch.setenv("UCN_SKY_F32_CHAIN", "1")
+        monkeypatch.setenv("UCN_F32_LIBRARY", "0")
+        hits = []
+        real = D._bits_of
+        monkeypatch.setattr(D, "_bits_of", lambda m, M, N: hits.append(real(m, M, N) is not None) or real(m, M, N))
+
+        def run(bits):
+            monkeypatch.setattr(D, "RELU_BITS", bits)
+            net.zero_grad(set_to_none=True)
+            del hits[:]
+            out = tg.sky_forward(net, o, d, cam, far)
+            (out * up).sum().backward()
+            return out.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}, list(hits)
+        out_b, g_b, hits_b = run(True)
+        out_f, g_f, hits_f = run(False)
+        assert hits_b == [True] * 9 and hits_f == [], (hits_b, hits_f)       # masks hv, h7 .. h0
+        assert torch.equal(out_b, out_f)
+        for k in g_f:
+            assert torch.equal(g_b[k], g_f[k]), k
+    finally:
+        D.set_engine(prev)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("engine", ["split", "exact"])
 def test_fp32_training_step_runs_no_library_gemm(engine):
     """VERDICT r03 missing #2: the NON-autocast training step (the reference's shipped precision, scripts/train_waymo.sh:3) -- fields, sky

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UCN_LIB_PATH: an experiment build of the same ABI (tools/build_variant.sh) for A/B measurements; default = the in-tree product
 LIB_PATH = os.environ.get("UCN_LIB_PATH") or os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 RAYS_INCOHERENT = 0x1000   # ucn_march_features layout flag: random (training) rays -> lane-paired fetch on every hashed level
@@ -129,7 +129,8 @@ SIGNATURES = {
     "ucn_pack_h3": [c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp],
     "ucn_gemm_h3": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_vp, c_vp],
     "ucn_gemm_h3_x2": [c_vp, c_u32, c_vp, c_vp, c_vp, c_vp, c_u32, c_u32, c_u32, c_i32, c_vp, c_u32, c_vp, c_u32, c_vp, c_u32, c_u32, c_vp, c_u32,
-                       c_vp, c_u32, c_vp, c_vp],
+                       c_vp, c_u32, c_vp, c_vp, c_vp, c_vp],
+    "ucn_relu_bits_words": [c_u64, c_u32],
     "ucn_wgrad_h3_ws_floats": [c_u32, c_u32, c_u64],
     "ucn_wgrad_h3": [c_vp, c_u32, c_vp, c_u32, c_vp, c_vp, c_u32, c_u32, c_u32, c_vp, c_vp, c_vp, c_vp],
     "ucn_marching_cubes_ws_bytes": [c_u32, c_u32, c_u32],
@@ -147,7 +148,7 @@ SIGNATURES = {
 _RESTYPES = {"ucn_last_error": ctypes.c_char_p, "ucn_abi_version": c_u32, "ucn_field_packed_floats": c_u64,
              "ucn_field_dir_floats": c_u64, "ucn_march_features_backward_ws_floats": c_u64,
              "ucn_sky_packed_floats": c_u64, "ucn_sky_workspace_floats": c_u64, "ucn_train_fwd_fragments": c_u64,
-             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_wgrad_f32_ws_floats": c_u64, "ucn_wgrad_h3_ws_floats": c_u64, "ucn_pack_h3_bytes": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_image_metrics_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
+             "ucn_prop_train_bwd_ws_floats": c_u64, "ucn_sky_train_packed_bytes": c_u64, "ucn_wgrad_ws_floats": c_u64, "ucn_wgrad_f32_ws_floats": c_u64, "ucn_wgrad_h3_ws_floats": c_u64, "ucn_pack_h3_bytes": c_u64, "ucn_relu_bits_words": c_u64, "ucn_marching_cubes_ws_bytes": c_u64, "ucn_image_metrics_ws_bytes": c_u64, "ucn_sky_train_act_ld": c_u32,
              "ucn_sky_train_grad_ld": c_u32}
 
 _lib = None

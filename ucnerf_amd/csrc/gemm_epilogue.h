@@ -25,7 +25,16 @@ struct GemmOut {
     // (staged vector form only: the host requires N = 256 with it -- the scalar tail path is at hipcc's full-unroll limit.)
     const float *x2 = nullptr, *w2 = nullptr;
     uint32_t ldx2 = 0, ldw2 = 0;
+    // r06: ReLU derivatives as BIT masks (staged form of the split engine only).  bits_out: the producing GEMM (forward, ReLU) leaves
+    // "y > 0" of every output as one bit; bits_in: the d X GEMM of the layer above reads those bits instead of the stored fp32 output
+    // (1 GB per [2^20, 256] layer).  Layout = the staged store's own: 64-bit word (((row tile of 32) * (N / 64) + column block) * 8 + u) * 4 + j
+    // holds, at bit `lane`, the output this lane stores in step u, component j -- writer and reader walk the same loop, no bit is moved.
+    unsigned long long *bits_out = nullptr;
+    const unsigned long long *bits_in = nullptr;
 };
+
+// 64-bit words of a bit mask over an [M, N] output (N a multiple of 64)
+__host__ __device__ inline unsigned long long gemm_bits_words(unsigned long long M, unsigned N) { return (M + 31u) / 32u * (N / 64u) * 32u; }
 
 __device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
     if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
@@ -83,10 +92,11 @@ __device__ __forceinline__ float gemm_store_direct(const f32x16 (&acc)[NT], cons
 // tile cost 32 / SR x 4 NT quarter- or half-empty ds_write_b128: 128 per 32 x 256 tile at SR = 8, 40 % of the CU's LDS time.)
 // The tile is 32 x (64 + 4) floats = 8.5 KiB per wave.
 constexpr uint32_t kStageFloats = 32u * 68u;
-template <uint32_t NT, bool TRACK = false, bool X2 = false>
+template <uint32_t NT, bool TRACK = false, bool X2 = false, int BITS = 0>       // BITS: 1 = write o.bits_out, 2 = mask by o.bits_in
 __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], const GemmOut &o, float *tile, uint32_t m0, uint32_t n0,
                                                    uint32_t lane) {
     float mx = 0.0f;
+    const unsigned long long bits_row = BITS ? (unsigned long long)__builtin_amdgcn_readfirstlane(m0 >> 5) * (o.N >> 6) : 0ull;
     static_assert(NT % 2u == 0u, "column blocks of two tiles");
     constexpr uint32_t RS = 68u;                                   // row stride in floats (64 + 4: the rows of a write fall on different bank groups)
     const uint32_t i = lane & 31u, kk = lane >> 5;
@@ -115,6 +125,15 @@ __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], cons
             const uint32_t f = lane + 64u * u, r = f >> 4, c4 = f & 15u;
             const uint32_t ro = m0 + r, col = n0 + 64u * cb + 4u * c4;
             float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
+            const unsigned long long wbase = BITS ? ((bits_row + (n0 >> 6) + cb) * 8u + u) * 4u : 0ull;       // wave-uniform
+            unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
+            if constexpr (BITS == 2) {
+                if (m0 < o.M) {                                     // (a wave wholly past the last row owns no words)
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) mw[j] = o.bits_in[wbase + j];
+                }
+            }
+            bool pos[4] = {false, false, false, false};
             if (ro < o.M) {
                 if constexpr (X2) {
                     const float4 xv = *reinterpret_cast<const float4 *>(o.x2 + (size_t)ro * o.ldx2);
@@ -123,9 +142,20 @@ __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], cons
                     v.z += xv.x * w2r[2].x + xv.y * w2r[2].y + xv.z * w2r[2].z + xv.w * w2r[2].w;
                     v.w += xv.x * w2r[3].x + xv.y * w2r[3].y + xv.z * w2r[3].z + xv.w * w2r[3].w;
                 }
-                const float4 f = gemm_finish(v, o, ro, col);
+                float4 f = gemm_finish(v, o, ro, col);
+                if constexpr (BITS == 2) {
+                    f.x = ((mw[0] >> lane) & 1ull) ? f.x : 0.f; f.y = ((mw[1] >> lane) & 1ull) ? f.y : 0.f;
+                    f.z = ((mw[2] >> lane) & 1ull) ? f.z : 0.f; f.w = ((mw[3] >> lane) & 1ull) ? f.w : 0.f;
+                }
+                if constexpr (BITS == 1) { pos[0] = f.x > 0.f; pos[1] = f.y > 0.f; pos[2] = f.z > 0.f; pos[3] = f.w > 0.f; }
                 if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
                 *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = f;
+            }
+            if constexpr (BITS == 1) {                              // (outside the row guard: a ballot is taken by the whole wave)
+                unsigned long long b[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) b[j] = __ballot(pos[j]);
+                if (lane < 4u && m0 < o.M) o.bits_out[wbase + lane] = lane == 0u ? b[0] : lane == 1u ? b[1] : lane == 2u ? b[2] : b[3];
             }
         }
         wave_lds_handoff();

@@ -383,9 +383,18 @@ __global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restri
 #endif
     if constexpr (NT >= 2u) {
         if ((oe.flags & kGemmVec) && n0 + NT * 32u <= oe.N) {
-            if constexpr (NT >= 4u) {                                   // the second operand pair: 256-wide outputs only (the host checks)
-                if (oe.x2) mx = gemm_store_staged<NT, true, true>(acc, oe, tile, m0, n0, lane);
-                else mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, n0, lane);
+            // the epilogue's optional pieces are template flags of the store (run-time tests inside it cost the exact engine's resident
+            // kernels their registers): second operand pair (256-wide outputs: the host checks), ReLU bits written / read (NT >= 4)
+            if constexpr (NT >= 4u) {
+                if (oe.x2) {
+                    if (oe.bits_in) mx = gemm_store_staged<NT, true, true, 2>(acc, oe, tile, m0, n0, lane);
+                    else if (oe.bits_out) mx = gemm_store_staged<NT, true, true, 1>(acc, oe, tile, m0, n0, lane);
+                    else mx = gemm_store_staged<NT, true, true>(acc, oe, tile, m0, n0, lane);
+                } else {
+                    if (oe.bits_in) mx = gemm_store_staged<NT, true, false, 2>(acc, oe, tile, m0, n0, lane);
+                    else if (oe.bits_out) mx = gemm_store_staged<NT, true, false, 1>(acc, oe, tile, m0, n0, lane);
+                    else mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, n0, lane);
+                }
             } else {
                 mx = gemm_store_staged<NT, true>(acc, oe, tile, m0, n0, lane);
             }
@@ -583,6 +592,8 @@ extern "C" int ucn_h3_clock_read(unsigned long long *out8, int reset) {
 }
 #endif
 
+extern "C" uint64_t ucn_relu_bits_words(uint64_t M, uint32_t N) { return gemm_bits_words(M, N); }
+
 extern "C" uint64_t ucn_pack_h3_bytes(uint32_t N, uint32_t K) { return (uint64_t)h3_ksteps(K) * h3_tiles(N) * 2048u; }
 
 extern "C" int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K, int transposed, void *packed, float *wmax_out,
@@ -601,13 +612,14 @@ extern "C" int ucn_pack_h3(const float *W, uint32_t ldw, uint32_t N, uint32_t K,
 extern "C" int ucn_gemm_h3(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias,
                            uint32_t M, uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm,
                            const float *rowbias, uint32_t ldr, uint32_t rgroup, float *ymax, ucn_stream_t stream) {
-    return ucn_gemm_h3_x2(X, ldx, packed, xmax, wmax, bias, M, N, K, flags, Y, ldy, mask, ldm, rowbias, ldr, rgroup, nullptr, 0, nullptr, 0, ymax, stream);
+    return ucn_gemm_h3_x2(X, ldx, packed, xmax, wmax, bias, M, N, K, flags, Y, ldy, mask, ldm, rowbias, ldr, rgroup, nullptr, 0, nullptr, 0, nullptr,
+                          nullptr, ymax, stream);
 }
 
 extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, const float *xmax, const float *wmax, const float *bias,
                               uint32_t M, uint32_t N, uint32_t K, int flags, float *Y, uint32_t ldy, const float *mask, uint32_t ldm,
                               const float *rowbias, uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2,
-                              float *ymax, ucn_stream_t stream) {
+                              uint64_t *relu_bits_out, const uint64_t *mask_bits, float *ymax, ucn_stream_t stream) {
     UCN_REQUIRE(!X2 == !W2, "gemm_h3: the 4-wide second operand pair needs both X2 [M, 4] and W2 [N, 4]");
     UCN_REQUIRE(!X2 || (ldx2 >= 4 && ldw2 >= 4 && ldx2 % 4u == 0u && ldw2 % 4u == 0u && (((uintptr_t)X2 | (uintptr_t)W2) & 15u) == 0u),
                 "gemm_h3: X2 / W2 rows are 4 floats, 16-byte aligned (ldx2 %u ldw2 %u)", ldx2, ldw2);
@@ -626,6 +638,11 @@ extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, 
     UCN_REQUIRE(!X2 || (vec && N == 256u), "gemm_h3: the second operand pair is built for 256-wide outputs with the vector epilogue (N %u)", N);
     GemmOut o{bias, (flags & (int)kGemmMask) ? mask : nullptr, rowbias, Y, ldy, ldm, ldr, rgroup ? rgroup : 1u, M, N, (uint32_t)flags | (vec ? kGemmVec : 0u)};
     o.x2 = X2; o.w2 = W2; o.ldx2 = ldx2; o.ldw2 = ldw2;
+    UCN_REQUIRE(!(relu_bits_out || mask_bits) || (vec && N % 64u == 0u && N >= 128u && h3_tiles(N) * 32u == N),
+                "gemm_h3: ReLU bit masks need the staged epilogue of a 128- or 256-wide output (N %u)", N);
+    UCN_REQUIRE(!(mask_bits && (flags & (int)kGemmMask)), "gemm_h3: a float mask and a bit mask together");
+    o.bits_out = reinterpret_cast<unsigned long long *>(relu_bits_out);
+    o.bits_in = reinterpret_cast<const unsigned long long *>(mask_bits);
     const uint32_t ks = h3_ksteps(K);
     // UCN_H3_HALVES=2 (experiment, measured SLOWER: 0.755 against 0.656 ms at N = K = 256, profiles/r06/gemm_h3_notes.txt): 256-wide outputs as
     // two workgroups of 4 tiles per row tile instead of one of 8 -- the 4-tile kernel moves 4.3 TB/s on its own 128-wide shape, but here the

@@ -73,6 +73,8 @@ def forget(t):
     """call after writing into a tensor through its raw pointer (kernels do not bump `_version`): its recorded maximum is stale"""
     if hasattr(t, "_ucn_amax"):
         del t._ucn_amax
+    if hasattr(t, "_ucn_relu_bits"):
+        del t._ucn_relu_bits
 
 
 def amax_of(t):
@@ -92,12 +94,35 @@ def amax_of(t):
 def stash_amax(ctx, tensors):
     """autograd: remember the recorded maxima of tensors about to be saved for backward (saved_tensors may hand back new objects)"""
     ctx._ucn_amax = [getattr(t, "_ucn_amax", None) if t is not None else None for t in tensors]
+    ctx._ucn_bits = [getattr(t, "_ucn_relu_bits", None) if t is not None else None for t in tensors]      # (and their ReLU bit masks)
 
 
 def restore_amax(ctx, tensors):
     for t, a in zip(tensors, getattr(ctx, "_ucn_amax", ())):
         if t is not None and a is not None and a[1] == t._version:
             t._ucn_amax = a
+    for t, b in zip(tensors, getattr(ctx, "_ucn_bits", ())):
+        if t is not None and b is not None and b[1] == t._version and b[2] == t.data_ptr():
+            t._ucn_relu_bits = b
+
+
+RELU_BITS = os.environ.get("UCN_RELU_BITS", "1") != "0"     # A/B switch: 0 = the d X GEMMs read the stored fp32 outputs as their masks
+
+
+def _bits_shape_ok(out, N, bias, rowbias, mask=None):
+    """the split engine's staged epilogue (the one that writes / reads ReLU bit masks): 128- or 256-wide outputs, 16-byte rows"""
+    return (RELU_BITS and N in (128, 256) and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0)
+            and (rowbias is None or (rowbias.stride(0) % 4 == 0 and rowbias.data_ptr() % 16 == 0))
+            and (mask is None or (mask.stride(0) % 4 == 0 and mask.data_ptr() % 16 == 0)))
+
+
+def _bits_of(mask, M, N):
+    """the bit form of a ReLU mask: recorded by the split engine when it produced `mask` as a ReLU output of this very shape"""
+    hit = getattr(mask, "_ucn_relu_bits", None)
+    if hit is not None and hit[1] == mask._version and hit[2] == mask.data_ptr() and hit[3] == (M, N) and tuple(mask.shape) == (M, N):
+        return hit[0]
+    return None
 
 
 def _rows(t):
@@ -156,11 +181,24 @@ def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None
         if x2 is not None:
             assert x2.shape == (M, 4) and w2.shape[1] == 4 and w2.shape[0] >= N and x2.dtype == w2.dtype == torch.float32
             assert x2.stride(1) == 1 and w2.stride(1) == 1
+        # ReLU derivatives as bits (r06): a ReLU product leaves "out > 0" as one bit per element next to its fp32 output; a masked
+        # product whose mask carries such bits reads them instead of the fp32 tensor (4 bytes -> 1 bit per element of the d X epilogue)
+        mbits = None
+        if mask is not None and _bits_shape_ok(out, N, bias, rowbias):
+            mbits = _bits_of(mask, M, N)
+        if mbits is not None:
+            mask = None
+        forget(out)
+        obits = None
+        if (int(flags) & RELU) and _bits_shape_ok(out, N, bias, rowbias, mask):
+            obits = torch.empty(lib.ucn_relu_bits_words(M, N), device=x.device, dtype=torch.int64)
         _lib.check(lib.ucn_gemm_h3_x2(x.data_ptr(), x.stride(0), packed.data_ptr(), xmax.data_ptr(), wmax.data_ptr(), _lib.ptr(bias), M, N, K,
                                       int(flags) | (MASK if mask is not None else 0), out.data_ptr(), out.stride(0), _lib.ptr(mask),
                                       0 if mask is None else mask.stride(0), _lib.ptr(rowbias), 0 if rowbias is None else rowbias.stride(0),
                                       int(rgroup), _lib.ptr(x2), 0 if x2 is None else x2.stride(0), _lib.ptr(w2),
-                                      0 if w2 is None else w2.stride(0), ymax.data_ptr(), _lib.stream()))
+                                      0 if w2 is None else w2.stride(0), _lib.ptr(obits), _lib.ptr(mbits), ymax.data_ptr(), _lib.stream()))
+        if obits is not None:
+            out._ucn_relu_bits = (obits, out._version, out.data_ptr(), (M, N))
         return _tag(out, ymax)
     forget(out)
     if mask is None and rowbias is None:
