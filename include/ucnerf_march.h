@@ -510,7 +510,7 @@ int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, const float
                    uint32_t ldr, uint32_t rgroup, const float *X2, uint32_t ldx2, const float *W2, uint32_t ldw2,
                    uint64_t *relu_bits_out, const uint64_t *mask_bits, float *ymax, ucn_stream_t stream);
 /* ReLU derivatives as bit masks (128- / 256-wide outputs): relu_bits_out != NULL: the call leaves "Y > 0" of every output as one bit
- * (ucn_relu_bits_words(M, N) 64-bit words, in the epilogue's own store order); mask_bits != NULL: Y = bit ? Y : 0 as the last step, from
+ * (ucn_relu_bits_words(M, N) 64-bit words; 32-bit word ((row / 32) * (N / 64) + column / 64) * 64 + lane, bit 4 u + j = row 32 (row / 32) + 4 u + lane / 16, column 64 (column / 64) + 4 (lane % 16) + j: the epilogue's own store order); mask_bits != NULL: Y = bit ? Y : 0 as the last step, from
  * the bits a forward call of the same [M, N] shape left -- the d X GEMM of a Linear + ReLU layer without reading the layer's stored
  * fp32 output (UCN_GEMM_MASK's 4 bytes per element become 1 bit). */
 uint64_t ucn_relu_bits_words(uint64_t M, uint32_t N);

@@ -267,15 +267,15 @@ def test_relu_derivative_as_bit_mask_is_the_float_mask(M, N, K, x2):
         h = D.gemm(x, w, b, D.RELU)
         bits = h._ucn_relu_bits[0]
         assert bits.numel() == (M + 31) // 32 * (N // 64) * 32
-        # every bit: word (((row tile) * (N/64) + column block) * 8 + u) * 4 + j, bit lane <-> row 32 tile + 4 u + lane // 16, column
+        # every bit: 32-bit word ((row tile) * (N/64) + column block) * 64 + lane, bit 4 u + j <-> row 32 tile + 4 u + lane // 16, column
         # 64 block + 4 (lane % 16) + j
-        words = bits.view(-1, N // 64, 8, 4).cpu().numpy().astype(np.uint64)
-        lane = np.arange(64, dtype=np.uint64)
-        got = ((words[..., None] >> lane) & np.uint64(1)).astype(bool)                     # [tile, cb, u, j, lane]
+        words = bits.view(torch.int32).view(-1, N // 64, 64).cpu().numpy().astype(np.uint32)
+        bit = np.arange(32, dtype=np.uint32)
+        got = ((words[..., None] >> bit) & np.uint32(1)).astype(bool).reshape(-1, N // 64, 4, 16, 8, 4)   # [tile, cb, lane // 16, lane % 16, u, j]
         hp = torch.zeros((M + 31) // 32 * 32, N, device="cuda")
         hp[:M] = h
         want = (hp > 0).cpu().numpy().reshape(-1, 8, 4, N // 64, 16, 4)                     # [tile, u, lane // 16, cb, lane % 16, j]
-        want = want.transpose(0, 3, 1, 5, 2, 4).reshape(got.shape)
+        want = want.transpose(0, 3, 2, 4, 1, 5)
         assert np.array_equal(got, want)
         gy = torch.randn(M, 64, device="cuda", generator=g)
         wt = torch.randn(N, 64, device="cuda", generator=g)

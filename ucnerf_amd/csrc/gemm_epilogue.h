@@ -27,24 +27,32 @@ struct GemmOut {
     uint32_t ldx2 = 0, ldw2 = 0;
     // r06: ReLU derivatives as BIT masks (staged form of the split engine only).  bits_out: the producing GEMM (forward, ReLU) leaves
     // "y > 0" of every output as one bit; bits_in: the d X GEMM of the layer above reads those bits instead of the stored fp32 output
-    // (1 GB per [2^20, 256] layer).  Layout = the staged store's own: 64-bit word (((row tile of 32) * (N / 64) + column block) * 8 + u) * 4 + j
-    // holds, at bit `lane`, the output this lane stores in step u, component j -- writer and reader walk the same loop, no bit is moved.
-    unsigned long long *bits_out = nullptr;
-    const unsigned long long *bits_in = nullptr;
+    // (1 GB per [2^20, 256] layer).  Layout = the staged store's own: 32-bit word ((row tile of 32) * (N / 64) + column block) * 64 + lane
+    // holds, at bit 4 u + j, the output this lane stores in step u, component j (row 32 tile + 4 u + lane / 16, column 64 block +
+    // 4 (lane % 16) + j) -- writer and reader walk the same loop: one coalesced 256-byte store / load per wave and column block, no
+    // ballot, no bit is moved.  (first form: 64-bit ballots, word per (u, j): 32 eight-byte stores and as many scalar loads per block.)
+    uint32_t *bits_out = nullptr;
+    const uint32_t *bits_in = nullptr;
 };
 
 // 64-bit words of a bit mask over an [M, N] output (N a multiple of 64)
 __host__ __device__ inline unsigned long long gemm_bits_words(unsigned long long M, unsigned N) { return (M + 31u) / 32u * (N / 64u) * 32u; }
 
-__device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {      // vector form: col + 3 < N
+// `rb` = the row-group bias of this quad (zeros without one): the staged store fetches it once per column block, not once per row
+__device__ __forceinline__ float4 gemm_finish_v(float4 v, const GemmOut &o, uint32_t row, uint32_t col, float4 rb) {      // vector form: col + 3 < N
     if (o.bias) { const float4 bv = *reinterpret_cast<const float4 *>(o.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-    if (o.rbias) { const float4 bv = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(row / o.rgroup) * o.ldr + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
     if (o.flags & kGemmRelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (o.flags & kGemmMask) {
         const float4 m = *reinterpret_cast<const float4 *>(o.mask + (size_t)row * o.ldm + col);
         v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
     }
     return v;
+}
+__device__ __forceinline__ float4 gemm_finish(float4 v, const GemmOut &o, uint32_t row, uint32_t col) {
+    float4 rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o.rbias) rb = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(row / o.rgroup) * o.ldr + col);
+    return gemm_finish_v(v, o, row, col, rb);
 }
 
 // Direct form: a lane stores the quads of its own row (any N, any alignment).  TRACK: returns the maximum of |every value this lane stored|
@@ -96,7 +104,12 @@ template <uint32_t NT, bool TRACK = false, bool X2 = false, int BITS = 0>       
 __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], const GemmOut &o, float *tile, uint32_t m0, uint32_t n0,
                                                    uint32_t lane) {
     float mx = 0.0f;
-    const unsigned long long bits_row = BITS ? (unsigned long long)__builtin_amdgcn_readfirstlane(m0 >> 5) * (o.N >> 6) : 0ull;
+    const size_t bits_row = BITS ? (size_t)(m0 >> 5) * (o.N >> 6) : 0u;
+    // row-group bias: a tile of 32 rows meets at most two groups of >= 32 rows -- two (scalar) divisions per tile, the two groups' quads
+    // of this lane's columns fetched once per column block, a compare per row (r06; first form: a division and a load per row and quad)
+    const bool rb_wide = o.rbias && o.rgroup >= 32u;
+    const uint32_t rb_g0 = rb_wide ? (uint32_t)__builtin_amdgcn_readfirstlane(m0) / o.rgroup : 0u, rb_next = (rb_g0 + 1u) * o.rgroup;
+    const uint32_t rb_g1 = rb_wide ? min(rb_g0 + 1u, (o.M - 1u) / o.rgroup) : 0u;
     static_assert(NT % 2u == 0u, "column blocks of two tiles");
     constexpr uint32_t RS = 68u;                                   // row stride in floats (64 + 4: the rows of a write fall on different bank groups)
     const uint32_t i = lane & 31u, kk = lane >> 5;
@@ -120,20 +133,22 @@ __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], cons
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) w2r[j] = *reinterpret_cast<const float4 *>(o.w2 + (size_t)(n0 + 64u * cb + 4u * (lane & 15u) + j) * o.ldw2);
         }
+        float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
+        if (rb_wide) {
+            const float *rp = o.rbias + n0 + 64u * cb + 4u * (lane & 15u);
+            rb0 = *reinterpret_cast<const float4 *>(rp + (size_t)rb_g0 * o.ldr);
+            rb1 = *reinterpret_cast<const float4 *>(rp + (size_t)rb_g1 * o.ldr);
+        }
+        const size_t widx = BITS ? (bits_row + (n0 >> 6) + cb) * 64u + lane : 0u;
+        uint32_t word = 0u;
+        if constexpr (BITS == 2) {
+            if (m0 < o.M) word = o.bits_in[widx];                  // (a wave wholly past the last row owns no words)
+        }
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) {
             const uint32_t f = lane + 64u * u, r = f >> 4, c4 = f & 15u;
             const uint32_t ro = m0 + r, col = n0 + 64u * cb + 4u * c4;
             float4 v = *reinterpret_cast<const float4 *>(tile + r * RS + 4u * c4);
-            const unsigned long long wbase = BITS ? ((bits_row + (n0 >> 6) + cb) * 8u + u) * 4u : 0ull;       // wave-uniform
-            unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
-            if constexpr (BITS == 2) {
-                if (m0 < o.M) {                                     // (a wave wholly past the last row owns no words)
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) mw[j] = o.bits_in[wbase + j];
-                }
-            }
-            bool pos[4] = {false, false, false, false};
             if (ro < o.M) {
                 if constexpr (X2) {
                     const float4 xv = *reinterpret_cast<const float4 *>(o.x2 + (size_t)ro * o.ldx2);
@@ -142,21 +157,21 @@ __device__ __forceinline__ float gemm_store_staged(const f32x16 (&acc)[NT], cons
                     v.z += xv.x * w2r[2].x + xv.y * w2r[2].y + xv.z * w2r[2].z + xv.w * w2r[2].w;
                     v.w += xv.x * w2r[3].x + xv.y * w2r[3].y + xv.z * w2r[3].z + xv.w * w2r[3].w;
                 }
-                float4 f = gemm_finish(v, o, ro, col);
+                float4 rb = ro >= rb_next ? rb1 : rb0;
+                if (o.rbias && !rb_wide) rb = *reinterpret_cast<const float4 *>(o.rbias + (size_t)(ro / o.rgroup) * o.ldr + col);
+                float4 f = gemm_finish_v(v, o, ro, col, rb);
                 if constexpr (BITS == 2) {
-                    f.x = ((mw[0] >> lane) & 1ull) ? f.x : 0.f; f.y = ((mw[1] >> lane) & 1ull) ? f.y : 0.f;
-                    f.z = ((mw[2] >> lane) & 1ull) ? f.z : 0.f; f.w = ((mw[3] >> lane) & 1ull) ? f.w : 0.f;
+                    f.x = (word & (1u << (4u * u))) ? f.x : 0.f; f.y = (word & (2u << (4u * u))) ? f.y : 0.f;
+                    f.z = (word & (4u << (4u * u))) ? f.z : 0.f; f.w = (word & (8u << (4u * u))) ? f.w : 0.f;
                 }
-                if constexpr (BITS == 1) { pos[0] = f.x > 0.f; pos[1] = f.y > 0.f; pos[2] = f.z > 0.f; pos[3] = f.w > 0.f; }
+                if constexpr (BITS == 1)
+                    word |= ((f.x > 0.f ? 1u : 0u) | (f.y > 0.f ? 2u : 0u) | (f.z > 0.f ? 4u : 0u) | (f.w > 0.f ? 8u : 0u)) << (4u * u);
                 if constexpr (TRACK) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
                 *reinterpret_cast<float4 *>(o.Y + (size_t)ro * o.ldy + col) = f;
             }
-            if constexpr (BITS == 1) {                              // (outside the row guard: a ballot is taken by the whole wave)
-                unsigned long long b[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) b[j] = __ballot(pos[j]);
-                if (lane < 4u && m0 < o.M) o.bits_out[wbase + lane] = lane == 0u ? b[0] : lane == 1u ? b[1] : lane == 2u ? b[2] : b[3];
-            }
+        }
+        if constexpr (BITS == 1) {
+            if (m0 < o.M) o.bits_out[widx] = word;
         }
         wave_lds_handoff();
     }

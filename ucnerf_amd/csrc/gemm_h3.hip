@@ -641,8 +641,8 @@ extern "C" int ucn_gemm_h3_x2(const float *X, uint32_t ldx, const void *packed, 
     UCN_REQUIRE(!(relu_bits_out || mask_bits) || (vec && N % 64u == 0u && N >= 128u && h3_tiles(N) * 32u == N),
                 "gemm_h3: ReLU bit masks need the staged epilogue of a 128- or 256-wide output (N %u)", N);
     UCN_REQUIRE(!(mask_bits && (flags & (int)kGemmMask)), "gemm_h3: a float mask and a bit mask together");
-    o.bits_out = reinterpret_cast<unsigned long long *>(relu_bits_out);
-    o.bits_in = reinterpret_cast<const unsigned long long *>(mask_bits);
+    o.bits_out = reinterpret_cast<uint32_t *>(relu_bits_out);
+    o.bits_in = reinterpret_cast<const uint32_t *>(mask_bits);
     const uint32_t ks = h3_ksteps(K);
     // UCN_H3_HALVES=2 (experiment, measured SLOWER: 0.755 against 0.656 ms at N = K = 256, profiles/r06/gemm_h3_notes.txt): 256-wide outputs as
     // two workgroups of 4 tiles per row tile instead of one of 8 -- the 4-tile kernel moves 4.3 TB/s on its own 128-wide shape, but here the

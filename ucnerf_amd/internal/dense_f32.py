@@ -91,6 +91,18 @@ def amax_of(t):
     return s
 
 
+def tag_amax_of_parts(whole, *parts):
+    """`whole` was assembled from `parts` (column blocks written by kernels / copies): its maximum is the largest of theirs -- one
+    tiny device op instead of a pass over `whole`.  Parts without a recorded maximum get one (amax_of)."""
+    if _ENGINE != "split" or not whole.is_cuda:
+        return whole
+    m = None
+    for p_ in parts:
+        s = amax_of(p_ if p_.dim() == 2 else p_.reshape(-1, p_.shape[-1]))
+        m = s if m is None else torch.maximum(m, s)
+    return _tag(whole, m)
+
+
 def stash_amax(ctx, tensors):
     """autograd: remember the recorded maxima of tensors about to be saved for backward (saved_tensors may hand back new objects)"""
     ctx._ucn_amax = [getattr(t, "_ucn_amax", None) if t is not None else None for t in tensors]

@@ -316,9 +316,21 @@ class _ColourMLPComposed(torch.autograd.Function):
         R, G = dense_f32._rows, dense_f32.gemm
         h0, A0, A1, W1h, Wr = R(h0), R(A0), R(A1), R(W1h), R(Wr)
         pr0, pr1 = pr0.contiguous(), pr1.contiguous()
-        h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
-        h2 = G(h1, W1h)
-        G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
+        if os.environ.get("UCN_COLOUR_CAT", "1") != "0":
+            # r06: layer 1's two products as ONE over the concatenated input [h1 | h0] (K = 256 + 64): h1 is written straight into its
+            # column block of the buffer; the second, accumulating pass re-read the whole [M, 256] output (0.65 + 0.69 ms -> 0.82 + a
+            # 0.1 ms copy).  UCN_COLOUR_CAT=0: the two-pass form (A/B)
+            M = h0.shape[0]
+            cat = torch.empty(M, W1h.shape[1] + h0.shape[1], device=h0.device, dtype=torch.float32)
+            cat[:, W1h.shape[1]:] = h0      # (before the kernel writes h1 into its view: an in-place torch op bumps the shared version
+            h1 = G(h0, A0, None, dense_f32.RELU, out=cat[:, :W1h.shape[1]], rowbias=pr0, rgroup=S)  # counter and h1's records would go stale)
+            dense_f32.tag_amax_of_parts(cat, h1, h0)
+            h2 = G(cat, torch.cat([W1h, A1], dim=1), None, dense_f32.RELU, rowbias=pr1, rgroup=S)
+            del cat
+        else:
+            h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
+            h2 = G(h1, W1h)
+            G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
         rgbl = G(h2, Wr, br.float().contiguous())
         ctx.save_for_backward(h0, h1, h2, A0, A1, W1h, Wr)
         dense_f32.stash_amax(ctx, (h0, h1, h2))
