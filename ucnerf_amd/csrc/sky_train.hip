@@ -667,6 +667,78 @@ __global__ __launch_bounds__(64) void k_sky_composite_bwd(const float *__restric
     }
 }
 
+// The same gradients with one WAVE per ray (r06; the default): lane l holds samples 2 l and 2 l + 1 (coalesced 32-byte pieces of the
+// ray's 1920 bytes), the transmittance is an exclusive prefix PRODUCT and the suffix sum an inclusive prefix sum across the wave (DPP
+// scans, wave_dpp.h).  The one-thread-per-ray form above is 128 waves of 240 dependent iterations each for a batch of 8192 rays: beside
+// the field's kernels on the other stream it sat on the sky stream's critical path for 3 ms (profiles/r06/train_top_heads.txt).  A scan
+// multiplies / adds in tree order: the results differ from the serial form's in the last bits (the forward pass, whose pixel values
+// are compared with the rendering kernel's, keeps the serial order).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or1(float v) {          // the DPP-selected lane's value, 1 where there is none
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_product(float v) {
+    v *= dpp_or1<0x111, 0xf>(v);
+    v *= dpp_or1<0x112, 0xf>(v);
+    v *= dpp_or1<0x114, 0xf>(v);
+    v *= dpp_or1<0x118, 0xf>(v);
+    v *= dpp_or1<0x142, 0xa>(v);
+    v *= dpp_or1<0x143, 0xc>(v);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_sky_composite_bwd_wave(const float *__restrict__ raw, const float *__restrict__ dirs,
+                                                                const float *__restrict__ far_, const float *__restrict__ t_vals,
+                                                                const float *__restrict__ g_out, uint32_t N, float *__restrict__ g_raw) {
+    static_assert(kSkySamples <= 128 && kSkySamples % 2 == 0, "two samples per lane");
+    const uint32_t ray = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (ray >= N) return;                                           // (wave-uniform)
+    const float inv_sky_far = inv_sky_far_of(far_);
+    const float dx = dirs[ray * 3 + 0], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float dn = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float nr = far_[ray];
+    const float g0 = g_out[ray * 3 + 0], g1 = g_out[ray * 3 + 1], g2 = g_out[ray * 3 + 2];
+    const bool live = 2u * lane < (uint32_t)kSkySamples;
+    const uint32_t s0 = live ? 2u * lane : 0u;
+    float zv[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const uint32_t s = s0 + q < (uint32_t)kSkySamples ? s0 + q : (uint32_t)kSkySamples - 1u;
+        zv[q] = nr * (1.0f - t_vals[s]) + inv_sky_far * t_vals[s];
+    }
+    const size_t o = ((size_t)ray * kSkySamples + s0) * 4;
+    float4 v[2];
+    v[0] = *reinterpret_cast<const float4 *>(raw + o);
+    v[1] = *reinterpret_cast<const float4 *>(raw + o + 4);
+    float e[2], alpha[2], keep[2], dist[2], c[2][3], gc[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        dist[q] = (s0 + q + 1u < (uint32_t)kSkySamples ? zv[q + 1] - zv[q] : 1e10f) * dn;
+        const float sg = fmaxf(v[q].w, 0.0f);
+        e[q] = expf(-sg * dist[q]);
+        alpha[q] = 1.0f - e[q];
+        keep[q] = live ? (1.0f - alpha[q]) + 1e-10f : 1.0f;
+        c[q][0] = 1.0f / (1.0f + expf(-v[q].x)); c[q][1] = 1.0f / (1.0f + expf(-v[q].y)); c[q][2] = 1.0f / (1.0f + expf(-v[q].z));
+        gc[q] = (g0 * c[q][0] + g1 * c[q][1]) + g2 * c[q][2];
+    }
+    // transmittance in front of the lane's first sample: the exclusive product of the lanes below
+    const float incl = wave_scan_product(keep[0] * keep[1]);
+    const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+    float T[2] = {below, below * keep[0]};
+    float w[2] = {alpha[0] * T[0], alpha[1] * T[1]};
+    const float wg0 = live ? w[0] * gc[0] : 0.0f, wg1 = live ? w[1] * gc[1] : 0.0f;
+    const float sum_incl = wave_scan_dpp<float>(wg0 + wg1);
+    const float total = wave_last<float>(sum_incl);
+    const float prefix[2] = {(sum_incl - (wg0 + wg1)) + wg0, sum_incl};
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const float dalpha = T[q] * gc[q] - (total - prefix[q]) / keep[q];
+        const float dsig = v[q].w > 0.0f ? dalpha * dist[q] * e[q] : 0.0f;
+        *reinterpret_cast<float4 *>(g_raw + o + 4 * q) =
+            make_float4(g0 * w[q] * c[q][0] * (1.0f - c[q][0]), g1 * w[q] * c[q][1] * (1.0f - c[q][1]), g2 * w[q] * c[q][2] * (1.0f - c[q][2]), dsig);
+    }
+}
+
 // the forward compositing with the device-side far plane (k_sky_composite of sky.hip takes it from the host)
 __global__ __launch_bounds__(64) void k_sky_composite_dev(const float *__restrict__ raw, const float *__restrict__ dirs,
                                                           const float *__restrict__ far_, const float *__restrict__ t_vals,
@@ -816,8 +888,12 @@ extern "C" int ucn_sky_train_bwd(const void *packed, const float *g_sky_rgb, con
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t M = (uint64_t)N * kSkySamples;
-    hipLaunchKernelGGL(k_sky_composite_bwd, dim3(ucn_div_up(N, 64)), dim3(64), 0, st, raw, directions, far_, t_vals, g_sky_rgb, N,
-                       g_raw_ws);
+    const char *serial = getenv("UCN_SKY_COMP_SERIAL");           // A/B switch (read per call): 1 = one thread per ray
+    if (serial && atoi(serial) == 1)
+        hipLaunchKernelGGL(k_sky_composite_bwd, dim3(ucn_div_up(N, 64)), dim3(64), 0, st, raw, directions, far_, t_vals, g_sky_rgb, N, g_raw_ws);
+    else
+        hipLaunchKernelGGL(k_sky_composite_bwd_wave, dim3(ucn_div_up(N, 4)), dim3(256), 0, st, raw, directions, far_, t_vals, g_sky_rgb, N,
+                           g_raw_ws);
     SkyTrainBwdArgs a{reinterpret_cast<const uint8_t *>(packed), g_raw_ws, reinterpret_cast<const uint4 *>(mask),
                       reinterpret_cast<const uint2 *>(mask_v), reinterpret_cast<uint16_t *>(grad), (uint32_t)M};
     hipLaunchKernelGGL(k_sky_train_bwd, dim3(ucn_div_up(M, 32 * kBwdWaves)), dim3(64 * kBwdWaves),
