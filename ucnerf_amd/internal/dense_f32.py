@@ -160,6 +160,19 @@ def _rows(t):
     return out
 
 
+ACT_PAD = int(os.environ.get("UCN_ACT_PAD", "0"))          # experiment: floats added to the row stride of wide activation buffers
+
+
+def rows_buffer(M, N, device):
+    """an uninitialised [M, N] float32 activation buffer for `out=`.  UCN_ACT_PAD > 0 (experiment, measured SLOWER): on the split engine
+    a column view of an [M, N + ACT_PAD] allocation, so that rows are not 1024 bytes apart (tools/h3_alias_probe.py had the 256 x 256
+    product alone at 0.60 - 0.66 ms against 0.72 with such strides at M = 2^20; in the step, M = 983 040 / 1.8 M rows, the fp32 sky step
+    went 32.7 -> 34.3 / 34.4 / 35.0 ms with 8 / 24 / 72 floats of padding and the literal launch 49.3 -> 51.6 / 51.9 / 52.3)."""
+    if _ENGINE == "split" and ACT_PAD > 0 and M >= H3_MIN_ROWS and N % 128 == 0:
+        return torch.empty(M, N + ACT_PAD, device=device, dtype=torch.float32)[:, :N]
+    return torch.empty(M, N, device=device, dtype=torch.float32)
+
+
 def gemm(x, w, bias=None, flags=0, out=None, n_out=None, mask=None, rowbias=None, rgroup=0, x2=None, w2=None):
     """out[M, N] (+)= x[M, K] w[N, K]^T (+ bias) (+ rowbias[row // rgroup]) (+ x2[M, 4] w2[N, 4]^T) (ReLU); x / w as returned by _rows
     (equal padded K).  `out` may be a column view.  mask [M, N] (a float tensor, e.g. the stored ReLU output of the layer below):

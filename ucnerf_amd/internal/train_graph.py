@@ -321,11 +321,11 @@ class _ColourMLPComposed(torch.autograd.Function):
             # column block of the buffer; the second, accumulating pass re-read the whole [M, 256] output (0.65 + 0.69 ms -> 0.82 + a
             # 0.1 ms copy).  UCN_COLOUR_CAT=0: the two-pass form (A/B)
             M = h0.shape[0]
-            cat = torch.empty(M, W1h.shape[1] + h0.shape[1], device=h0.device, dtype=torch.float32)
+            cat = torch.empty(M, W1h.shape[1] + h0.shape[1] + dense_f32.ACT_PAD, device=h0.device, dtype=torch.float32)[:, :W1h.shape[1] + h0.shape[1]]
             cat[:, W1h.shape[1]:] = h0      # (before the kernel writes h1 into its view: an in-place torch op bumps the shared version
             h1 = G(h0, A0, None, dense_f32.RELU, out=cat[:, :W1h.shape[1]], rowbias=pr0, rgroup=S)  # counter and h1's records would go stale)
             dense_f32.tag_amax_of_parts(cat, h1, h0)
-            h2 = G(cat, torch.cat([W1h, A1], dim=1), None, dense_f32.RELU, rowbias=pr1, rgroup=S)
+            h2 = G(cat, torch.cat([W1h, A1], dim=1), None, dense_f32.RELU, out=dense_f32.rows_buffer(M, W1h.shape[0], h0.device), rowbias=pr1, rgroup=S)
             del cat
         else:
             h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
@@ -346,10 +346,11 @@ class _ColourMLPComposed(torch.autograd.Function):
         n_rgb = Wr.shape[0]
         g4 = R(g_rgbl.float())                                                     # [M, 3 -> 4]
         gWr4, gbr4 = WG(g4, h2, True)
-        d1 = G(g4, R(Wr.t()), mask=h2)                                             # d (layer 1 pre-activation)
-        r1 = d1.view(N, S, NW).sum(dim=1)
-        d0 = G(d1, R(W1h.t()), mask=h1)
-        r0 = d0.view(N, S, NW).sum(dim=1)
+        E = lambda: dense_f32.rows_buffer(g4.shape[0], NW, g4.device)
+        d1 = G(g4, R(Wr.t()), mask=h2, out=E())                                    # d (layer 1 pre-activation)
+        r1 = d1.unflatten(0, (N, S)).sum(dim=1)                                    # (strided views: no copy)
+        d0 = G(d1, R(W1h.t()), mask=h1, out=E())
+        r0 = d0.unflatten(0, (N, S)).sum(dim=1)
         gA0, gA1, gW1h = WG(d0, h0)[0], WG(d1, h0)[0], WG(d1, h1)[0]
         gh0 = G(d0, R(A0.t()))
         G(d1, R(A1.t()), flags=dense_f32.ACCUMULATE, out=gh0)
@@ -921,18 +922,19 @@ class _SkyTrunkF32(torch.autograd.Function):
         group = M // n
         pad4 = lambda w: torch.nn.functional.pad(w, (0, 4 - w.shape[1] % 4)) if w.shape[1] % 4 else w
         hs = []
-        h = G(pts4, pad4(Ws[0].detach()).contiguous(), bs[0].detach(), dense_f32.RELU)
+        E = lambda n_: dense_f32.rows_buffer(M, n_, pts4.device)          # (row strides off the powers of two: rows_buffer)
+        h = G(pts4, pad4(Ws[0].detach()).contiguous(), bs[0].detach(), dense_f32.RELU, out=E(256))
         hs.append(h)
         for i in range(1, 8):
             W = Ws[i].detach()
             if i == 5:                                                      # [pts | h] -> two column blocks of the weight: the 3-d block
                 h = G(h, W[:, 3:].contiguous(), bs[i].detach(), dense_f32.RELU,       # rides in the wide product's epilogue (r06)
-                      x2=pts4, w2=pad4(W[:, :3]).contiguous())
+                      out=E(256), x2=pts4, w2=pad4(W[:, :3]).contiguous())
             else:
-                h = G(h, W.contiguous(), bs[i].detach(), dense_f32.RELU)
+                h = G(h, W.contiguous(), bs[i].detach(), dense_f32.RELU, out=E(256))
             hs.append(h)
         sigma = G(h, Wa.detach().contiguous(), ba.detach())                                    # [M, 1]
-        hv = G(h, Mv.detach().contiguous(), bv.detach(), dense_f32.RELU, rowbias=per_ray.detach().contiguous(), rgroup=group)    # [M, 128]
+        hv = G(h, Mv.detach().contiguous(), bv.detach(), dense_f32.RELU, out=E(128), rowbias=per_ray.detach().contiguous(), rgroup=group)    # [M, 128]
         rgbl = G(hv, Wr.detach().contiguous(), br.detach())                                    # [M, 3] logits
         ctx.save_for_backward(pts4, Mv, Wa, Wr, hv, *hs, *Ws)
         dense_f32.stash_amax(ctx, (pts4, hv, *hs))
@@ -959,14 +961,16 @@ class _SkyTrunkF32(torch.autograd.Function):
         # rgb row
         gWr4, gbr4 = WG(g4, hv, True)
         gWr, gbr = gWr4[:3], gbr4[:3]
-        dv = G(g4, padT(Wr), mask=hv)                                                          # d (view layer pre-activation) [M, 128]
+        E = lambda n_: dense_f32.rows_buffer(M, n_, dev)
+        dv = G(g4, padT(Wr), mask=hv, out=E(128))                                              # d (view layer pre-activation) [M, 128]
         gMv, gbv = WG(dv, hs[7], True)
-        g_per_ray = dv.reshape(n, ctx.group, -1).sum(dim=1)
+        g_per_ray = dv.unflatten(0, (n, ctx.group)).sum(dim=1)                                 # (a strided view: no copy)
         # into h7: view layer + density row, masked by h7 > 0 after the sum
         gWa4, gba4 = WG(gs4, hs[7], True)
         gWa, gba = gWa4[:1], gba4[:1]
-        d = G(dv, Mv.detach().t().contiguous(), mask=hs[7], x2=gs4, w2=padT(Wa))    # (the density row's rank-1 term in the epilogue, r06)
+        d = G(dv, Mv.detach().t().contiguous(), mask=hs[7], out=E(256), x2=gs4, w2=padT(Wa))    # (the density row's rank-1 term in the epilogue, r06)
         del dv
+        spare = E(256)                                                                         # two gradient buffers ping-pong
         gW, gb = [None] * 8, [None] * 8
         for i in range(7, 0, -1):
             W = Ws[i].detach()
@@ -974,10 +978,10 @@ class _SkyTrunkF32(torch.autograd.Function):
                 gWh, gb[i] = WG(d, hs[4], True)
                 gWp = WG(d, pts4, False)[0]
                 gW[i] = torch.cat([gWp[:, :3], gWh], dim=1)
-                d = G(d, W[:, 3:].t().contiguous(), mask=hs[4])
+                d, spare = G(d, W[:, 3:].t().contiguous(), mask=hs[4], out=spare), d
             else:
                 gW[i], gb[i] = WG(d, hs[i - 1], True)
-                d = G(d, W.t().contiguous(), mask=hs[i - 1])
+                d, spare = G(d, W.t().contiguous(), mask=hs[i - 1], out=spare), d
         gW0, gb[0] = WG(d, pts4, True)
         gW[0] = gW0[:, :3]
         out = [None, g_per_ray, gMv, gbv, gWa, gba, gWr, gbr]
