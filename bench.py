@@ -202,12 +202,26 @@ def hbm_probe(device, n_floats=1 << 28, steps=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    os.environ["UCN_PROBE_COPY_UNROLL"] = "1"           # the same copy with four loads in flight per thread (4096 workgroups)
+    try:
+        for _ in range(2):
+            _lib.check(lib.ucn_probe_copy(src.data_ptr(), dst.data_ptr(), n_floats, _lib.stream()))
+        e0.record()
+        for _ in range(steps):
+            _lib.check(lib.ucn_probe_copy(src.data_ptr(), dst.data_ptr(), n_floats, _lib.stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        ms4 = e0.elapsed_time(e1) / steps
+    finally:
+        del os.environ["UCN_PROBE_COPY_UNROLL"]
     return dict(bytes_read_plus_written=8 * n_floats, ms=ms, GBps=8 * n_floats / (ms * 1e-3) / 1e9, spec_peak_GBps=PEAK_HBM_GBS,
-                guide_float4_copy_GBps=6290.0,
+                GBps_four_loads_in_flight=8 * n_floats / (ms4 * 1e-3) / 1e9, guide_float4_copy_GBps=6290.0,
                 shape=("k_copy4: a grid-stride float4 copy, 2048 workgroups x 256 threads, 1 GiB read + 1 GiB written, one load in flight per "
                        "thread (no unrolling, no non-temporal hints); /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for its float4 "
                        "copy -- this probe is the repo's OWN plain-kernel yardstick and is the pessimistic one of the two; neither enters "
-                       "`roofline.frac`, which is taken against the 8 TB/s spec peak"))
+                       "`roofline.frac`, which is taken against the 8 TB/s spec peak.  GBps_four_loads_in_flight: the same copy, four "
+                       "independent 16-byte loads per thread before the first store, 4096 workgroups (r06: 4.65 against 5.04 TB/s -- more "
+                       "requests in flight do not lift a 1 GiB -> 1 GiB copy on this part)"))
 
 
 class Ranks:

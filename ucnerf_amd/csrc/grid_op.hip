@@ -500,9 +500,23 @@ namespace {
 __global__ __launch_bounds__(256) void k_copy4(const float4 *__restrict__ s, float4 *__restrict__ d, uint64_t n4) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256u) d[i] = s[i];
 }
+// four independent 16-byte loads in flight per thread before the first store (UCN_PROBE_COPY_UNROLL=1; read per call)
+__global__ __launch_bounds__(256) void k_copy4x4(const float4 *__restrict__ s, float4 *__restrict__ d, uint64_t n4) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3u * stride < n4; i += 4u * stride) {
+        const float4 a = s[i], b = s[i + stride], c = s[i + 2u * stride], e = s[i + 3u * stride];
+        d[i] = a; d[i + stride] = b; d[i + 2u * stride] = c; d[i + 3u * stride] = e;
+    }
+    for (; i < n4; i += stride) d[i] = s[i];
+}
 }  // namespace
 extern "C" int ucn_probe_copy(const float *src, float *dst, uint64_t n_floats, ucn_stream_t stream) {
     UCN_REQUIRE((n_floats & 3) == 0, "probe_copy: n_floats must be a multiple of 4");
+    const char *u = getenv("UCN_PROBE_COPY_UNROLL");
+    if (u && atoi(u) == 1)
+        hipLaunchKernelGGL(k_copy4x4, dim3(4096), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst, n_floats / 4);
+    else
     hipLaunchKernelGGL(k_copy4, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst, n_floats / 4);
     UCN_LAUNCH_CHECK("probe_copy");
     return 0;
