@@ -54,6 +54,12 @@ def test_argument_errors_surface_as_messages_without_a_gpu():
     assert fwd(1, 2 | _lib.FEAT_BF16) != 0 and b"bf16 features are the inference form" in lib.ucn_last_error()
     assert fwd(None, 4 | _lib.FEAT_BF16) != 0 and b"level_dim 2" in lib.ucn_last_error()
     assert fwd(None, 2, h0=1) != 0 and b"no stores" in lib.ucn_last_error()
+    # r06: the split engine's ReLU bit masks -- one bit per element of whole 32-row tiles; only behind the staged 128- / 256-wide epilogue
+    assert lib.ucn_relu_bits_words(33, 256) == 2 * 4 * 32 and lib.ucn_relu_bits_words(32, 128) == 2 * 32 and lib.ucn_relu_bits_words(0, 256) == 0
+    h3 = lambda N, bits_out, bits_in, flags=0, mask=None: lib.ucn_gemm_h3_x2(16, 64, 16, 16, 16, None, 64, N, 64, flags, 16, N, mask, N, None, 0, 0,
+                                                                            None, 0, None, 0, bits_out, bits_in, None, None)
+    assert h3(64, 16, None) != 0 and b"bit masks need the staged epilogue" in lib.ucn_last_error()
+    assert h3(256, None, 16, flags=4, mask=16) != 0 and b"a float mask and a bit mask together" in lib.ucn_last_error()
 
 
 def test_gridencoder_extension_module_exports_the_reference_operator():
