@@ -30,6 +30,7 @@ GATHER_BYTES_PROP = S_PROP * 6 * 6 * 8 * 2 * 4           # 147,456 B
 MAC_NERF = 32 * 64 + 64 * 256 + 283 * 256 + 539 * 256 + 256 * 3      # 229,632 MAC / sample (reference formulation)
 FLOP_NERF_RAY = S_NERF * 2 * MAC_NERF
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PROF_EVERY = 8                # live per-kernel times: HIP events around every 8th pass of the timed frames (see main())
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 # MACs the split-f16 kernel issues per sample: first layer padded to 64 inputs; the bottleneck is composed away
@@ -716,6 +717,7 @@ def main():
         out = step()
     fence()
     model._prof = []
+    model._prof_every = PROF_EVERY
     udist.EXCHANGE_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -736,11 +738,15 @@ def main():
     if rank == 0:
         lo, hi = udist.shard_bounds(n_rays, world, rank)
         rays_rank = (hi - lo) * args.steps
-        assert rays_seen[1] == rays_rank
+        assert 0 < rays_seen[1] <= rays_rank and launches[1] >= 8
+        sampling = (f"HIP events around every {PROF_EVERY}th pass of the timed frames ({launches[1]} NeRF-level launches timed): an event record "
+                    "costs the queue ~10 us of idle time at a kernel boundary -- around every pass (r01-r05) that was 9 ms of a 470 ms "
+                    "frame, 1.9 % off `value` (tools/frame_gaps.py, profiles/r06/frame_gaps.txt)")
         gather = dict(bound="hbm", kernel="k_march_features<2, 256, float, false> (FEW_LEVELS = false: the NeRF-level launches)" + (", half tables" if args.autocast else ""),
                       achieved=rays_seen[1] * (GATHER_BYTES_NERF // 2 if args.autocast else GATHER_BYTES_NERF) / (feat_ms[1] * 1e-3) / 1e9,
                       peak=PEAK_HBM_GBS, unit="GB/s",
-                      avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], traffic=None)
+                      avg_launch_ms=feat_ms[1] / launches[1], rays_per_launch=rays_seen[1] / launches[1], launches_timed=launches[1],
+                      timing=sampling, traffic=None)
         if args.autocast:
             gather["bytes_note"] = "half tables: 2-byte entries, half the algorithmic gather bytes of the fp32 path"
         gather["frac"] = gather["achieved"] / gather["peak"]
@@ -848,8 +854,9 @@ def main():
                      "so 1 / (1 / hbm + 1 / mfma) is the serial ceiling"),
             "launch": ("self-launched: bench.py re-executed itself under torch.distributed.run" if os.environ.get("UCN_BENCH_SELF_LAUNCHED")
                        else ("torch.distributed.run (external launcher)" if world > 1 else "single process")),
-            "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / args.steps, "mlp_prop": mlp_ms[0] / args.steps,
-                                         "features_nerf": feat_ms[1] / args.steps, "mlp_nerf": mlp_ms[1] / args.steps},
+            # (from the timed sample of passes: ms per ray of the sample x the rank's rays per step)
+            "kernel_ms_per_step_rank0": {"features_prop": feat_ms[0] / max(rays_seen[0], 1) * (hi - lo), "mlp_prop": mlp_ms[0] / max(rays_seen[0], 1) * (hi - lo),
+                                         "features_nerf": feat_ms[1] / rays_seen[1] * (hi - lo), "mlp_nerf": mlp_ms[1] / rays_seen[1] * (hi - lo)},
         }
         if world > 1:
             # proof that the collective library saw N ranks, and what the frame's one exchange cost on rank 0

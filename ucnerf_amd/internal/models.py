@@ -561,6 +561,7 @@ class Model(nn.Module):
                                         sdist.data_ptr(), st))
             _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
             prof = getattr(self, '_prof', None)
+            prof_every = max(1, int(getattr(self, '_prof_every', 1)))
             # Two HIP streams: featurisation of pass i+1 (L2-request / VALU bound) runs beside the MLP of pass i
             # (MFMA bound) on a second feature buffer; the hardware splits the CUs between the two kernels.
             overlap = bool(self.overlap_streams) and N > chunk
@@ -578,12 +579,16 @@ class Model(nn.Module):
                 n = min(chunk, N - r0)
                 sl = slice(r0, r0 + n)
                 fb = feats[i_pass % len(feats)]
-                if prof is not None:
-                    e0, e1, m0, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+                # (bench.py's live per-kernel times: HIP events around every `_prof_every`-th pass only -- an event record costs the queue
+                #  ~10 us of idle time at a kernel boundary; around every pass that was 9 ms of a 470 ms frame, tools/frame_gaps.py)
+                timed = prof is not None and i_pass % prof_every == prof_every // 2
+                if timed:
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    m0 = torch.cuda.Event(enable_timing=True) if overlap else e1       # one stream: the MLP starts where the gather ends
                 fstream = side if overlap else cur
                 if overlap and mlp_done[i_pass % 2] is not None:
                     side.wait_event(mlp_done[i_pass % 2])             # the buffer's previous reader
-                if prof is not None:
+                if timed:
                     e0.record(fstream)
                 _lib.check(lib.ucn_march_features(
                     ctypes.byref(desc if mixed is None else mixed['desc']), sdist[sl].data_ptr(), near[sl].data_ptr(), far[sl].data_ptr(),
@@ -592,13 +597,13 @@ class Model(nn.Module):
                     float(self.std_scale), n, S, int(self.levels_per_block),
                     ((2 if self.rays_fastest else 0) | co) if mixed is None else (2 | mixed['table_flag'] | (mixed['feat_flag'] if not is_prop else 0)),
                     fb.data_ptr(), None if coord is None else coord[sl].data_ptr(), None, fstream.cuda_stream))
-                if prof is not None:
+                if timed:
                     e1.record(fstream)
                 if overlap:
                     ready = torch.cuda.Event()
                     ready.record(side)
                     cur.wait_event(ready)
-                if prof is not None:
+                if timed and overlap:
                     m0.record(cur)
                 compact = (not is_prop) and (not want_history) and self.compact_min_weight > 0 and mlp.mlp_mode == 1 and mixed is None
                 if mixed is not None and is_prop:
@@ -641,7 +646,7 @@ class Model(nn.Module):
                 if overlap:
                     mlp_done[i_pass % 2] = torch.cuda.Event()
                     mlp_done[i_pass % 2].record(cur)
-                if prof is not None:
+                if timed:
                     e2.record(cur)
                     prof.append((i_level, n, e0, e1, m0, e2))      # features: e0..e1 on its stream, MLP: m0..e2
             if overlap:
