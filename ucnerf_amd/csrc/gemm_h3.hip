@@ -230,8 +230,11 @@ struct H3Scales {
 // back edge hipcc's wait-count pass does not carry the ORDER of the loads in flight -- a register requested in the previous trip is
 // waited for as if every load of that trip had to land first (vmcnt(6) where 14 were allowed: the requests' real depth fell from four
 // steps to one and a half).  In straight-line code its counts are exact.  KS = 0: the loop, any K.
+#ifndef UCN_H3_OCC_NARROW
+#define UCN_H3_OCC_NARROW 2          // experiment: workgroups per CU asked for the NT <= 4 instantiations (3: <= 168 registers)
+#endif
 template <uint32_t NT, uint32_t KS>
-__global__ __launch_bounds__(kH3Threads, 2) void k_gemm_h3(const float *__restrict__ X, uint32_t ldx, const u4v *__restrict__ Wp, uint32_t K_rt,
+__global__ __launch_bounds__(kH3Threads, NT <= 4u ? UCN_H3_OCC_NARROW : 2) void k_gemm_h3(const float *__restrict__ X, uint32_t ldx, const u4v *__restrict__ Wp, uint32_t K_rt,
                                                           uint32_t ksteps_rt, H3Scales sc, GemmOut o) {
     constexpr uint32_t PX = kH3PX, PW = kH3PW;
     static_assert(PX % PW == 0u, "the weight sets rotate inside a chunk");
