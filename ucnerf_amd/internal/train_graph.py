@@ -160,14 +160,18 @@ class _TallLinear(torch.autograd.Function):
         return gx, gw.to(w_dt), ge, None
 
 
-def tall_linear(lin, x, grad_t=False):
-    """nn.Linear `lin` applied through _TallLinear (autocast: operands in bf16 like F.linear under autocast).
-    grad_t: the input gradient comes back as the transpose of a contiguous [K, M] matrix (for _FieldFeatures)."""
+def tall_linear(lin, x, grad_t=False, relu=False):
+    """nn.Linear `lin` (+ ReLU) applied through _TallLinear (autocast: operands in bf16 like F.linear under autocast).
+    grad_t: the input gradient comes back as the transpose of a contiguous [K, M] matrix (for _FieldFeatures).
+    relu: on the fp32 route the ReLU is the GEMM's epilogue (and its output keeps the recorded maximum the next product scales by:
+    the waymo.gin proposal level -- 1.9 M rows x 64 -- paid an elementwise pass and an amax pass for a separate F.relu)."""
     if torch.is_autocast_enabled():
-        return _TallLinear.apply(x, lin.weight, lin.bias, grad_t)
+        y = _TallLinear.apply(x, lin.weight, lin.bias, grad_t)
+        return F.relu(y) if relu else y
     if dense_f32.usable(x, lin.weight):            # the fp32 step (train_waymo.sh:3): hand-written fp32 MFMA GEMMs (csrc/gemm_f32.hip)
-        return dense_f32.hip_linear(x, lin.weight, lin.bias)
-    return F.linear(x, lin.weight, lin.bias)
+        return dense_f32.hip_linear(x, lin.weight, lin.bias, relu=relu)
+    y = F.linear(x, lin.weight, lin.bias)
+    return F.relu(y) if relu else y
 
 
 def tall_matmul(x, weight, acc=None):
@@ -792,7 +796,7 @@ def field_heads(mlp, feat, viewdirs, N, S):
         density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
         rgb = torch.sigmoid(mlp.rgb_premultiplier * rgbl.reshape(N, S, -1) + mlp.rgb_bias)
         return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
-    x = tall_linear(mlp.density_layer[2], F.relu(tall_linear(mlp.density_layer[0], feat)))       # [N*S, bottleneck]
+    x = tall_linear(mlp.density_layer[2], tall_linear(mlp.density_layer[0], feat, relu=True))    # [N*S, bottleneck]
     if mlp.disable_rgb:
         return F.softplus(x.reshape(N, S, -1)[..., 0] + mlp.density_bias), torch.zeros(N, S, 3, device=feat.device)
     enc = view_encoding(viewdirs, mlp.deg_view)                                                  # [N, 27], per ray
