@@ -367,7 +367,7 @@ int ucn_train_bwd(const void *gy, const void *graw, const float *head, const flo
 
 /* The PROPOSAL field's dense part in training (models.py:507-516 with disable_rgb: Linear(F,64) + ReLU, Linear(64,1),
  * softplus(raw + density_bias)), forward and backward, as VALU kernels (prop_train.hip) instead of ~45 library launches.
- * feat [M,F] fp32 (F <= 16), W0 [64,F], b0 [64], w1 [64], b1 [1] = the module's fp32 parameters.  round_bf16 != 0: operands
+ * feat [M,F] fp32 (F <= 24), W0 [64,F], b0 [64], w1 [64], b1 [1] = the module's fp32 parameters.  round_bf16 != 0: operands
  * and layer outputs rounded to bf16 with fp32 accumulation (what accelerator.autocast() makes of these layers); 0: fp32.
  * bwd: density = the forward's output, g_density its gradient; gfeat [M,F] | NULL; gW0 / gb0 / gw1 / gb1 fp32, summed in a
  * fixed order (deterministic); workspace of ucn_prop_train_bwd_ws_floats(F, M) floats. */

@@ -737,7 +737,7 @@ def test_sanitize_gradients_is_nan_to_num_on_every_gradient():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("F_in,M", [(12, 64 * 128), (12, 1000), (5, 4097), (16, 2048)])
+@pytest.mark.parametrize("F_in,M", [(12, 64 * 128), (12, 1000), (5, 4097), (16, 2048), (24, 128 * 100 + 7), (19, 3000)])
 def test_proposal_field_train_kernels(F_in, M, monkeypatch):
     """ucn_prop_train_fwd / _bwd (the proposal field's Linear-ReLU-Linear-softplus of models.py:507-516 as VALU kernels)
     against torch autograd on the same parameters: fp32 mode to accumulation-order rounding; bf16 mode against the same

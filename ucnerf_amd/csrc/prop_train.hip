@@ -1,6 +1,6 @@
 // Training-time forward and backward of the PROPOSAL field's dense part:
 // models.py:507-516 with disable_rgb = True -- Linear(F, 64) + ReLU, Linear(64, 1), softplus(raw + density_bias) -- on
-// the F = levels x channels features of the proposal grid (12 in the reference's configs).
+// the F = levels x channels features of the proposal grid (12 in BASELINE's configs, 24 on the reference's own waymo.gin grid: r06).
 //
 // As library ops this tiny MLP is ~45 launches per step (two GEMMs whose outputs are 64 and 1 columns wide, casts,
 // bias / ReLU / softplus passes, and in the backward a one-row weight-gradient GEMM that the library serves through a
@@ -240,7 +240,7 @@ constexpr uint32_t kSlab = 1024;     // samples per workgroup of the weight pass
 
 int check_shapes(uint32_t F, uint32_t hidden, uint64_t M) {
     UCN_REQUIRE(hidden == (uint32_t)kHidden, "prop_train: hidden width %u (this kernel: 64)", hidden);
-    UCN_REQUIRE(F >= 1 && F <= 16, "prop_train: 1..16 input features, got %u", F);
+    UCN_REQUIRE(F >= 1 && F <= 24, "prop_train: 1..24 input features, got %u", F);
     UCN_REQUIRE(M < 0xFFFF0000ull, "prop_train: too many samples");
     return 0;
 }
@@ -252,7 +252,9 @@ int check_shapes(uint32_t F, uint32_t hidden, uint64_t M) {
         case 4: { constexpr int FPC = 4; __VA_ARGS__; } break;   \
         case 8: { constexpr int FPC = 8; __VA_ARGS__; } break;   \
         case 12: { constexpr int FPC = 12; __VA_ARGS__; } break; \
-        default: { constexpr int FPC = 16; __VA_ARGS__; } break; \
+        case 16: { constexpr int FPC = 16; __VA_ARGS__; } break; \
+        case 20: { constexpr int FPC = 20; __VA_ARGS__; } break; \
+        default: { constexpr int FPC = 24; __VA_ARGS__; } break; \
     }
 
 extern "C" int ucn_prop_train_fwd(const float *feat, uint32_t F, uint32_t hidden, const float *W0, const float *b0, const float *w1,

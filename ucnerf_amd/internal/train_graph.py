@@ -745,7 +745,7 @@ class _PropHeads(torch.autograd.Function):
 
 def _fusable_prop(mlp, feat):
     l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
-    return (mlp.disable_rgb and len(mlp.density_layer) == 3 and feat.is_cuda and feat.shape[1] <= 16 and l0.out_features == 64
+    return (mlp.disable_rgb and len(mlp.density_layer) == 3 and feat.is_cuda and feat.shape[1] <= 24 and l0.out_features == 64
             and l1.out_features == 1 and l0.bias is not None and l1.bias is not None
             and (not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") == torch.bfloat16))
 
