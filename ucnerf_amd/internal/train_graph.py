@@ -998,14 +998,17 @@ def sky_forward(net, origins, directions, cam_dirs, far):
     """models.py:852-904 + :743-850 with torch ops (training only; rendering uses csrc/sky.hip)."""
     n = origins.shape[0]
     near = far.reshape(n, 1)
-    sky_far = torch.full_like(near, float(near[0].detach().cpu().item()) * 1.5)
-    tv = torch.linspace(0., 1., steps=120, device=origins.device)
+    sky_far = (near[0:1].detach() * 1.5).expand_as(near)        # 1.5 x the first ray's far plane (models.py:856-858), on the device:
+    tv = torch.linspace(0., 1., steps=120, device=origins.device)   # (r06: was float(near[0].item()) -- a host sync in every step)
     z = (near * (1. - tv) + 1. / sky_far * tv).expand(n, 120)
     pts = origins[:, None, :] + directions[:, None, :] * z[:, :, None]
-    views = cam_dirs[:, None, :].expand(-1, 120, -1)
     freqs = 2. ** torch.linspace(0., 3., 4, device=origins.device)
-    venc = torch.cat([views] + [fn(views * f) for f in freqs for fn in (torch.sin, torch.cos)], dim=-1)
-    if dense_f32.usable(pts, net.pts_linears[0].weight) and not dense_f32.library_route():
+    embed = lambda v: torch.cat([v] + [fn(v * f) for f in freqs for fn in (torch.sin, torch.cos)], dim=-1)
+    on_kernels = dense_f32.usable(pts, net.pts_linears[0].weight) and not dense_f32.library_route()
+    # the view encoding is the same for a ray's 120 samples: the kernel route needs it per RAY only (r06: it was formed per sample --
+    # nine elementwise passes and a 27-wide concatenation over [n, 120, .] -- and read back as venc[:, 0])
+    venc = embed(cam_dirs)[:, None, :] if on_kernels else embed(cam_dirs[:, None, :].expand(-1, 120, -1))
+    if on_kernels:
         # the fp32 step: every layer on csrc/gemm_f32.hip.  The reference's two concatenations (models.py:790-795: [pts | h] into
         # layer 5, [feature | view encoding] into the views layer) are products by column blocks of the weight instead -- the
         # direction block is per RAY ([n, 27] against [n * 120, 283] rows)
