@@ -1192,6 +1192,48 @@ def test_fp32_sky_chain_node_matches_the_layer_by_layer_route_and_torch(monkeypa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["split", "exact"])
+def test_fp32_field_mlp_as_one_node_matches_three_nodes(engine, monkeypatch):
+    """_FieldMLPComposed (r06: density layer 0 + the density row + the composed colour MLP as one autograd node, the 64-wide hidden
+    layer's gradient accumulated in one buffer and masked in the last product's epilogue) against the three-node route
+    (hip_linear -> _ColourMLPComposed, hip_linear; UCN_FIELD_NODE=0): same outputs, same gradients of the features and of every
+    parameter to fp32 reassociation, on both dense engines."""
+    import bench
+    from ucnerf_amd.internal import train_graph as tg, dense_f32 as D
+    prev, prev_rows = D.set_engine(engine), D.H3_MIN_ROWS
+    D.H3_MIN_ROWS = 4096
+    try:
+        dev = torch.device("cuda", 0)
+        model, _, _ = bench.build_model(dev)
+        mlp = model.nerf_mlp
+        Fp = mlp.encoder.num_levels * mlp.encoder.level_dim
+        N, S = 96, 128
+        g = torch.Generator(device=dev).manual_seed(5)
+        feat = torch.randn(N * S, Fp, device=dev, generator=g).requires_grad_(True)
+        vd = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1)
+        cd, cr = torch.randn(N, S, device=dev, generator=g), torch.randn(N, S, 3, device=dev, generator=g)
+        outs = {}
+        for node in ("1", "0"):
+            monkeypatch.setenv("UCN_FIELD_NODE", node)
+            mlp.zero_grad(set_to_none=True)
+            feat.grad = None
+            d, rgb = tg.field_heads(mlp, feat, vd, N, S)
+            ((d * cd).sum() + (rgb * cr).sum()).backward()
+            outs[node] = (d.detach().clone(), rgb.detach().clone(), feat.grad.clone(),
+                          {k: p.grad.clone() for k, p in mlp.named_parameters() if "encoder" not in k and p.grad is not None})
+        a, b = outs["1"], outs["0"]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                  # the same forward kernels on the same operands
+        tol = 2e-6 if engine == "exact" else 2e-5      # split: the summed gradient is scaled by ITS maximum, the parts by theirs
+        assert float((a[2] - b[2]).abs().max()) <= tol * float(b[2].abs().max())
+        assert set(a[3]) == set(b[3]) and len(a[3]) >= 8
+        for k in b[3]:
+            assert float((a[3][k] - b[3][k]).abs().max()) <= tol * max(float(b[3][k].abs().max()), 1e-6), k
+    finally:
+        D.set_engine(prev)
+        D.H3_MIN_ROWS = prev_rows
+
+
+@pytest.mark.gpu
 def test_fp32_sky_chain_backward_reads_relu_bits_and_changes_nothing(monkeypatch):
     """r06: on the split engine every ReLU layer of _SkyTrunkF32 leaves its derivative as one bit per element and the d X GEMM above
     reads the bits instead of the stored fp32 activations (ucn_gemm_h3_x2 relu_bits_out / mask_bits): all nine masked products of the

@@ -300,6 +300,50 @@ class _ColourMLP(torch.autograd.Function):
         return gx.to(x_dt), None, gW0.to(w_dt), gb0.to(b_dt), gW1.to(w_dt), gb1.to(b_dt), None, None
 
 
+def _colour_forward(h0, A0, pr0, W1h, A1, pr1, Wr, br, S):
+    """h1, h2, colour logits of the composed colour MLP (see _ColourMLPComposed) from the 64-wide hidden layer h0 [M, 64]; operands as
+    dense_f32._rows returns them."""
+    G = dense_f32.gemm
+    # r05: the per-ray terms are the GEMMs' row-group bias, the ReLUs their epilogue, and the rgb row (models.py:663) sits inside the
+    # node so that its d X GEMM can carry h2's ReLU derivative as a mask epilogue (r04: ucn_bias_relu / ucn_relu_backward_reduce passes)
+    pr0, pr1 = pr0.contiguous(), pr1.contiguous()
+    if os.environ.get("UCN_COLOUR_CAT", "1") != "0":
+        # r06: layer 1's two products as ONE over the concatenated input [h1 | h0] (K = 256 + 64): h1 is written straight into its
+        # column block of the buffer; the second, accumulating pass re-read the whole [M, 256] output (0.65 + 0.69 ms -> 0.82 + a
+        # 0.1 ms copy).  UCN_COLOUR_CAT=0: the two-pass form (A/B)
+        M = h0.shape[0]
+        cat = torch.empty(M, W1h.shape[1] + h0.shape[1] + dense_f32.ACT_PAD, device=h0.device, dtype=torch.float32)[:, :W1h.shape[1] + h0.shape[1]]
+        cat[:, W1h.shape[1]:] = h0      # (before the kernel writes h1 into its view: an in-place torch op bumps the shared version
+        h1 = G(h0, A0, None, dense_f32.RELU, out=cat[:, :W1h.shape[1]], rowbias=pr0, rgroup=S)  # counter and h1's records would go stale)
+        dense_f32.tag_amax_of_parts(cat, h1, h0)
+        h2 = G(cat, torch.cat([W1h, A1], dim=1), None, dense_f32.RELU, out=dense_f32.rows_buffer(M, W1h.shape[0], h0.device), rowbias=pr1, rgroup=S)
+        del cat
+    else:
+        h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
+        h2 = G(h1, W1h)
+        G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
+    rgbl = G(h2, Wr, br.float().contiguous())
+    return h1, h2, rgbl
+
+
+def _colour_backward(g_rgbl, h0, h1, h2, A0, A1, W1h, Wr, N, S):
+    """gradients of _colour_forward: (d h0 [M, 64] -- a buffer the caller may keep accumulating into --, d A0, d pr0, d W1h, d A1, d pr1,
+    d Wr, d br)."""
+    R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
+    NW, n_rgb = W1h.shape[0], Wr.shape[0]
+    g4 = R(g_rgbl.float())                                                     # [M, 3 -> 4]
+    gWr4, gbr4 = WG(g4, h2, True)
+    E = lambda: dense_f32.rows_buffer(g4.shape[0], NW, g4.device)
+    d1 = G(g4, R(Wr.t()), mask=h2, out=E())                                    # d (layer 1 pre-activation)
+    r1 = d1.unflatten(0, (N, S)).sum(dim=1)                                    # (strided views: no copy)
+    d0 = G(d1, R(W1h.t()), mask=h1, out=E())
+    r0 = d0.unflatten(0, (N, S)).sum(dim=1)
+    gA0, gA1, gW1h = WG(d0, h0)[0], WG(d1, h0)[0], WG(d1, h1)[0]
+    gh0 = G(d0, R(A0.t()))
+    G(d1, R(A1.t()), flags=dense_f32.ACCUMULATE, out=gh0)
+    return gh0, gA0, r0, gW1h, gA1, r1, gWr4[:n_rgb], gbr4[:n_rgb]
+
+
 class _ColourMLPComposed(torch.autograd.Function):
     """fp32 route (r04): the colour MLP's two hidden layers with the activation-free bottleneck COMPOSED into them, on csrc/gemm_f32.hip.
 
@@ -315,50 +359,58 @@ class _ColourMLPComposed(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, A0, pr0, W1h, A1, pr1, Wr, br, N, S):
-        # r05: the per-ray terms are the GEMMs' row-group bias, the ReLUs their epilogue, and the rgb row (models.py:663) sits inside the
-        # node so that its d X GEMM can carry h2's ReLU derivative as a mask epilogue (r04: ucn_bias_relu / ucn_relu_backward_reduce passes)
-        R, G = dense_f32._rows, dense_f32.gemm
+        R = dense_f32._rows
         h0, A0, A1, W1h, Wr = R(h0), R(A0), R(A1), R(W1h), R(Wr)
-        pr0, pr1 = pr0.contiguous(), pr1.contiguous()
-        if os.environ.get("UCN_COLOUR_CAT", "1") != "0":
-            # r06: layer 1's two products as ONE over the concatenated input [h1 | h0] (K = 256 + 64): h1 is written straight into its
-            # column block of the buffer; the second, accumulating pass re-read the whole [M, 256] output (0.65 + 0.69 ms -> 0.82 + a
-            # 0.1 ms copy).  UCN_COLOUR_CAT=0: the two-pass form (A/B)
-            M = h0.shape[0]
-            cat = torch.empty(M, W1h.shape[1] + h0.shape[1] + dense_f32.ACT_PAD, device=h0.device, dtype=torch.float32)[:, :W1h.shape[1] + h0.shape[1]]
-            cat[:, W1h.shape[1]:] = h0      # (before the kernel writes h1 into its view: an in-place torch op bumps the shared version
-            h1 = G(h0, A0, None, dense_f32.RELU, out=cat[:, :W1h.shape[1]], rowbias=pr0, rgroup=S)  # counter and h1's records would go stale)
-            dense_f32.tag_amax_of_parts(cat, h1, h0)
-            h2 = G(cat, torch.cat([W1h, A1], dim=1), None, dense_f32.RELU, out=dense_f32.rows_buffer(M, W1h.shape[0], h0.device), rowbias=pr1, rgroup=S)
-            del cat
-        else:
-            h1 = G(h0, A0, None, dense_f32.RELU, rowbias=pr0, rgroup=S)
-            h2 = G(h1, W1h)
-            G(h0, A1, None, dense_f32.ACCUMULATE | dense_f32.RELU, out=h2, rowbias=pr1, rgroup=S)
-        rgbl = G(h2, Wr, br.float().contiguous())
+        h1, h2, rgbl = _colour_forward(h0, A0, pr0, W1h, A1, pr1, Wr, br, S)
         ctx.save_for_backward(h0, h1, h2, A0, A1, W1h, Wr)
         dense_f32.stash_amax(ctx, (h0, h1, h2))
-        ctx.meta = (N, S, W1h.shape[0])
+        ctx.meta = (N, S)
         return rgbl
 
     @staticmethod
     def backward(ctx, g_rgbl):
         h0, h1, h2, A0, A1, W1h, Wr = ctx.saved_tensors
         dense_f32.restore_amax(ctx, (h0, h1, h2))
-        N, S, NW = ctx.meta
+        N, S = ctx.meta
+        return _colour_backward(g_rgbl, h0, h1, h2, A0, A1, W1h, Wr, N, S) + (None, None)
+
+
+class _FieldMLPComposed(torch.autograd.Function):
+    """fp32 route (r06): the NeRF field's whole dense part as ONE node -- density layer 0 (+ ReLU), the density row of the bottleneck
+    (feature 0 of density layer 1: models.py:508-510), the composed colour MLP of _ColourMLPComposed -- so that the 64-wide hidden layer's
+    gradient is formed in one buffer: the colour branch's two products accumulate into it, the density row's rank-1 term is a third
+    accumulating product whose epilogue applies the layer's ReLU derivative (the mask is linear: masking the sum = masking the parts).
+    As three nodes autograd added the two branches' [M, 64] gradients, ran threshold_backward over the sum and copied it once more
+    (0.36 ms of elementwise passes per step at M = 2^20).  Returns (raw density [M, 1], colour logits [M, 3])."""
+
+    @staticmethod
+    def forward(ctx, feat, Wd0, bd0, wrow, brow, A0, pr0, W1h, A1, pr1, Wr, br, N, S):
+        R, G = dense_f32._rows, dense_f32.gemm
+        feat, Wd0, wrow, A0, A1, W1h, Wr = R(feat), R(Wd0), R(wrow), R(A0), R(A1), R(W1h), R(Wr)
+        h0 = G(feat, Wd0, bd0.float().contiguous(), dense_f32.RELU)                # [M, 64]
+        raw = G(h0, wrow, brow.float().contiguous())                              # [M, 1]
+        h1, h2, rgbl = _colour_forward(h0, A0, pr0, W1h, A1, pr1, Wr, br, S)
+        ctx.save_for_backward(feat, h0, h1, h2, Wd0, wrow, A0, A1, W1h, Wr)
+        dense_f32.stash_amax(ctx, (feat, h0, h1, h2))
+        ctx.meta = (N, S)
+        return raw, rgbl
+
+    @staticmethod
+    def backward(ctx, g_raw, g_rgbl):
+        feat, h0, h1, h2, Wd0, wrow, A0, A1, W1h, Wr = ctx.saved_tensors
+        dense_f32.restore_amax(ctx, (feat, h0, h1, h2))
+        N, S = ctx.meta
         R, G, WG = dense_f32._rows, dense_f32.gemm, dense_f32.wgrad
-        n_rgb = Wr.shape[0]
-        g4 = R(g_rgbl.float())                                                     # [M, 3 -> 4]
-        gWr4, gbr4 = WG(g4, h2, True)
-        E = lambda: dense_f32.rows_buffer(g4.shape[0], NW, g4.device)
-        d1 = G(g4, R(Wr.t()), mask=h2, out=E())                                    # d (layer 1 pre-activation)
-        r1 = d1.unflatten(0, (N, S)).sum(dim=1)                                    # (strided views: no copy)
-        d0 = G(d1, R(W1h.t()), mask=h1, out=E())
-        r0 = d0.unflatten(0, (N, S)).sum(dim=1)
-        gA0, gA1, gW1h = WG(d0, h0)[0], WG(d1, h0)[0], WG(d1, h1)[0]
-        gh0 = G(d0, R(A0.t()))
-        G(d1, R(A1.t()), flags=dense_f32.ACCUMULATE, out=gh0)
-        return gh0, gA0, r0, gW1h, gA1, r1, gWr4[:n_rgb], gbr4[:n_rgb], None, None
+        gh0, gA0, r0, gW1h, gA1, r1, gWr, gbr = _colour_backward(g_rgbl, h0, h1, h2, A0, A1, W1h, Wr, N, S)
+        g4 = torch.zeros(h0.shape[0], 4, device=h0.device)
+        g4[:, :1] = g_raw
+        gwrow4, gbrow4 = WG(g4, h0, True)                                          # [4, 64], [4]
+        w4 = torch.zeros(wrow.shape[1], 4, device=h0.device)
+        w4[:, :1] = wrow[:1].t()                                                   # [64, 4]: the row as the product's weight
+        dp0 = G(g4, w4, flags=dense_f32.ACCUMULATE, out=gh0, mask=h0)              # d (layer 0 pre-activation): the sum, masked
+        gWd0, gbd0 = WG(dp0, feat, True)                                           # [64, F]
+        gfeat = G(dp0, R(Wd0.t()))                                                 # [M, F]
+        return (gfeat, gWd0, gbd0, gwrow4[:1], gbrow4[:1], gA0, r0, gW1h, gA1, r1, gWr, gbr, None, None)
 
 
 # ------------------------------------------------------------------ fused bf16 forward of the NeRF field's dense layers
@@ -784,15 +836,20 @@ def field_heads(mlp, feat, viewdirs, N, S):
         NB = d1l.out_features
         NW = l0.out_features
         enc = view_encoding(viewdirs, mlp.deg_view)                                              # [N, 27], per ray
-        h0 = lin(feat, d0l.weight, d0l.bias, relu=True)                                          # [N*S, 64]
         Wd1t = d1l.weight.t()                                                                    # [64, NB] (view: autograd transposes back)
         W0x, W0e = l0.weight[:, :NB], l0.weight[:, NB:]
         W1h, W1x, W1e = l1.weight[:, :NW], l1.weight[:, NW:NW + NB], l1.weight[:, NW + NB:]
         A0, A1 = lin(W0x, Wd1t), lin(W1x, Wd1t)                                                  # W_ix Wd1   [NW, 64]
         pr0 = lin(enc, W0e, l0.bias) + lin(d1l.bias[None, :], W0x)                               # [N, NW] + [1, NW]
         pr1 = lin(enc, W1e, l1.bias) + lin(d1l.bias[None, :], W1x)
-        rgbl = _ColourMLPComposed.apply(h0, A0, pr0, W1h, A1, pr1, mlp.rgb_layer.weight, mlp.rgb_layer.bias, N, S)
-        raw = lin(h0, d1l.weight[:1], d1l.bias[:1])                                              # feature 0 of the bottleneck (models.py:508)
+        if os.environ.get("UCN_FIELD_NODE", "1") != "0" and feat.shape[1] % 4 == 0:
+            # r06: density layer 0, the density row and the colour MLP as one node (_FieldMLPComposed); 0: three nodes (A/B, cross-check)
+            raw, rgbl = _FieldMLPComposed.apply(feat, d0l.weight, d0l.bias, d1l.weight[:1], d1l.bias[:1], A0, pr0, W1h, A1, pr1,
+                                                mlp.rgb_layer.weight, mlp.rgb_layer.bias, N, S)
+        else:
+            h0 = lin(feat, d0l.weight, d0l.bias, relu=True)                                      # [N*S, 64]
+            rgbl = _ColourMLPComposed.apply(h0, A0, pr0, W1h, A1, pr1, mlp.rgb_layer.weight, mlp.rgb_layer.bias, N, S)
+            raw = lin(h0, d1l.weight[:1], d1l.bias[:1])                                          # feature 0 of the bottleneck (models.py:508)
         density = F.softplus(raw.reshape(N, S) + mlp.density_bias)
         rgb = torch.sigmoid(mlp.rgb_premultiplier * rgbl.reshape(N, S, -1) + mlp.rgb_bias)
         return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
