@@ -717,7 +717,7 @@ def main():
         out = step()
     fence()
     model._prof = []
-    model._prof_every = PROF_EVERY
+    model._prof_every = 1 if args.pmc_child else PROF_EVERY       # (the 30-pass counter child: every pass, so that the launch-count check below holds)
     udist.EXCHANGE_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):

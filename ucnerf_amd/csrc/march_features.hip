@@ -974,6 +974,13 @@ static GradStrides grad_strides(int layout, size_t B, uint32_t L, uint32_t C) {
     return {B * C, C, 1};
 }
 
+#ifndef UCN_KSCAN
+#define UCN_KSCAN 4
+#endif
+constexpr uint32_t kScan = UCN_KSCAN;                          // samples per thread and scan step (8 measured: see DESIGN)
+#ifndef UCN_BWD_BYTE_MASKS_DEFAULT
+#define UCN_BWD_BYTE_MASKS_DEFAULT 1
+#endif
 constexpr uint32_t kMaxMaskWords = 16;                  // sample-item levels: up to 512 row blocks (16 KiB of LDS in the mask pass)
 struct MaskPlan {
     uint16_t plane[UCN_MAX_LEVELS];
@@ -982,7 +989,7 @@ struct MaskPlan {
     uint16_t split[UCN_MAX_LEVELS];        // workgroups per row block (cut along the samples): ~128 per level, 256 for the last
     uint32_t skip_fine;                    // 1: the fine levels are taken by the item-list kernels (k_bwd_list), not by bwd_cmp
     uint8_t order[UCN_MAX_LEVELS];         // levels in the order their workgroups are dispatched: longest workgroups first
-    uint8_t fine_kind[UCN_MAX_LEVELS];     // point-item levels: 0 = ballot-ordered items + corner walk, 1 = lane-ordered items + corner walk, 2 = lane-ordered + (y, z) combinations
+    uint8_t fine_kind[UCN_MAX_LEVELS];     // point-item levels: 0 = ballot-ordered items + corner walk, 1 = lane-ordered items + corner walk, 2 = lane-ordered + (y, z) combinations, 3 = 2 on byte planes (cmp_block_bytes)
 };
 __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
     return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
@@ -1021,6 +1028,15 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         if (!mp->coarse[l]) mp->fine_kind[l] = (!lv.lv[l].hashed || lv.lv[l].resolution >= 4096u) ? 2 : 0;
         static const int force_kind = getenv("UCN_BWD_FINE_KIND") ? atoi(getenv("UCN_BWD_FINE_KIND")) : -1;      // experiment knob
         if (!mp->coarse[l] && force_kind >= 0 && force_kind <= 2) mp->fine_kind[l] = (uint8_t)force_kind;
+        // 3 (r06, VERDICT r05 item 2 b): shape 2 with BYTE PLANES -- per row block one byte per sample (bit j = multisample j has a
+        // corner in the block), so that a scanning lane reads FOUR samples of ITS block in one dword (popcount 3.4 on average)
+        // where the nibble planes above give it one sample of four blocks (0.84 hits): one load, one popcount and one DPP prefix
+        // sum per 4096-sample unit instead of four.  Same number of planes.  UCN_BWD_BYTE_MASKS=0: off; =2: every point-item level
+        // (the lane order of its items makes the compare-and-swaps of resolution 1024 / 2048 collide, as with shape 1).
+        static const int byte_masks = getenv("UCN_BWD_BYTE_MASKS") ? atoi(getenv("UCN_BWD_BYTE_MASKS")) : UCN_BWD_BYTE_MASKS_DEFAULT;
+        if (!mp->coarse[l] && nb_l <= 32u && B % 4u == 0u && kScan == 4u &&
+            ((byte_masks == 1 && mp->fine_kind[l] == 2) || byte_masks == 2))
+            mp->fine_kind[l] = 3;
         mp->plane[l] = (uint16_t)mp->n_planes;
         if (mp->coarse[l] == 3) {
             // bit planes: [block][ceil(B / 64)] 64-bit words (one bit per sample) = nb x 2 x ceil(B / 64) 32-bit words, in units of B
@@ -1119,7 +1135,12 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         const uint32_t nb_l = (lv.rows + (1u << plan.shift) - 1u) >> plan.shift;
         bool nz = false;
         float gmax = 0.0f;
+#ifdef UCN_EXP_MASKS_NO_GRAD                                   // timing-only build (results garbage): geometry + masks alone, i.e. what is left
+        nz = valid;                                            // of this pass if k_train_bwd's epilogue wrote the level-major gradient (VERDICT r05 item 2 c)
+        for (uint32_t c = 0; c < 0u; c++) {
+#else
         for (uint32_t c = 0; c < C; c++) {
+#endif
             const float g = grad_features[lvl * gs.level + bb * gs.sample + c * gs.chan];
             nz |= valid && g != 0.0f;
             gmax = fmaxf(gmax, valid ? fabsf(g) : 0.0f);
@@ -1129,7 +1150,11 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             // an item stage would repeat it ~27 times per sample and level)
             if (valid) grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
         }
+#ifndef UCN_EXP_MASKS_NO_GRAD
         if (l1_partial) {                                   // (workgroup-uniform; every wave of the block gets here: no early `continue` above)
+#else
+        if (false) {
+#endif
             const float wsum = wave_sum_dpp<float>(gmax);
             if ((threadIdx.x & 63u) == 0u) s_l1[lvl][threadIdx.x >> 6] = wsum;
         }
@@ -1193,6 +1218,26 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
         if (!nz) {
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
+        }
+        if (plan.fine_kind[lvl] == 3 && !plan.coarse[lvl]) {
+            // BYTE PLANES (cmp_block_bytes): plane p = B bytes, byte b = the six point bits of sample b for row block p.  A thread
+            // spreads its masks into words of four block bytes (nibble x 0x00204081 puts bit i of a nibble at bit 8 i), the four
+            // threads of a quad (samples 4 q ... 4 q + 3; B % 4 == 0, so a quad is in range or not as a whole) transpose 4 x 4 bytes
+            // through DPP quad broadcasts + v_perm_b32, and thread i of the quad stores the dword of block 4 k + i.
+            const uint32_t qi = threadIdx.x & 3u;
+            const uint32_t sel01 = qi | ((4u + qi) << 8) | 0x0c0c0000u, sel23 = 0x00000c0cu | (qi << 16) | ((4u + qi) << 24);
+            uint8_t *pl = reinterpret_cast<uint8_t *>(masks + (size_t)plan.plane[lvl] * B);
+            const uint32_t groups = (nb_l + 3u) / 4u;
+            for (uint32_t k = 0; k < groups; k++) {
+                uint32_t wk = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < 6; j++) wk |= ((((m[j] >> (4u * k)) & 15u) * 0x00204081u) & 0x01010101u) << j;
+                const uint32_t w0 = dpp_or0<0x00, 0xf>(wk), w1 = dpp_or0<0x55, 0xf>(wk), w2 = dpp_or0<0xaa, 0xf>(wk), w3 = dpp_or0<0xff, 0xf>(wk);
+                const uint32_t d = __builtin_amdgcn_perm(w1, w0, sel01) | __builtin_amdgcn_perm(w3, w2, sel23);
+                const uint32_t blk = 4u * k + qi;
+                if (valid && blk < nb_l) *reinterpret_cast<uint32_t *>(pl + (size_t)blk * B + (b & ~(size_t)3)) = d;
+            }
+            continue;
         }
         if (!valid) continue;
         uint32_t *mp = masks + (size_t)plan.plane[lvl] * B + b;
@@ -1416,10 +1461,6 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_blk(UcnLevels lvls,
 // a global load + vmcnt(0) in front of every point -- and the LDS base came from the dynamic-LDS offset table,
 // an s_load per corner; that version spent 80 % of its time waiting on those.)
 constexpr uint32_t kQueue = 512;                               // items per wave; 16 waves x 2 KiB beside the 128 KiB block
-#ifndef UCN_KSCAN
-#define UCN_KSCAN 4
-#endif
-constexpr uint32_t kScan = UCN_KSCAN;                          // samples per thread and scan step (8 measured: see DESIGN)
 
 template <uint32_t C, bool HASHED, bool POW2, bool COARSE>
 __device__ __forceinline__ void cmp_fetch(uint32_t item, bool valid, size_t B, const float *__restrict__ gl,
@@ -1564,6 +1605,80 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, A *__restrict__ s_
                     else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
                 }
             }
+            head += avail;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Point-item levels on BYTE PLANES (MaskPlan::fine_kind 3; r06, VERDICT r05 item 2 b).  `mb` = this row block's plane: one byte per
+// sample, bit j = multisample j has a corner in the block (k_cast_cache_masks).  A lane reads ONE dword = four consecutive samples
+// per unit of 4096 (cmp_block: four dwords, one sample each, 6 useful bits of 32), counts its hits, the wave takes one DPP prefix
+// sum and every lane appends its own items; (y, z)-combination scatter as in shape 2.  A lane can hold up to 24 hits: when the
+// wave's count would not fit the ring, only every lane's lowest non-empty byte (<= 6 hits, <= 384 per wave: the bound cmp_block
+// lives with) is taken in this round and the rest of the word stays for the next one.
+template <uint32_t C, bool HASHED, bool POW2, typename A>
+__device__ __forceinline__ void cmp_block_bytes(const UcnLevel &lv, A *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t row_lo,
+                                                uint32_t nrows, uint32_t part, uint32_t split, size_t B,
+                                                const uint8_t *__restrict__ mb, const float *__restrict__ gl,
+                                                const float *__restrict__ geom, float gscale) {
+    static_assert(kScan == 4u, "a unit is 1024 dwords of four sample bytes");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t head = 0, tail = 0;
+    const size_t stride = (size_t)split * 4096u;
+    size_t base = (size_t)part * 4096u;
+    bool more = base < B, fresh = true;
+    uint32_t cur = 0u, nxt = 0u;
+    {
+        const size_t b = base + 4u * threadIdx.x;
+        if (b < B) cur = *reinterpret_cast<const uint32_t *>(mb + b) & 0x3f3f3f3fu;
+    }
+    while (more || tail != head) {
+        if (more) {
+            if (fresh) {                                                      // the next unit's word: in flight under this unit's items
+                const size_t b = base + stride + 4u * threadIdx.x;
+                nxt = b < B ? *reinterpret_cast<const uint32_t *>(mb + b) & 0x3f3f3f3fu : 0u;
+                fresh = false;
+            }
+            uint32_t take = cur;
+            uint32_t cnt = (uint32_t)__popc(take);
+            uint32_t incl = wave_scan_dpp<uint32_t>(cnt);
+            uint32_t tot = wave_last<uint32_t>(incl);
+            if (tail - head + tot > kQueue) {                                 // (wave-uniform, rare: 64 x 3.4 hits expected)
+                take = cur ? cur & (0xffu << ((uint32_t)__builtin_ctz(cur) & 24u)) : 0u;
+                cnt = (uint32_t)__popc(take);
+                incl = wave_scan_dpp<uint32_t>(cnt);
+                tot = wave_last<uint32_t>(incl);
+            }
+            uint32_t pos = tail + incl - cnt;
+            tail += tot;
+            cur &= ~take;
+            const uint32_t b4 = (uint32_t)base + 4u * threadIdx.x;
+            while (take) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(take);
+                take &= take - 1u;
+                q[pos & (kQueue - 1u)] = (b4 + (bit >> 3)) | (bit << 29);       // j = bit & 7 < 6: bits 29..31 (the sample's bits fall off the top)
+                pos++;
+            }
+            if (__ballot(cur != 0u) == 0ull) {
+                base += stride;
+                more = base < B;
+                cur = nxt;
+                fresh = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Ring: <= 127 left over + a fitting round (checked above) or <= 384 appended <= kQueue.
+        const uint32_t thr = more ? 128u : 1u;
+        while (tail - head >= thr && tail != head) {
+            const uint32_t avail = tail - head < 128u ? tail - head : 128u;
+            const uint32_t i0 = q[(head + lane) & (kQueue - 1u)], i1 = q[(head + 64u + lane) & (kQueue - 1u)];
+            const bool v0 = lane < avail, v1 = lane + 64u < avail;
+            float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
+            cmp_fetch<C, HASHED, POW2, false>(i0, v0, B, gl, geom, u0, rs0, g0, gscale);
+            cmp_fetch<C, HASHED, POW2, false>(i1, v1, B, gl, geom, u1, rs1, g1, gscale);
+            if (v0) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
+            if (v1) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
             head += avail;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1872,7 +1987,8 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale)
 #define UCN_CMPF(H, P2)                                                                                                      \
     do {                                                                                                                     \
-        if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);      \
+        if (plan.fine_kind[lvl] == 3) cmp_block_bytes<C, H, P2>(lv, acc_rows, q, row_lo, nrows, part, split, B, reinterpret_cast<const uint8_t *>(masks + (size_t)plan.plane[lvl] * B) + (size_t)blk * B, gl, geom, gscale); \
+        else if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);      \
         else if (plan.fine_kind[lvl] == 1) cmp_block<C, H, P2, false, false, 1>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale); \
         else cmp_block<C, H, P2, false, false, 0>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);           \
     } while (0)
