@@ -994,7 +994,7 @@ struct MaskPlan {
 __host__ __device__ __forceinline__ uint32_t bwd_sample_split(uint32_t blocks_in_level, uint32_t target = 128u) {
     return blocks_in_level >= target ? 1u : target / blocks_in_level;     // ~`target` workgroups per level (default 128)
 }
-static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan *mp) {
+static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan *mp, bool fixed_rows = false) {
     uint32_t shift = 0;
     while ((1u << shift) < rpb) shift++;
     if ((1u << shift) != rpb) return false;
@@ -1035,8 +1035,13 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         // (the lane order of its items makes the compare-and-swaps of resolution 1024 / 2048 collide, as with shape 1).
         static const int byte_masks = getenv("UCN_BWD_BYTE_MASKS") ? atoi(getenv("UCN_BWD_BYTE_MASKS")) : UCN_BWD_BYTE_MASKS_DEFAULT;
         if (!mp->coarse[l] && nb_l <= 32u && B % 4u == 0u && kScan == 4u &&
-            ((byte_masks == 1 && mp->fine_kind[l] == 2) || byte_masks == 2))
+            ((byte_masks == 1 && mp->fine_kind[l] == 2) || byte_masks == 2 || (byte_masks == 3 && mp->fine_kind[l] == 2)))
             mp->fine_kind[l] = 3;
+        // 4 (=3 only, experiment): the byte-plane scan with the CORNER WALK of shape 0 for the levels whose points still share cells
+        // (resolution 1024 / 2048) -- only where the row updates are fire-and-forget fixed-point adds: with compare-and-swap rows the
+        // lane order of the items makes neighbouring lanes fight for one row
+        else if (!mp->coarse[l] && nb_l <= 32u && B % 4u == 0u && kScan == 4u && byte_masks == 3 && fixed_rows && mp->fine_kind[l] == 0)
+            mp->fine_kind[l] = 4;
         mp->plane[l] = (uint16_t)mp->n_planes;
         if (mp->coarse[l] == 3) {
             // bit planes: [block][ceil(B / 64)] 64-bit words (one bit per sample) = nb x 2 x ceil(B / 64) 32-bit words, in units of B
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
 #pragma unroll
             for (uint32_t j = 0; j < 6; j++) m[j] = 0u;
         }
-        if (plan.fine_kind[lvl] == 3 && !plan.coarse[lvl]) {
+        if (plan.fine_kind[lvl] >= 3 && !plan.coarse[lvl]) {
             // BYTE PLANES (cmp_block_bytes): plane p = B bytes, byte b = the six point bits of sample b for row block p.  A thread
             // spreads its masks into words of four block bytes (nibble x 0x00204081 puts bit i of a nibble at bit 8 i), the four
             // threads of a quad (samples 4 q ... 4 q + 3; B % 4 == 0, so a quad is in range or not as a whole) transpose 4 x 4 bytes
@@ -1617,7 +1622,7 @@ __device__ __forceinline__ void cmp_block(const UcnLevel &lv, A *__restrict__ s_
 // sum and every lane appends its own items; (y, z)-combination scatter as in shape 2.  A lane can hold up to 24 hits: when the
 // wave's count would not fit the ring, only every lane's lowest non-empty byte (<= 6 hits, <= 384 per wave: the bound cmp_block
 // lives with) is taken in this round and the rest of the word stays for the next one.
-template <uint32_t C, bool HASHED, bool POW2, typename A>
+template <uint32_t C, bool HASHED, bool POW2, bool COMBOS, typename A>
 __device__ __forceinline__ void cmp_block_bytes(const UcnLevel &lv, A *__restrict__ s_acc, uint32_t *__restrict__ q, uint32_t row_lo,
                                                 uint32_t nrows, uint32_t part, uint32_t split, size_t B,
                                                 const uint8_t *__restrict__ mb, const float *__restrict__ gl,
@@ -1677,8 +1682,14 @@ __device__ __forceinline__ void cmp_block_bytes(const UcnLevel &lv, A *__restric
             float u0[6][3], rs0[6], g0[C], u1[6][3], rs1[6], g1[C];
             cmp_fetch<C, HASHED, POW2, false>(i0, v0, B, gl, geom, u0, rs0, g0, gscale);
             cmp_fetch<C, HASHED, POW2, false>(i1, v1, B, gl, geom, u1, rs1, g1, gscale);
-            if (v0) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
-            if (v1) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+            if (v0) {
+                if constexpr (COMBOS) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
+                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u0[0], rs0[0], g0);
+            }
+            if (v1) {
+                if constexpr (COMBOS) point_scatter_combos<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+                else point_scatter_block<C, HASHED, POW2>(lv, s_acc, row_lo, nrows, u1[0], rs1[0], g1);
+            }
             head += avail;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1987,7 +1998,8 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
 #define UCN_CMP(H, P2, CO, RU) cmp_block<C, H, P2, CO, RU>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale)
 #define UCN_CMPF(H, P2)                                                                                                      \
     do {                                                                                                                     \
-        if (plan.fine_kind[lvl] == 3) cmp_block_bytes<C, H, P2>(lv, acc_rows, q, row_lo, nrows, part, split, B, reinterpret_cast<const uint8_t *>(masks + (size_t)plan.plane[lvl] * B) + (size_t)blk * B, gl, geom, gscale); \
+        if (plan.fine_kind[lvl] == 3) cmp_block_bytes<C, H, P2, true>(lv, acc_rows, q, row_lo, nrows, part, split, B, reinterpret_cast<const uint8_t *>(masks + (size_t)plan.plane[lvl] * B) + (size_t)blk * B, gl, geom, gscale); \
+        else if (plan.fine_kind[lvl] == 4) cmp_block_bytes<C, H, P2, false>(lv, acc_rows, q, row_lo, nrows, part, split, B, reinterpret_cast<const uint8_t *>(masks + (size_t)plan.plane[lvl] * B) + (size_t)blk * B, gl, geom, gscale); \
         else if (plan.fine_kind[lvl] == 2) cmp_block<C, H, P2, false, false, 2>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);      \
         else if (plan.fine_kind[lvl] == 1) cmp_block<C, H, P2, false, false, 1>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale); \
         else cmp_block<C, H, P2, false, false, 0>(lv, acc_rows, q, blk, row_lo, nrows, part, split, B, mp, gl, geom, gscale);           \
@@ -2536,7 +2548,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             tasks += nb * bwd_sample_split(nb);
         }
         MaskPlan plan;
-        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, B, &plan) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) {
+        if (workspace && B < (1ull << 29) && make_mask_plan(lv, rpb, B, &plan, fixed) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) {
             tasks = 0;
             for (uint32_t l = 0; l < lv.L; l++) {
                 const uint32_t nb = ucn_div_up(lv.lv[l].rows, rpb);
