@@ -880,6 +880,20 @@ def field_heads(mlp, feat, viewdirs, N, S):
     return density, rgb * (1 + 2 * mlp.rgb_padding) - mlp.rgb_padding
 
 
+_ZEROS_RO = {}
+
+
+def _zeros_ro(n, k, device):
+    """A cached [n, k] fp32 block of zeros that kernels only READ (never hand it to anything that writes)."""
+    key = (int(n), int(k), str(device))
+    z = _ZEROS_RO.get(key)
+    if z is None:
+        if len(_ZEROS_RO) > 16:
+            _ZEROS_RO.clear()
+        z = _ZEROS_RO[key] = torch.zeros(n, k, device=device)
+    return z
+
+
 class _Composite(torch.autograd.Function):
     """render.py:155-174 + :203-216 as the rendering kernel `ucn_composite` (forward) and `ucn_composite_backward`:
     weights, rgb, depth, acc of N rays from density [N,S] and rgbs [N,S,3]; sample positions carry no gradient."""
@@ -897,6 +911,9 @@ class _Composite(torch.autograd.Function):
                                      None, _lib.stream()))
         ctx.save_for_backward(density, rgbs, sdist, near, far, dirs)
         ctx.consts = (float(bg), int(bool(opaque)))
+        # outputs nobody differentiates (depth and acc always, rgb at a proposal level) arrive as None in backward instead of as
+        # zero tensors autograd fills first: 12 launches per step less (tools/train_launch_sites.py)
+        ctx.set_materialize_grads(False)
         return weights, main[:, :3].contiguous(), main[:, 3].contiguous(), main[:, 4].contiguous()
 
     @staticmethod
@@ -905,13 +922,19 @@ class _Composite(torch.autograd.Function):
         lib = _lib.load()
         density, rgbs, sdist, near, far, dirs = ctx.saved_tensors
         N, S = density.shape
-        g_main = torch.zeros(N, 5, device=density.device)
-        if g_rgb is not None:
-            g_main[:, :3] = g_rgb
-        if g_depth is not None:
-            g_main[:, 3] = g_depth
-        if g_acc is not None:
-            g_main[:, 4] = g_acc
+        if g_w is None and g_rgb is None and g_depth is None and g_acc is None:
+            return None, None, None, None, None, None, None, None
+        if g_depth is None and g_acc is None:
+            # the usual case: one cat against a cached block of zeros (read-only) instead of a fill and up to three strided copies
+            g_main = _zeros_ro(N, 5, density.device) if g_rgb is None else torch.cat([g_rgb.float(), _zeros_ro(N, 2, density.device)], dim=1)
+        else:
+            g_main = torch.zeros(N, 5, device=density.device)
+            if g_rgb is not None:
+                g_main[:, :3] = g_rgb
+            if g_depth is not None:
+                g_main[:, 3] = g_depth
+            if g_acc is not None:
+                g_main[:, 4] = g_acc
         g_w = None if g_w is None else g_w.float().contiguous()
         g_density = torch.empty_like(density)
         g_rgbs = torch.empty_like(rgbs)
