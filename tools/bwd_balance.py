@@ -32,7 +32,7 @@ grad = torch.zeros_like(enc.embeddings)
 fld = mlp.grid_field()
 ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(fld), n, S), device=dev)
 args = (ctypes.byref(fld), sdist.data_ptr(), near.data_ptr(), far.data_ptr(), flat["origins"].data_ptr(), flat["directions"].data_ptr(),
-        basis.data_ptr(), rad.data_ptr(), None, None, 0.5, n, S, 0, 0, feat.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream())
+        basis.data_ptr(), rad.data_ptr(), None, None, 0.5, n, S, 0, (_lib.BWD_FIXED_POINT if os.environ.get('UCN_TOOL_FX') == '1' else 0), feat.data_ptr(), grad.data_ptr(), ws.data_ptr(), _lib.stream())
 for _ in range(3):
     _lib.check(lib.ucn_march_features_backward(*args))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

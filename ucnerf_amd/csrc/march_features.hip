@@ -1006,7 +1006,13 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         if (nb_l > kMaxMaskWords * 32u) return false;                     // (> 512 blocks, e.g. 2^23 rows of C = 4: the atomic fallback)
         // measured per level on the benchmark grid (tools/level_times_bwd.py): sample items + run merging win up to
         // resolution 512, walking consecutive samples in one lane up to 64
-        static const uint32_t coarse_res = getenv("UCN_BWD_COARSE_RES") ? (uint32_t)atoi(getenv("UCN_BWD_COARSE_RES")) : 512u;   // experiment knob
+        // r06, FIXED-POINT rows (the autocast step): a row update is one fire-and-forget ds_add_u64 there, so run merging buys nothing
+        // and the ~8 row blocks a SAMPLE of the hashed levels 84 ... 446 touches each redo all of its 48 corners; as point items on byte
+        // planes those levels cost 44-47 instead of 45-82 ms-CU each (tools/bwd_balance.py under UCN_TOOL_FX=1, whole call 3.54 ->
+        // 3.20 ms; profiles/r06/bwd_coarse_res_fx.txt).  With float rows the same change LOSES (3.71 -> 5.3 ms: compare-and-swap
+        // collisions; bwd_coarse_res_float.txt), so the threshold follows the row type.
+        static const int coarse_res_env = getenv("UCN_BWD_COARSE_RES") ? atoi(getenv("UCN_BWD_COARSE_RES")) : -1;                 // experiment knob
+        const uint32_t coarse_res = coarse_res_env >= 0 ? (uint32_t)coarse_res_env : (fixed_rows ? 64u : 512u);
         mp->coarse[l] = lv.lv[l].resolution <= coarse_res ? 1 : 0;
         if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
         // More than 32 row blocks per level (the reference's own waymo.gin grid: T = 2^21 rows of C = 4 -> 256 blocks of 8192 rows):
@@ -1033,7 +1039,8 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         // where the nibble planes above give it one sample of four blocks (0.84 hits): one load, one popcount and one DPP prefix
         // sum per 4096-sample unit instead of four.  Same number of planes.  UCN_BWD_BYTE_MASKS=0: off; =2: every point-item level
         // (the lane order of its items makes the compare-and-swaps of resolution 1024 / 2048 collide, as with shape 1).
-        static const int byte_masks = getenv("UCN_BWD_BYTE_MASKS") ? atoi(getenv("UCN_BWD_BYTE_MASKS")) : UCN_BWD_BYTE_MASKS_DEFAULT;
+        static const int byte_masks_env = getenv("UCN_BWD_BYTE_MASKS") ? atoi(getenv("UCN_BWD_BYTE_MASKS")) : -1;
+        const int byte_masks = byte_masks_env >= 0 ? byte_masks_env : (fixed_rows ? 2 : UCN_BWD_BYTE_MASKS_DEFAULT);   // fixed-point rows: every point-item level (no compare-and-swap to collide)
         if (!mp->coarse[l] && nb_l <= 32u && B % 4u == 0u && kScan == 4u &&
             ((byte_masks == 1 && mp->fine_kind[l] == 2) || byte_masks == 2 || (byte_masks == 3 && mp->fine_kind[l] == 2)))
             mp->fine_kind[l] = 3;
@@ -2502,12 +2509,19 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     const uint32_t rpb = 128u * 1024u / (lv.C * 4u);
     const size_t B = (size_t)N * S;
     const bool masks = make_mask_plan(lv, rpb, B, &plan);
+    MaskPlan plan_fx;                                                                         // the fixed-point call cuts the levels differently: room for either
+    const bool masks_fx = masks && make_mask_plan(lv, rpb, B, &plan_fx, true);
+    if (masks_fx && plan_fx.n_planes > plan.n_planes) plan.n_planes = plan_fx.n_planes;
     // geometry planes + block-mask planes + a level-major copy of the gradient (layouts 1 and 3)
     uint64_t n = (24ull + (masks ? plan.n_planes + lv.L * lv.C : 0u)) * B + 64u;             // + the task counter
     n += (((uint64_t)lv.L * ucn_div_up(B, 256) + 63u) & ~63ull);                                 // + the 256-sample L1 partials of the fixed-point mode
     ListPlan lp;
+    uint64_t n_lists = 0;
     if (masks && make_list_plan(lv, plan, rpb, B, &lp))      // + the item lists of the fine levels and their control block
-        n += (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
+        n_lists = (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
+    if (masks_fx && make_list_plan(lv, plan_fx, rpb, B, &lp) && (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64 > n_lists)
+        n_lists = (uint64_t)lp.n_fine * (lp.cap + kCtlPerLevel) + 64;
+    n += n_lists;
     return n;
 }
 
