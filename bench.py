@@ -282,6 +282,7 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=40960, per_call=8192
         return rend[-1]["rgb"].reshape(-1, 3)
 
     main_threads = min(ncpu, 32)
+    threads_before = torch.get_num_threads()             # restored below: the GPU legs that follow keep the process default
     torch.set_num_threads(main_threads)
     run(slice(0, 256))                                   # warm-up
     rgb, secs = [], []
@@ -303,6 +304,7 @@ def cpu_baseline(sd, rays_flat, rand_vec, gpu_rgb, n_sample=40960, per_call=8192
             dt = time.perf_counter() - t0
             threads[str(nt)] = dict(rays_per_s=n / dt, chunks=1, rays_per_chunk=n, seconds=dt)
         torch.set_num_threads(main_threads)
+    torch.set_num_threads(threads_before)
     best = max(threads, key=lambda k: threads[k]["rays_per_s"])
     linf = float((rgb - gpu_rgb[idx].cpu()).abs().max())
     mse = float(((rgb - gpu_rgb[idx].cpu()) ** 2).mean())
@@ -735,6 +737,7 @@ def main():
     feat_ms = {0: 0.0, 1: 0.0}; mlp_ms = {0: 0.0, 1: 0.0}; rays_seen = {0: 0, 1: 0}; launches = {0: 0, 1: 0}
     for lvl, n, e0, e1, m0, e2 in prof:
         feat_ms[lvl] += e0.elapsed_time(e1); mlp_ms[lvl] += m0.elapsed_time(e2); rays_seen[lvl] += n; launches[lvl] += 1
+    cpu_leg = None
     if rank == 0:
         lo, hi = udist.shard_bounds(n_rays, world, rank)
         rays_rank = (hi - lo) * args.steps
@@ -870,11 +873,17 @@ def main():
                                          algbw_GBps=exch[0][2] * world / (sum(ms) / len(ms) * 1e-3) / 1e9,
                                          note="HIP events around the frame's one packed all_gather_into_tensor on rank 0 (includes waiting "
                                               "for the slowest rank's shard)")
+        # the CPU leg runs AFTER the training legs when both are on: its 32- and 256-thread passes leave the host busy enough
+        # (thread pools, a changed torch thread count) to show in the launch-heavy training steps that followed it -- r06: 9.37 ms
+        # in the line against 8.7 ms for the same step run alone on the same box (profiles/r06/bench_order_note.txt)
         if world == 1 and not args.no_cpu_baseline:
-            flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
-            res["cpu_baseline"] = cpu_baseline(sd, flat, rand_vec, out["rgb"].reshape(n_rays, 3), heads=args.cfg5,
-                                               eval_camidx=eval_camidx if args.cfg5 else None,
-                                               n_sample=8192 if args.cfg5 else 40960)
+            flat_cpu = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
+            rgb_cpu = out["rgb"].reshape(n_rays, 3).clone()
+            cpu_leg = lambda: cpu_baseline(sd, flat_cpu, rand_vec, rgb_cpu, heads=args.cfg5, eval_camidx=eval_camidx if args.cfg5 else None,
+                                           n_sample=8192 if args.cfg5 else 40960)
+            if args.no_train or args.no_extras or args.cameras != 1 or args.cfg5:
+                res["cpu_baseline"] = cpu_leg()
+                cpu_leg = None
         if world == 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
             flat = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
             # the price of strict fp32 in the headline: the same frame with the exact-fp32 MFMA dense layers (--mlp-mode 0)
@@ -960,6 +969,9 @@ def main():
                     res["fitted_field"] = fitted_field_frames(device, cfg)
                 except Exception as e:                                    # noqa: BLE001 -- reported, never fatal to the line
                     res["fitted_field"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+                if cpu_leg is not None:
+                    res["cpu_baseline"] = cpu_leg()
+                    cpu_leg = None
                 # the other BASELINE configs, one timed frame each, with their own CPU-oracle L-inf
                 res["configs"] = {
                     "configs[3] 5-camera frame, fp32-class": render_config(device, 5, heads=False, autocast=False),
@@ -968,6 +980,8 @@ def main():
                     # not a BASELINE config: one frame on the reference's own waymo.gin grid (L 10, C 4, T 2^21; 128 + 32 samples)
                     "waymo.gin grid, 1 camera, fp32-class": render_config(device, 1, heads=False, autocast=False, grid="R"),
                 }
+    if rank == 0 and world == 1 and cpu_leg is not None:                 # (no path above should leave it pending)
+        res["cpu_baseline"] = cpu_leg()
     if world > 1 and not args.no_train and args.cameras == 1 and not args.cfg5:
         # every rank takes part (collectives in the backward); after the timed render, outside it
         flat_t = {k: v.reshape(n_rays, -1) for k, v in batch.items() if k != "rand_vec"}
