@@ -324,7 +324,28 @@ def test_item_list_backward_is_the_same_adjoint():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UCN_BWD_LISTS="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-k",
-                        "(adjoint or features_backward or train_graph_matches_reference_step) and not item_list",
+                        "(adjoint or features_backward or train_graph_matches_reference_step) and not item_list and not mask_plane_routes",
+                        os.path.join(repo, "tests", "test_full_size.py"), os.path.join(repo, "tests", "test_gpu_parity.py"),
+                        os.path.join(repo, "tests", "test_train_step.py")],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("knobs", [dict(UCN_BWD_BYTE_MASKS="0", UCN_BWD_COARSE_RES="512"), dict(UCN_BWD_BYTE_MASKS="3")],
+                         ids=["r05_plan_nibble_planes", "byte_scan_with_corner_walk"])
+def test_mask_plane_routes_of_the_table_gradient_are_the_same_adjoint(knobs):
+    """r06: the point-item levels of the table gradient read BYTE planes (MaskPlan::fine_kind 3, cmp_block_bytes), and under fixed-point
+    rows the hashed levels of resolution 84 ... 446 are point items as well -- the defaults every other test of this suite runs.  The
+    routes behind the switches (the r05 plan: nibble planes + sample items up to 512; the byte scan with the corner walk, fine_kind 4)
+    must pass the same adjoint / parity / fixed-point / full-size training tests.  The switches are read once per process: a child pytest."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **knobs)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k",
+                        "(adjoint or features_backward or fixed_point or random_grid_shapes or train_graph_matches_reference_step) "
+                        "and not item_list and not mask_plane_routes",
                         os.path.join(repo, "tests", "test_full_size.py"), os.path.join(repo, "tests", "test_gpu_parity.py"),
                         os.path.join(repo, "tests", "test_train_step.py")],
                        capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
