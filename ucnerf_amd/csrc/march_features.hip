@@ -1104,6 +1104,16 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
 template <bool HASHED, bool POW2>
 __device__ __forceinline__ uint32_t point_block_mask(const UcnLevel &lv, uint32_t shift, const float (&p)[3]) {
     if (!in_unit_cube(p[0], p[1], p[2])) return 0u;
+    if constexpr (HASHED && POW2) {
+        // row = (x ^ y P1 ^ z P2) & mask with x <= resolution + 1 < 2^shift: x only reaches the bits BELOW the block index, so the two x
+        // corners of a (y, z) combination share their block and the block follows from y and z alone -- 4 hashes instead of 8 rows, no x
+        if (lv.resolution + 2u <= (1u << shift)) {
+            const uint32_t y0 = (uint32_t)floorf(fmaf(p[1], lv.scale, 0.5f)), z0 = (uint32_t)floorf(fmaf(p[2], lv.scale, 0.5f));
+            const uint32_t ya = y0 * kP1, yb = ya + kP1, za = z0 * kP2, zb = za + kP2;
+            return (1u << (((ya ^ za) & lv.mask) >> shift)) | (1u << (((yb ^ za) & lv.mask) >> shift)) |
+                   (1u << (((ya ^ zb) & lv.mask) >> shift)) | (1u << (((yb ^ zb) & lv.mask) >> shift));
+        }
+    }
     float fx, fy, fz;
     uint32_t rows[8], m = 0u;
     corner_rows<HASHED, POW2>(lv, p[0], p[1], p[2], fx, fy, fz, rows);
@@ -1342,12 +1352,18 @@ __device__ __forceinline__ void point_scatter_combos(const UcnLevel &lv, A *__re
         else return idx < lv.rows ? idx : idx % lv.rows;
     };
     uint32_t pend = 0u;
+    // hashed power-of-two levels whose row block is an aligned power of two above the resolution: x only reaches the bits below
+    // the block index, both x corners of a combination lie in the block of (y P1 ^ z P2) -- one test per combination (wave-uniform switch)
+    bool yz_decides = false;
+    if constexpr (HASHED && POW2) yz_decides = (nrows & (nrows - 1u)) == 0u && (row_lo & (nrows - 1u)) == 0u && lv.resolution + 2u <= nrows;
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++) {
         const uint32_t yv = (c & 1u) ? yb : ya, zv = (c & 2u) ? zb : za;
         uint32_t yz;
         if constexpr (HASHED) yz = yv ^ zv; else yz = yv + zv;
-        const bool hit = (row_of(xa, yz) - row_lo < nrows) || (row_of(xb, yz) - row_lo < nrows);
+        bool hit;
+        if (yz_decides) hit = (yz & lv.mask) - row_lo < nrows;
+        else hit = (row_of(xa, yz) - row_lo < nrows) || (row_of(xb, yz) - row_lo < nrows);
         pend |= hit ? 1u << c : 0u;
     }
     const float damp = erf_pos(rsj * lv.inv_gs);
