@@ -41,24 +41,43 @@ for case in range(n_cases):
     grad[:, torch.rand(N * S, device=dev, generator=g) < 0.2] = 0.0
     ws = torch.empty(max(1, lib.ucn_march_features_backward_ws_floats(ctypes.byref(d), N, S)), device=dev)
 
-    def run(lpb, work):
+    def run(lpb, work, flags=0):
         out = torch.zeros_like(enc.embeddings)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(d), sdist.data_ptr(), near.data_ptr(), far.data_ptr(), origins.contiguous().data_ptr(),
-                                                   dirs.contiguous().data_ptr(), basis.data_ptr(), radii.data_ptr(), None, None, 0.5, N, S, lpb, 0,
+                                                   dirs.contiguous().data_ptr(), basis.data_ptr(), radii.data_ptr(), None, None, 0.5, N, S, lpb, flags,
                                                    grad.data_ptr(), out.data_ptr(), _lib.ptr(work), _lib.stream()))
         torch.cuda.synchronize()
         return out
     want = run(1, None)
     got = run(0, ws)
-    tol = 3e-5 * max(float(want.abs().max()), 1e-30)
-    err = float((got - want).abs().max())
+    # a level whose resolution^2 wraps negative in int32 has a NaN damping factor in the reference too (models.py:495: sqrt of the wrapped
+    # int32 square; grid_op.hip keeps that): such rows must be non-finite on BOTH routes, the rest is compared
+    fin = torch.ones_like(want, dtype=torch.bool)
+    nan_levels = []
+    for l in range(L):
+        r = np.int64(enc._sizes_np[l])
+        if np.int32(np.uint32((r * r) & 0xFFFFFFFF)) < 0:                       # what torch's int32 square holds (models.py:495)
+            fin[int(enc._offsets_np[l]):int(enc._offsets_np[l + 1])] = False
+            nan_levels.append(l)
+    same_pattern = bool(torch.isfinite(got)[fin].all()) and bool(torch.isfinite(want)[fin].all())
+    big = max(float(want[fin].abs().max()) if bool(fin.any()) else 0.0, 1e-30)
+    tol = 3e-5 * big
+    err = (float((got - want)[fin].abs().max()) if bool(fin.any()) else 0.0) if same_pattern else float("inf")
     rows = [int(enc._offsets_np[l + 1] - enc._offsets_np[l]) for l in range(L)]
     rpb = 128 * 1024 // (C * 4)
     tag = f"case {case:3d}: L {L:2d} C {C} T 2^{T} base {base} desired {desired} N {N} S {S}  max blocks/level {max((r + rpb - 1) // rpb for r in rows):4d}"
-    if not err <= tol or not torch.isfinite(got).all():
+    # r06: the FIXED-POINT row blocks (the autocast step's route: its own cut between sample and point items, byte planes everywhere).
+    # Resolution 2^-30 ... 2^-29 of a task's summed |g| per addend: held to 1e-3 of the largest entry
+    err_fx = 0.0
+    if C % 2 == 0:
+        got_fx = run(0, ws, _lib.BWD_FIXED_POINT)
+        err_fx = (float((got_fx - want)[fin].abs().max()) if bool(fin.any()) else 0.0) if bool(torch.isfinite(got_fx)[fin].all()) else float("inf")
+    tol_fx = 1e-3 * big
+    if not err <= tol or not err_fx <= tol_fx:
         bad += 1
-        print("MISMATCH", tag, err, tol)
+        print("MISMATCH", tag, err, tol, err_fx, tol_fx, "non-finite entries: atomic kernel", int((~torch.isfinite(want)).sum()),
+              "row blocks", int((~torch.isfinite(got)).sum()), "resolutions", [int(r) for r in enc._sizes_np[:L]] if hasattr(enc, "_sizes_np") else "")
     else:
-        print("ok      ", tag, f"err {err:.2e} of {float(want.abs().max()):.2e}")
+        print("ok      ", tag, f"err {err:.2e} (fixed-point rows {err_fx:.2e}) of {big:.2e}" + ("" if not nan_levels else f"  [levels {nan_levels}: NaN damping in the reference too, not compared]"))
 print("fuzz done, mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -2007,14 +2007,17 @@ __global__ __launch_bounds__(1024) void k_march_features_bwd_cmp(UcnLevels lvls,
             for (uint32_t w = 0; w < 16u; w++) l1 += s_red[w];                     // fixed order, every thread the same value
             __syncthreads();                                                       // before the rings are used again
             l1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l1)));
-            if (l1 > 0.0f && l1 <= 3.0e38f) {
+            // (a level whose resolution^2 wrapped negative in int32 has a NaN damping factor, models.py:495: NaN rows in the reference and on
+            // the float route -- a NaN addend would pack as 0 here, so the task is poisoned like one with a non-finite gradient)
+            const bool nan_level = lv.inv_gs != lv.inv_gs;
+            if (!nan_level && l1 > 0.0f && l1 <= 3.0e38f) {
                 int x;
                 (void)frexpf(l1, &x);                                              // l1 = m 2^x, m in [0.5, 1): l1 <= 2^x
                 int e = 30 - x;
                 e = e > 120 ? 120 : (e < -100 ? -100 : e);                          // x <= 128 (l1 <= 3e38): e >= -98, never clamped from below
                 gscale = ldexpf(1.0f, e);
                 ginv = ldexpf(1.0f, -e);
-            } else if (!(l1 <= 3.0e38f)) {
+            } else if (nan_level || !(l1 <= 3.0e38f)) {
                 ginv = __builtin_nanf("");                                         // a non-finite gradient on this level: every row of the task's block becomes NaN (flush below)
             }
         }
