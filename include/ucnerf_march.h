@@ -175,7 +175,9 @@ int ucn_march_features(const ucn_field_t *f, const float *sdist /*[N,S+1]*/, con
  * table has <= 64 blocks of 128 KiB per level, else the atomic scatter; >= 1 forces the atomic scatter.
  * sample_major: 0 = grad_features [num_levels][N*S][level_dim], 1 = [N*S][num_levels*level_dim] (what autograd
  * hands to grid.py:68), 3 = [num_levels*level_dim][N*S] (the output of a transposed dgrad GEMM; row-block
- * algorithms only). */
+ * algorithms only), 4 (ABI 26) = layout 0 with every value ALREADY divided by 6 (ucn_train_bwd with UCN_GFEAT_LEVEL_MAJOR wrote it):
+ * the row-block kernel reads it in place -- no level-major copy, no division in the mask pass; needs a workspace, refused where the
+ * call would fall back to the atomic kernels. */
 int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                 const float *origins, const float *directions, const float *basis,
                                 const float *radii, const float *flip, const float *spin, float std_scale,
@@ -188,6 +190,9 @@ int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const 
                                                    cannot compact its work (several times slower)*/,
                                 ucn_stream_t stream);
 uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, uint32_t N, uint32_t S);
+/* ABI 26: 1 if that call (levels_per_block = 0, with its workspace) runs the compacted row-block kernel -- the only route that accepts
+ * sample_major = 4; 0 where it would fall back (more than 512 row blocks per level, >= 2^29 samples). */
+int ucn_march_features_backward_row_blocks(const ucn_field_t *f, uint32_t N, uint32_t S);
 
 /* Introspection of the fused featurisation's geometry stage (the parity tests of SURVEY 8 rows a5 / a6; not on the
  * rendering path): the six multisample Gaussians of every sample exactly as ucn_march_features derives them
@@ -357,7 +362,10 @@ int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float
  * masks ucn_train_fwd wrote.  With head (the same HOST float[4]) gy / graw are the fp32 gradients of rgb [M,3] /
  * density [M] and the activation derivatives are taken from the forward's outputs `density`, `rgb`.
  * Outputs: the pre-activation gradients the weight-gradient GEMMs need, d1, d0, gx
- * [M,256] and gh0 [M,64] as bf16, and the feature gradient gfeat [M,F] fp32. */
+ * [M,256] and gh0 [M,64] as bf16, and the feature gradient gfeat [M,F] fp32.  F | UCN_GFEAT_LEVEL_MAJOR (ABI 26, F % 4 == 0, features in
+ * pairs of level_dim 2): gfeat is written as [F / 2][M][2] with every value divided by 6 -- ucn_march_features_backward's layout 4, which
+ * then neither copies nor divides it. */
+#define UCN_GFEAT_LEVEL_MAJOR 0x10000
 int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
                   const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S,
                   uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M, dy_ld] bf16 | NULL: the colour-logit

@@ -11,10 +11,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UCN_LIB_PATH: an experiment build of the same ABI (tools/build_variant.sh) for A/B measurements; default = the in-tree product
 LIB_PATH = os.environ.get("UCN_LIB_PATH") or os.path.join(_HERE, "csrc", "libucnerf_march.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 RAYS_INCOHERENT = 0x1000   # ucn_march_features layout flag: random (training) rays -> lane-paired fetch on every hashed level
+GFEAT_LEVEL_MAJOR = 0x10000  # ucn_train_bwd F flag: gfeat as [F / 2][M][2], / 6 = ucn_march_features_backward's layout 4 (include/ucnerf_march.h)
 BWD_FIXED_POINT = 0x800    # ucn_march_features_backward layout flag: int32 fixed-point row blocks (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)
 FEAT_BF16 = 0x100          # ucn_train_fwd feat_level_dim flag: the features are those pairs          # include/ucnerf_march.h UCN_LAUNCH_CORESIDENT
@@ -76,6 +77,7 @@ SIGNATURES = {
     "ucn_march_features_backward": [ctypes.POINTER(UcnField), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_f32, c_u32, c_u32, c_u32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "ucn_march_features_backward_ws_floats": [ctypes.POINTER(UcnField), c_u32, c_u32],
+    "ucn_march_features_backward_row_blocks": [ctypes.POINTER(UcnField), c_u32, c_u32],
     "ucn_cast_probe": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_u32, c_vp, c_vp],
     "ucn_contract_probe": [c_vp, c_vp, c_u32, c_vp, c_vp, c_vp],
     "ucn_points_features": [ctypes.POINTER(UcnField), c_vp, c_vp, c_u32, c_u32, c_i32, c_u32, c_vp, c_vp, c_vp],

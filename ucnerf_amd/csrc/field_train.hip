@@ -364,8 +364,9 @@ struct TrainBwdArgs {
     uint16_t *d1, *d0, *gx, *gh0;     // bf16 [M,256] x3, [M,64]
     uint16_t *dy;                     // bf16 [M, ld_dy] | NULL: the colour-logit gradient this kernel consumed (columns 0..2), column 3 = the density head's
     uint32_t ld_dy;                   // row stride of dy in elements (4, or 32: a zero-padded tile that ucn_wgrad_bf16 takes as its A operand)
-    float *gfeat;                     // [M, F]
+    float *gfeat;                     // [M, F]; lm: [F / 2][M][2], every value / 6
     uint32_t M, F;
+    uint32_t lm;                      // 1: the feature gradient as ucn_march_features_backward's layout 4 wants it (r06, VERDICT r05 item 2 c)
 };
 
 
@@ -511,7 +512,16 @@ __global__ __launch_bounds__(64 * kTrainWaves, kTrainWaves == 8 ? 1 : UCN_TRAIN_
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t f0 = 32u * ft + 8u * q + 4u * h;            // features f0 .. f0 + 3 = registers 4q .. 4q + 3
-                if (f0 + 3 < a.F && a.F % 4 == 0) {
+                if (a.lm) {
+                    // level-major pairs (level_dim 2: features 2 l, 2 l + 1 = level l), divided by the 6 multisamples of the mean with the
+                    // same IEEE division the mask pass of the table gradient applied to this layout's row-major form: 32 lanes = 32
+                    // consecutive samples = 256 contiguous bytes per level
+                    if (f0 + 3 < a.F) {
+                        float2 *o = reinterpret_cast<float2 *>(a.gfeat);
+                        o[(size_t)(f0 / 2u) * a.M + sample] = make_float2(gf[ft][4 * q] / 6.0f, gf[ft][4 * q + 1] / 6.0f);
+                        o[(size_t)(f0 / 2u + 1u) * a.M + sample] = make_float2(gf[ft][4 * q + 2] / 6.0f, gf[ft][4 * q + 3] / 6.0f);
+                    }
+                } else if (f0 + 3 < a.F && a.F % 4 == 0) {
                     *reinterpret_cast<float4 *>(a.gfeat + (size_t)sample * a.F + f0) =
                         make_float4(gf[ft][4 * q], gf[ft][4 * q + 1], gf[ft][4 * q + 2], gf[ft][4 * q + 3]);
                 } else {
@@ -579,12 +589,15 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gh0 && gfeat, "train_bwd: null pointer argument");
+    const uint32_t lm = (F & UCN_GFEAT_LEVEL_MAJOR) ? 1u : 0u;
+    F &= ~(uint32_t)UCN_GFEAT_LEVEL_MAJOR;
     UCN_REQUIRE(F >= 1 && F <= 64, "train_bwd: 1..64 input features, got %u", F);
+    UCN_REQUIRE(!lm || F % 4u == 0u, "train_bwd: the level-major feature gradient needs F %% 4 == 0 (pairs of level_dim 2), got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");
     UCN_REQUIRE(!head || (density && rgb), "train_bwd: head mode needs the forward's density and rgb");
     TrainBwdArgs a{gy, graw, head != nullptr, density, rgb, head ? head[1] : 1.0f, head ? head[3] : 0.0f, (const uint4 *)packed_t, m0,
                    (const uint4 *)m1, (const uint4 *)m2,
-                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F};
+                   (uint16_t *)d1, (uint16_t *)d0, (uint16_t *)gx, (uint16_t *)gh0, (uint16_t *)dy, dy_ld ? dy_ld : 4u, gfeat, (uint32_t)M, F, lm};
     if (F <= 32) hipLaunchKernelGGL(k_train_bwd<1>, dim3(ucn_div_up(M, 32 * kTrainWaves)), dim3(64 * kTrainWaves), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_train_bwd<2>, dim3(ucn_div_up(M, 32 * kTrainWaves)), dim3(64 * kTrainWaves), kFtSlots * kTChunk * 1024 + kStageBytes, (hipStream_t)stream, a);
     UCN_LAUNCH_CHECK("train_bwd");

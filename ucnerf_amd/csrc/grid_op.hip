@@ -24,7 +24,7 @@ int ucn_fail(const char *fmt, ...) {
 }
 
 extern "C" const char *ucn_last_error(void) { return g_ucn_err; }
-extern "C" uint32_t ucn_abi_version(void) { return 25; }
+extern "C" uint32_t ucn_abi_version(void) { return 26; }
 
 int ucn_build_levels(UcnLevels *out, const int32_t *offsets, const int32_t *grid_sizes, uint32_t L, uint32_t C,
                      uint32_t D, float S, uint32_t H, uint32_t gridtype, int align_corners) {

@@ -1170,8 +1170,9 @@ __global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInp
             // the row-block workgroups fetch gradients per ITEM (scattered): give them 8 contiguous bytes per sample,
             // already divided by the 6 multisamples of the mean (an IEEE division is ~13 VALU instructions per channel;
             // an item stage would repeat it ~27 times per sample and level)
-            if (valid) grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
+            if (valid && grad_level_major) grad_level_major[((size_t)lvl * B + b) * C + c] = g / 6.0f;
         }
+        if (!grad_level_major) gmax *= 6.0f;                // layout 4: g arrived divided by 6 -- the bound is on the undivided gradient (6 addends of <= |g| / 6 x w)
 #ifndef UCN_EXP_MASKS_NO_GRAD
         if (l1_partial) {                                   // (workgroup-uniform; every wave of the block gets here: no early `continue` above)
 #else
@@ -2544,6 +2545,17 @@ extern "C" uint64_t ucn_march_features_backward_ws_floats(const ucn_field_t *f, 
     return n;
 }
 
+// 1 if ucn_march_features_backward(levels_per_block = 0, with a workspace) takes the compacted row-block kernel for this field and call
+// size -- the route that reads a layout-4 gradient (its launcher below applies the same test)
+extern "C" int ucn_march_features_backward_row_blocks(const ucn_field_t *f, uint32_t N, uint32_t S) {
+    UcnLevels lv;
+    if (field_levels(f, &lv)) return 0;
+    const size_t B = (size_t)N * S;
+    const uint32_t rpb = 128u * 1024u / (lv.C * 4u);
+    MaskPlan plan;
+    return (B > 0 && B < (1ull << 29) && B <= 0xFFFFFF00ull && make_mask_plan(lv, rpb, B, &plan) && !(plan_has_wide(lv, plan) && B >= (1ull << 24))) ? 1 : 0;
+}
+
 extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sdist, const float *near_, const float *far_,
                                            const float *origins, const float *directions, const float *basis,
                                            const float *radii, const float *flip, const float *spin, float std_scale,
@@ -2555,7 +2567,9 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
     UCN_REQUIRE((flip == nullptr) == (spin == nullptr), "march_features_backward: flip and spin come together");
     const bool want_fixed = (layout & UCN_BWD_FIXED_POINT) != 0;
     layout &= ~UCN_BWD_FIXED_POINT;
-    UCN_REQUIRE(layout == 0 || layout == 1 || layout == 3, "march_features_backward: layout must be 0, 1 or 3");
+    const bool prediv = layout == 4;                     // level-major and already / 6: read in place
+    if (prediv) layout = 0;
+    UCN_REQUIRE(layout == 0 || layout == 1 || layout == 3, "march_features_backward: layout must be 0, 1, 3 or 4");
     UcnLevels lv;
     if (int rc = field_levels(f, &lv)) return rc;
     if (N == 0) return 0;
@@ -2593,8 +2607,8 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             uint32_t *task_counter = reinterpret_cast<uint32_t *>(workspace + (24ull + plan.n_planes + (size_t)lv.L * lv.C) * B);
             float *l1_partial = reinterpret_cast<float *>(task_counter + 64);                   // [L][ceil(B / 256)] (fixed-point mode)
             hipLaunchKernelGGL(k_cast_cache_masks, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, lv, in, hx, std_scale, N, S, plan,
-                               grad_features, gs, lv.C, workspace, masks, glm, task_counter, fixed ? l1_partial : nullptr);
-            const float *glv = glm;                                                             // [L][B][C]
+                               grad_features, gs, lv.C, workspace, masks, prediv ? nullptr : glm, task_counter, fixed ? l1_partial : nullptr);
+            const float *glv = prediv ? grad_features : glm;                                    // [L][B][C], / 6
             const uint32_t cus = device_cu_count();
             ListPlan lp;
             const bool lists = bwd_lists_enabled() && make_list_plan(lv, plan, rpb, B, &lp);
@@ -2642,6 +2656,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
             UCN_LAUNCH_CHECK("march_features_backward (row blocks, compacted)");
             return 0;
         }
+        UCN_REQUIRE(!prediv, "march_features_backward: layout 4 (pre-divided level-major gradient) is the compacted row-block kernel's input; this call would take a fallback");
         if (blocks <= 64u * lv.L) {
             if (workspace)
                 hipLaunchKernelGGL(k_cast_cache, dim3(ucn_div_up(B, 256)), dim3(256), 0, st, in, hx, std_scale, N, S, workspace);
@@ -2661,6 +2676,7 @@ extern "C" int ucn_march_features_backward(const ucn_field_t *f, const float *sd
         levels_per_block = 1;
     }
     UCN_REQUIRE(layout != 3, "march_features_backward: layout 3 is a row-block layout (levels_per_block = 0, <= 64 blocks per level)");
+    UCN_REQUIRE(!prediv, "march_features_backward: layout 4 is a row-block layout (levels_per_block = 0 with a workspace)");
     const dim3 grid(ucn_div_up(B, 256), ucn_div_up(lv.L, levels_per_block));
 #define UCN_MB(CC)                                                                                                  \
     hipLaunchKernelGGL(k_march_features_bwd<CC>, grid, dim3(256), 0, st, lv, grad_embeddings, in, hx, std_scale, N, \

@@ -28,15 +28,25 @@ from . import dense_f32
 EPS = float(torch.finfo(torch.float32).eps)
 
 
+class _GradChannel:
+    """What the featurisation node and the ONE consumer of its features agree on about the feature gradient's layout (r06).  A plain object,
+    not a dict: torch.amp.custom_fwd(cast_inputs=...) rebuilds every container argument, a dict would arrive as a copy."""
+    __slots__ = ("feat_ptr", "levels", "level_dim", "lm")
+
+    def __init__(self):
+        self.feat_ptr = self.levels = self.level_dim = self.lm = None
+
+
 class _FieldFeatures(torch.autograd.Function):
     """features[N*S, L*C] = HIP featurisation of one level; backward scatters into the table gradient."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb, half_table=False):
+    def forward(ctx, embeddings, mlp, geom, N, S, std_scale, lpb, half_table=False, chan=None):
         lib = _lib.load()
         desc = mlp.grid_field()
         L, C = mlp.encoder.num_levels, mlp.encoder.level_dim
+        ctx.chan = chan
         layout = 1 | _lib.RAYS_INCOHERENT               # a training batch is random rays (datasets.py:278): see include/ucnerf_march.h
         if half_table:
             # gridencoder/grid.py:41-44: under autocast (and C even) the reference gathers `embeddings.to(torch.half)`.
@@ -57,6 +67,13 @@ class _FieldFeatures(torch.autograd.Function):
         # independent, one LDS add per channel pair); the fp32 step keeps exact fp32 adds (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
         ctx.fixed = bool(half_table) and bool(getattr(mlp, 'bwd_fixed_point', True))
         ctx.mark_non_differentiable(coord, tmean)
+        if chan is not None:
+            # r06 (VERDICT r05 item 2 c): tell the node that consumes `feat` -- and nothing else does, see field_level -- that its feature
+            # gradient may come back LEVEL-MAJOR and already divided by 6 (ucn_march_features_backward's layout 4: no copy, no division in
+            # the mask pass), if the table gradient of this call runs on the row-block kernel
+            chan.feat_ptr = chan.lm = None
+            if C == 2 and lib.ucn_march_features_backward_row_blocks(ctypes.byref(mlp.grid_field()), N, S) == 1:
+                chan.feat_ptr, chan.levels, chan.level_dim = feat.data_ptr(), L, C
         return feat, coord, tmean
 
     @staticmethod
@@ -71,16 +88,26 @@ class _FieldFeatures(torch.autograd.Function):
         # transposed view of [L*C][N*S] (_TallLinear grad_t; measured no faster than layout 1), layout 3 -- no
         # permuted level-major copy
         B = N * S
-        g = g_feat if g_feat.dtype == torch.float32 else g_feat.float()
-        if g.dim() == 2 and g.stride() == (1, B):
-            layout = 3
+        lm_ptr = None
+        if ctx.chan is not None:
+            lm_ptr, ctx.chan.lm = ctx.chan.lm, None
+        if lm_ptr is not None:
+            # the consumer wrote [L][B][C] / 6 into this very buffer: anything else arriving here (a sum with another consumer's gradient,
+            # a cast) would be read in the wrong layout -- fail loudly
+            if g_feat.data_ptr() != lm_ptr or g_feat.dtype != torch.float32 or not g_feat.is_contiguous():
+                raise RuntimeError("_FieldFeatures.backward: a level-major feature gradient was announced but another tensor arrived")
+            g, layout = g_feat, 4
         else:
-            g, layout = g.contiguous(), 1
+            g = g_feat if g_feat.dtype == torch.float32 else g_feat.float()
+            if g.dim() == 2 and g.stride() == (1, B):
+                layout = 3
+            else:
+                g, layout = g.contiguous(), 1
         ws = torch.empty(lib.ucn_march_features_backward_ws_floats(ctypes.byref(mlp.grid_field()), N, S), device=g.device)
         _lib.check(lib.ucn_march_features_backward(ctypes.byref(mlp.grid_field()), *[_lib.ptr(t) for t in ctx.geom], std_scale,
                                                    N, S, 0, layout | (_lib.BWD_FIXED_POINT if ctx.fixed else 0), g.data_ptr(), grad.data_ptr(),
                                                    ws.data_ptr(), _lib.stream()))
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
 class GradientScaler(torch.autograd.Function):
@@ -638,8 +665,12 @@ class _FusedHeads(torch.autograd.Function):
     copies, both fragment streams, accumulator-order biases) is one cat + one cast + one gather per step."""
 
     @staticmethod
-    def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S, head):
+    def forward(ctx, feat, enc, Wd0, bd0, Wd1, bd1, W0, b0, W1, b1, Wr, br, N, S, head, chan=None):
         lib = _lib.load()
+        # the feature gradient goes back level-major (see _FieldFeatures) when `feat` is that node's own output buffer
+        ctx.chan = chan if (chan is not None and chan.feat_ptr == feat.data_ptr() and feat.dtype == torch.float32 and feat.is_contiguous()
+                            and feat.shape[1] == chan.levels * chan.level_dim and feat.shape[1] % 4 == 0
+                            and os.environ.get("UCN_FEAT_GRAD_LM", "1") == "1") else None
         dev, dt = feat.device, torch.bfloat16
         NB, NW, F_in = Wd1.shape[0], W0.shape[0], Wd0.shape[1]
         E = W0.shape[1] - NB
@@ -697,9 +728,12 @@ class _FusedHeads(torch.autograd.Function):
             # 32-wide tile, the A operand of ucn_wgrad_bf16 (the rgb layer's and the bottleneck row's weight gradients without a library GEMM)
             dy = torch.zeros(M, 32 if lean else 4, device=dev, dtype=dt)
             gfeat = torch.empty(M, F_in, device=dev)
+            lm = ctx.chan is not None and f_dt == torch.float32
+            if lm:
+                ctx.chan.lm = gfeat.data_ptr()                        # the same bytes as [F_in / 2][M][2], every value / 6
             hd = (ctypes.c_float * 4)(*head)
             _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
-                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in,
+                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in | (_lib.GFEAT_LEVEL_MAJOR if lm else 0),
                                          d1.data_ptr(), d0.data_ptr(), _lib.ptr(gx), gh0.data_ptr(), dy.data_ptr(), dy.shape[1], gfeat.data_ptr(),
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
@@ -758,7 +792,7 @@ class _FusedHeads(torch.autograd.Function):
                 gWr, gbr = Gr[:3], _colsum(dy)[:3]
                 gWd0, gbd0 = _wgrad_cols(gh0, act, _ACT_FB, _ACT_FB + F_in), _colsum(gh0)
         return (gfeat.to(f_dt), None, gWd0.to(w_dt), gbd0.to(b_dt), gWd1.to(w_dt), gbd1.to(b_dt), gW0.to(w_dt), gb0.to(b_dt),
-                gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None)
+                gW1.to(w_dt), gb1.to(b_dt), gWr.to(w_dt), gbr.to(b_dt), None, None, None, None)
 
 
 class _PropHeads(torch.autograd.Function):
@@ -809,7 +843,7 @@ def _fusable_heads(mlp, feat):
             and mlp.net_width_viewdirs == 256 and mlp.rgb_layer.out_features == 3)
 
 
-def field_heads(mlp, feat, viewdirs, N, S):
+def field_heads(mlp, feat, viewdirs, N, S, chan=None):
     """models.py:507-674 on [N*S, F] features: density MLP, softplus, colour MLP (torch GEMMs).
 
     The reference concatenates [bottleneck, dir_enc] (and [h, bottleneck, dir_enc] after the skip layer) per SAMPLE
@@ -821,7 +855,7 @@ def field_heads(mlp, feat, viewdirs, N, S):
         d0, d1, l0, l1, lr = mlp.density_layer[0], mlp.density_layer[2], mlp.lin_second_stage_0, mlp.lin_second_stage_1, mlp.rgb_layer
         density, rgb = _FusedHeads.apply(feat, view_encoding(viewdirs, mlp.deg_view), d0.weight, d0.bias, d1.weight, d1.bias,
                                          l0.weight, l0.bias, l1.weight, l1.bias, lr.weight, lr.bias, N, S,
-                                         (mlp.density_bias, mlp.rgb_premultiplier, mlp.rgb_bias, mlp.rgb_padding))
+                                         (mlp.density_bias, mlp.rgb_premultiplier, mlp.rgb_bias, mlp.rgb_padding), chan)
         return density.reshape(N, S), rgb.reshape(N, S, 3)
     if _fusable_prop(mlp, feat) and os.environ.get("UCN_FUSED_HEADS", "1") == "1":
         l0, l1 = mlp.density_layer[0], mlp.density_layer[2]
@@ -1395,9 +1429,10 @@ def march_train(model, rand, batch, train_frac, compute_extras, eval_camidx):
         _lib.check(lib.ucn_cone_basis(cam.data_ptr(), rvec.data_ptr(), N, basis.data_ptr(), st))
         geom = (sdist, near, far, o, d, basis, rad, flip, spin)
         half_table = torch.is_autocast_enabled() and mlp.encoder.level_dim % 2 == 0 and getattr(model, 'autocast_half_tables', True)
+        chan = _GradChannel()                        # `feat` has exactly one consumer, the heads below: the two nodes may agree on its gradient's layout
         feat, coord, tmean = _FieldFeatures.apply(mlp.encoder.embeddings, mlp, geom, N, S, model.std_scale,
-                                                  model.levels_per_block, half_table)
-        density, rgbs = field_heads(mlp, feat, vd, N, S)
+                                                  model.levels_per_block, half_table, chan)
+        density, rgbs = field_heads(mlp, feat, vd, N, S, chan)
         if getattr(cfg, 'brightness_correction', False):              # models.py:233-235 (gated on this flag)
             rgbs, density = GradientScaler.apply(rgbs, density, tmean)
         weights, c_rgb, c_depth, c_acc = _Composite.apply(density, rgbs, sdist, near, far, d,
