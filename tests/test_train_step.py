@@ -1050,6 +1050,74 @@ def _graph_node_names(t):
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+def test_level_major_feature_gradient_is_the_row_major_one(monkeypatch):
+    """r06 (VERDICT r05 item 2 c, ABI 26): under bf16 autocast the NeRF field's feature gradient leaves `ucn_train_bwd` LEVEL-MAJOR and already
+    divided by 6 (`UCN_GFEAT_LEVEL_MAJOR`) and `ucn_march_features_backward` reads it in place (layout 4) -- same divisions, same addends as the
+    row-major hand-over behind `UCN_FEAT_GRAD_LM=0`, which copied and divided in its mask pass.  One backward on each route, pinned draws:
+    (i) the default route really is layout 4 for the NeRF level and row-major for the proposal level (its producer is another kernel),
+    (ii) every gradient agrees to the float-atomic noise of the `split` parts meeting in the table (1e-6 of the largest entry; the dense
+    parameters see the identical kernels and must be EQUAL), (iii) a foreign tensor arriving where the level-major buffer was announced raises."""
+    import bench
+    from ucnerf_amd import _lib
+    from ucnerf_amd.internal import train_graph as tg
+    dev = torch.device("cuda", 0)
+    model, _, _ = bench.build_model(dev)
+    model.train()
+    n = 2048
+    rays = {k: v.to(dev) for k, v in rm.synthetic_rays(n, seed=15).items()}
+    g = torch.Generator(device=dev).manual_seed(16)
+    batch = {k: v[:, None, None, :] for k, v in rays.items()}
+    batch['rand_vec'] = torch.randn(n, 6, device=dev, generator=g)
+    batch['march_noise'] = [dict(jitter=torch.rand(n, 1, device=dev, generator=g), flip=torch.rand(n, S, device=dev, generator=g),
+                                 spin=torch.rand(n, S, device=dev, generator=g)) for S in (64, 128)]
+    target = torch.rand(n, 3, device=dev, generator=g)
+    layouts = []
+    lib = _lib.load()
+    real = lib.ucn_march_features_backward
+
+    class Spy:
+        def __call__(self, *a):
+            layouts.append(int(a[14]) & 0xFF)
+            return real(*a)
+    monkeypatch.setattr(lib, "ucn_march_features_backward", Spy())
+
+    def grads(lm):
+        monkeypatch.setenv("UCN_FEAT_GRAD_LM", "1" if lm else "0")
+        model.zero_grad(set_to_none=True)
+        del layouts[:]
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            rend, hist = model(True, batch, 0.5, False, zero_glo=False)
+        loss = ((rend[-1]['rgb'].reshape(n, 3).float() - target) ** 2).mean() + 0.01 * hist[0]['weights'].float().square().mean()
+        loss.backward()
+        return list(layouts), {k: p.grad.float().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    lay1, g1 = grads(True)
+    lay0, g0 = grads(False)
+    assert sorted(lay1) == [1, 4] and sorted(lay0) == [1, 1], (lay1, lay0)            # NeRF level: in place; proposal level: row-major
+    assert g1.keys() == g0.keys() and len(g1) > 10
+    for k in g1:
+        big = float(g0[k].abs().max())
+        assert big > 0 and torch.isfinite(g1[k]).all(), k
+        if "embeddings" in k:
+            assert float((g1[k] - g0[k]).abs().max()) <= 1e-6 * big, (k, float((g1[k] - g0[k]).abs().max()), big)
+        else:
+            assert torch.equal(g1[k], g0[k]), k
+    # (iii) the announced buffer is the only thing the featurisation's backward accepts as level-major
+    monkeypatch.setenv("UCN_FEAT_GRAD_LM", "1")
+    orig = tg._FusedHeads.backward
+
+    def foreign(ctx, *gs):
+        out = orig(ctx, *gs)
+        return (out[0].clone(),) + tuple(out[1:])                                        # same values, another buffer
+    monkeypatch.setattr(tg._FusedHeads, "backward", staticmethod(foreign))
+    model.zero_grad(set_to_none=True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        rend, hist = model(True, batch, 0.5, False, zero_glo=False)
+    with pytest.raises(RuntimeError, match="level-major feature gradient was announced"):
+        ((rend[-1]['rgb'].reshape(n, 3).float() - target) ** 2).mean().backward()
+
+
 def test_fused_heads_tail_engages_under_bf16_autocast():
     """under train.py:165's autocast the colour-correction Linear layers return bf16 affine maps; the fused tail
     (`_AffineBlend`, `_IdentityLoss`) must still be the route taken (the maps are upcast exactly), and equal the eager tail."""
