@@ -1050,7 +1050,6 @@ def _graph_node_names(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
 def test_level_major_feature_gradient_is_the_row_major_one(monkeypatch):
     """r06 (VERDICT r05 item 2 c, ABI 26): under bf16 autocast the NeRF field's feature gradient leaves `ucn_train_bwd` LEVEL-MAJOR and already
     divided by 6 (`UCN_GFEAT_LEVEL_MAJOR`) and `ucn_march_features_backward` reads it in place (layout 4) -- same divisions, same addends as the
@@ -1118,6 +1117,7 @@ def test_level_major_feature_gradient_is_the_row_major_one(monkeypatch):
         ((rend[-1]['rgb'].reshape(n, 3).float() - target) ** 2).mean().backward()
 
 
+@pytest.mark.gpu
 def test_fused_heads_tail_engages_under_bf16_autocast():
     """under train.py:165's autocast the colour-correction Linear layers return bf16 affine maps; the fused tail
     (`_AffineBlend`, `_IdentityLoss`) must still be the route taken (the maps are upcast exactly), and equal the eager tail."""
