@@ -366,6 +366,8 @@ int ucn_train_fwd(const float *feat, uint32_t F, const void *packed, const float
  * pairs of level_dim 2): gfeat is written as [F / 2][M][2] with every value divided by 6 -- ucn_march_features_backward's layout 4, which
  * then neither copies nor divides it. */
 #define UCN_GFEAT_LEVEL_MAJOR 0x10000
+/* ... the same for level_dim 4 (the reference's own waymo.gin grid): [F / 4][M][4], / 6. */
+#define UCN_GFEAT_LEVEL_MAJOR4 0x20000
 int ucn_train_bwd(const void *gy, const void *graw, const float *head, const float *density, const float *rgb,
                   const void *packed_t, const uint32_t *m0, const void *m1, const void *m2, uint32_t N, uint32_t S,
                   uint32_t F, void *d1, void *d0, void *gx, void *gh0, void *dy /*[M, dy_ld] bf16 | NULL: the colour-logit

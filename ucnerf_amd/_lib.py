@@ -15,6 +15,7 @@ ABI_VERSION = 26
 LAUNCH_CORESIDENT = 0x100
 TABLE_F16 = 0x200
 RAYS_INCOHERENT = 0x1000   # ucn_march_features layout flag: random (training) rays -> lane-paired fetch on every hashed level
+GFEAT_LEVEL_MAJOR4 = 0x20000  # ... for level_dim 4: [F / 4][M][4], / 6
 GFEAT_LEVEL_MAJOR = 0x10000  # ucn_train_bwd F flag: gfeat as [F / 2][M][2], / 6 = ucn_march_features_backward's layout 4 (include/ucnerf_march.h)
 BWD_FIXED_POINT = 0x800    # ucn_march_features_backward layout flag: int32 fixed-point row blocks (include/ucnerf_march.h UCN_BWD_FIXED_POINT)
 FEATURES_BF16 = 0x400      # ucn_march_features layout flag: features as [L][B] bf16 pairs (half tables, level_dim 2)

@@ -366,7 +366,7 @@ struct TrainBwdArgs {
     uint32_t ld_dy;                   // row stride of dy in elements (4, or 32: a zero-padded tile that ucn_wgrad_bf16 takes as its A operand)
     float *gfeat;                     // [M, F]; lm: [F / 2][M][2], every value / 6
     uint32_t M, F;
-    uint32_t lm;                      // 1: the feature gradient as ucn_march_features_backward's layout 4 wants it (r06, VERDICT r05 item 2 c)
+    uint32_t lm;                      // 1 (level_dim 2) / 2 (level_dim 4): the feature gradient as ucn_march_features_backward's layout 4 wants it (r06, VERDICT r05 item 2 c)
 };
 
 
@@ -516,10 +516,13 @@ __global__ __launch_bounds__(64 * kTrainWaves, kTrainWaves == 8 ? 1 : UCN_TRAIN_
                     // level-major pairs (level_dim 2: features 2 l, 2 l + 1 = level l), divided by the 6 multisamples of the mean with the
                     // same IEEE division the mask pass of the table gradient applied to this layout's row-major form: 32 lanes = 32
                     // consecutive samples = 256 contiguous bytes per level
-                    if (f0 + 3 < a.F) {
+                    if (f0 + 3 < a.F && a.lm == 1u) {
                         float2 *o = reinterpret_cast<float2 *>(a.gfeat);
                         o[(size_t)(f0 / 2u) * a.M + sample] = make_float2(gf[ft][4 * q] / 6.0f, gf[ft][4 * q + 1] / 6.0f);
                         o[(size_t)(f0 / 2u + 1u) * a.M + sample] = make_float2(gf[ft][4 * q + 2] / 6.0f, gf[ft][4 * q + 3] / 6.0f);
+                    } else if (f0 + 3 < a.F) {                                 // level_dim 4 (the reference's own waymo.gin grid): one level per quad
+                        reinterpret_cast<float4 *>(a.gfeat)[(size_t)(f0 / 4u) * a.M + sample] =
+                            make_float4(gf[ft][4 * q] / 6.0f, gf[ft][4 * q + 1] / 6.0f, gf[ft][4 * q + 2] / 6.0f, gf[ft][4 * q + 3] / 6.0f);
                     }
                 } else if (f0 + 3 < a.F && a.F % 4 == 0) {
                     *reinterpret_cast<float4 *>(a.gfeat + (size_t)sample * a.F + f0) =
@@ -589,8 +592,8 @@ extern "C" int ucn_train_bwd(const void *gy, const void *graw, const float *head
     const uint64_t M = (uint64_t)N * S;
     if (M == 0) return 0;
     UCN_REQUIRE(gy && packed_t && m0 && m1 && m2 && d1 && d0 && gh0 && gfeat, "train_bwd: null pointer argument");
-    const uint32_t lm = (F & UCN_GFEAT_LEVEL_MAJOR) ? 1u : 0u;
-    F &= ~(uint32_t)UCN_GFEAT_LEVEL_MAJOR;
+    const uint32_t lm = (F & UCN_GFEAT_LEVEL_MAJOR) ? 1u : ((F & UCN_GFEAT_LEVEL_MAJOR4) ? 2u : 0u);
+    F &= ~(uint32_t)(UCN_GFEAT_LEVEL_MAJOR | UCN_GFEAT_LEVEL_MAJOR4);
     UCN_REQUIRE(F >= 1 && F <= 64, "train_bwd: 1..64 input features, got %u", F);
     UCN_REQUIRE(!lm || F % 4u == 0u, "train_bwd: the level-major feature gradient needs F %% 4 == 0 (pairs of level_dim 2), got %u", F);
     UCN_REQUIRE(M < 0xFFFFFF00ull, "train_bwd: too many samples");

@@ -72,7 +72,7 @@ class _FieldFeatures(torch.autograd.Function):
             # gradient may come back LEVEL-MAJOR and already divided by 6 (ucn_march_features_backward's layout 4: no copy, no division in
             # the mask pass), if the table gradient of this call runs on the row-block kernel
             chan.feat_ptr = chan.lm = None
-            if C == 2 and lib.ucn_march_features_backward_row_blocks(ctypes.byref(mlp.grid_field()), N, S) == 1:
+            if C in (2, 4) and lib.ucn_march_features_backward_row_blocks(ctypes.byref(mlp.grid_field()), N, S) == 1:
                 chan.feat_ptr, chan.levels, chan.level_dim = feat.data_ptr(), L, C
         return feat, coord, tmean
 
@@ -730,10 +730,10 @@ class _FusedHeads(torch.autograd.Function):
             gfeat = torch.empty(M, F_in, device=dev)
             lm = ctx.chan is not None and f_dt == torch.float32
             if lm:
-                ctx.chan.lm = gfeat.data_ptr()                        # the same bytes as [F_in / 2][M][2], every value / 6
+                ctx.chan.lm = gfeat.data_ptr()                        # the same bytes as [levels][M][level_dim], every value / 6
             hd = (ctypes.c_float * 4)(*head)
             _lib.check(lib.ucn_train_bwd(g_rgb.data_ptr(), _lib.ptr(g_density), hd, density.data_ptr(), rgb.data_ptr(),
-                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in | (_lib.GFEAT_LEVEL_MAJOR if lm else 0),
+                                         packed_t.data_ptr(), m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), N, S, F_in | ((_lib.GFEAT_LEVEL_MAJOR if ctx.chan.level_dim == 2 else _lib.GFEAT_LEVEL_MAJOR4) if lm else 0),
                                          d1.data_ptr(), d0.data_ptr(), _lib.ptr(gx), gh0.data_ptr(), dy.data_ptr(), dy.shape[1], gfeat.data_ptr(),
                                          _lib.stream()))
             # [NW, NW + NB] and [NW, 32]: as ONE 544-column GEMM the library picks a kernel twice as slow (602 us against
