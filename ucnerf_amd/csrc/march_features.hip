@@ -1014,7 +1014,12 @@ static bool make_mask_plan(const UcnLevels &lv, uint32_t rpb, size_t B, MaskPlan
         static const int coarse_res_env = getenv("UCN_BWD_COARSE_RES") ? atoi(getenv("UCN_BWD_COARSE_RES")) : -1;                 // experiment knob
         const uint32_t coarse_res = coarse_res_env >= 0 ? (uint32_t)coarse_res_env : (fixed_rows ? 64u : 512u);
         mp->coarse[l] = lv.lv[l].resolution <= coarse_res ? 1 : 0;
-        if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= 64u) mp->coarse[l] = 2;
+        // (experiment knob, r06: under fixed-point rows the plain sample item is cheaper than the walk on the dense levels too -- 17.1 / 19.4 /
+        // 39.1 -> 12.7 / 16.3 / 32.3 ms-CU, call 3.205 -> 3.164 ms, step -0.05 ... -0.1 ms -- but merging runs ACROSS six samples also means six
+        // times fewer ROUNDED addends on exactly the rows that collect the most samples: 2.4 x the fixed-point noise there (a fuzz case of
+        // 640 000 random-sign gradients went from < 1e-3 to 1.24e-3 of the largest entry) for 1 % of the step.  Not taken: 64 for both row types)
+        static const uint32_t runs_res = getenv("UCN_BWD_RUNS_RES") ? (uint32_t)atoi(getenv("UCN_BWD_RUNS_RES")) : 64u;
+        if (mp->coarse[l] && !lv.lv[l].hashed && lv.lv[l].resolution <= runs_res) mp->coarse[l] = 2;
         // More than 32 row blocks per level (the reference's own waymo.gin grid: T = 2^21 rows of C = 4 -> 256 blocks of 8192 rows):
         // the per-point masks of the point-item shapes would need 6 bits x 256 blocks per sample and level, so such a level goes by
         // SAMPLE items as well -- one bit per (sample, block) in nb / 32 mask words -- with the unmerged per-point scatter (a point's
