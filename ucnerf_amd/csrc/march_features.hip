@@ -978,6 +978,9 @@ static GradStrides grad_strides(int layout, size_t B, uint32_t L, uint32_t C) {
 #define UCN_KSCAN 4
 #endif
 constexpr uint32_t kScan = UCN_KSCAN;                          // samples per thread and scan step (8 measured: see DESIGN)
+#ifndef UCN_MASKS_MIN_BLOCKS
+#define UCN_MASKS_MIN_BLOCKS 1                           // experiment knob (r06): workgroups per CU the mask pass is compiled for.  8 = 64 registers (4 spilled), 8 waves per SIMD instead of 5 at 95: the autocast step's pass 0.419 -> 0.374 ms, but the fp32 step (row-major gradient copied and divided here) 14.52 -> 14.70 ms; 6 = 67 registers: 0.399 ms.  Not taken
+#endif
 #ifndef UCN_BWD_BYTE_MASKS_DEFAULT
 #define UCN_BWD_BYTE_MASKS_DEFAULT 1
 #endif
@@ -1128,7 +1131,7 @@ __device__ __forceinline__ uint32_t point_block_mask(const UcnLevel &lv, uint32_
 }
 
 // geometry planes + block masks of every sample, once per backward call
-__global__ __launch_bounds__(256) void k_cast_cache_masks(UcnLevels lvls, RayInputs in, HexPattern hx, float std_scale,
+__global__ __launch_bounds__(256, UCN_MASKS_MIN_BLOCKS) void k_cast_cache_masks(UcnLevels lvls, RayInputs in, HexPattern hx, float std_scale,
                                                           uint32_t N, uint32_t S, MaskPlan plan,
                                                           const float *__restrict__ grad_features, GradStrides gs, uint32_t C,
                                                           float *__restrict__ geom, uint32_t *__restrict__ masks,
